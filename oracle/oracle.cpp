@@ -1,0 +1,1428 @@
+// oracle.cpp -- CPU restatement of the lashhw/rtcuda render path.  TEST INFRASTRUCTURE ONLY.
+//
+// This file is the checker for the HIP path, never the product: only tests/, bench.py's
+// cpu_baseline leg and __graft_entry__.smoke() may load it.  Nothing under rtcuda_amd/ links,
+// imports or calls it.
+//
+// What it restates (file:line into the reference tree; nothing is copied, every function is
+// re-written from the behaviour read there):
+//   vec3.cuh:32-147          V3 arithmetic forms (Vec3/float == multiply by reciprocal, ...)
+//   triangle.cuh:6-86        precomputed {p0,e1,e2,n}, ray/triangle test, area sampling
+//   bounding_box.cuh:18-37   bounds layout [xmin,xmax,ymin,ymax,zmin,zmax], half_area
+//   aabb_intersector.cuh     per-ray octant / inverse direction / scaled origin, slab test
+//   bvh.cuh:30-219           full-sweep SAH builder (std::sort + std::stable_partition)
+//   bvh.cuh:221-357          closest-hit and any-hit stack traversal over sibling pairs
+//   material.cuh:46-109      MATTE / MIRROR / GLASS eval + sample
+//   light.cuh:29-64          point / area light sample + pdf
+//   camera.cuh:15-34         pinhole camera ctor + get_ray
+//   utility.cuh:31-77        Waechter-Binder origin offset, int-truncating power heuristic, samplers
+//   render.cuh:61-338        the nine stage kernels
+//   render.cuh:366-457       the host wavefront loop (literal schedule, W = 1048576 slots)
+//
+// Third-party arithmetic that is NOT in /root/reference:
+//   * cuRAND XORWOW device API (CUDA toolkit, version unpinned by the reference).  Restated from
+//     the published algorithm: Marsaglia xorwow + Weyl 362437, seed scramble constants of
+//     curand_kernel.h, subsequence stride 2^67 applied as a GF(2) linear map, uniform =
+//     x*2^-32 + 2^-33.  The scramble constants cannot be verified offline: RNG PARITY UNPINNED
+//     against a real CUDA toolkit; pinned against SURVEY.md Appendix C known answers.
+//   * CUB DeviceSelect::Flagged: semantics only (stable select).
+//   * libm/libdevice sincosf, powf: build with -DORC_LIBM to call glibc (reproduces the
+//     SURVEY.md Appendix C image hashes recorded in this container); the default build uses the
+//     pinned fp32 sequences of rtcuda_amd/csrc/rt_pinned_math.h so the GPU can match bit for bit.
+//
+// Parity status: the reference ships no tests, golden images or fixtures, and it cannot be
+// built here (needs nvcc + cuRAND + CUB; none present, and stand-ins are not allowed), so this
+// oracle is pinned ONLY by the known-answer values SURVEY.md Appendix C records.
+//
+// Build: see oracle/Makefile (g++ -O2 -std=c++17 -ffp-contract=off -fwrapv -fopenmp).
+
+#include <algorithm>
+#include <array>
+#include <cassert>
+#include <cfloat>
+#include <climits>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <numeric>
+#include <stack>
+#include <vector>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#include "../rtcuda_amd/csrc/rt_pinned_math.h"
+
+namespace {
+
+// ---------------------------------------------------------------- constants (constant.hpp:4-10)
+constexpr float kPi = 3.14159265358979323846f;
+constexpr float kTwoPi = 6.28318530717958647692f;
+constexpr float kInvPi = 0.31830988618379067153f;
+constexpr int kBvhMaxDepth = 30;
+constexpr int kW = 1048576;  // NUM_WORKING_PATHS
+constexpr float kRrThreshold = 1.f;
+constexpr int kRrStart = 4;
+
+// ---------------------------------------------------------------- V3 (vec3.cuh)
+struct V3 {
+    float x, y, z;
+};
+inline V3 mk(float x, float y, float z) { return V3{x, y, z}; }
+inline V3 neg(V3 a) { return mk(-a.x, -a.y, -a.z); }
+inline V3 add(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+inline V3 sub(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+inline V3 mul(V3 a, V3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+inline V3 scale(V3 a, float t) { return mk(a.x * t, a.y * t, a.z * t); }
+// vec3.cuh:56-59 -- Vec3 / float multiplies by the reciprocal
+inline V3 divf(V3 a, float t) {
+    float inv_t = 1.f / t;
+    return mk(a.x * inv_t, a.y * inv_t, a.z * inv_t);
+}
+inline float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline V3 cross(V3 a, V3 b) {
+    return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+inline float len2(V3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
+inline float len(V3 a) { return sqrtf(a.x * a.x + a.y * a.y + a.z * a.z); }
+inline V3 unit(V3 a) {
+    float inv_len = 1.f / len(a);
+    return mk(a.x * inv_len, a.y * inv_len, a.z * inv_len);
+}
+inline float max3(V3 a) { return fmaxf(fmaxf(a.x, a.y), a.z); }
+// vec3.cuh:71-73
+inline V3 reflect(V3 v, V3 n) { return sub(v, scale(n, 2.f * dot(v, n))); }
+// vec3.cuh:82-86 (4-argument form; the double eta converts back to float in operator*(float,Vec3))
+inline V3 refract4(V3 unit_v, V3 unit_n, float eta_ratio, float cos_theta) {
+    V3 v_parallel = scale(add(unit_v, scale(unit_n, cos_theta)), eta_ratio);
+    V3 v_perp = scale(unit_n, -sqrtf(1.f - len2(v_parallel)));
+    return add(v_parallel, v_perp);
+}
+
+inline float int_as_float(int32_t i) {
+    float f;
+    memcpy(&f, &i, 4);
+    return f;
+}
+inline int32_t float_as_int(float f) {
+    int32_t i;
+    memcpy(&i, &f, 4);
+    return i;
+}
+
+// ---------------------------------------------------------------- XORWOW (cuRAND, restated)
+struct Xorwow {
+    uint32_t d, v[5];
+};
+
+struct JumpTable {
+    // image of each of the 160 basis bits under A^(2^67); plus byte-indexed lookup for speed
+    uint32_t row[160][5];
+    uint32_t byte_lut[20][256][5];
+};
+
+void xorwow_linear_step(uint32_t v[5]) {
+    uint32_t t = v[0] ^ (v[0] >> 2);
+    v[0] = v[1];
+    v[1] = v[2];
+    v[2] = v[3];
+    v[3] = v[4];
+    v[4] = (v[4] ^ (v[4] << 4)) ^ (t ^ (t << 1));
+}
+
+void matvec160(const uint32_t m[160][5], const uint32_t in[5], uint32_t out[5]) {
+    uint32_t r[5] = {0, 0, 0, 0, 0};
+    for (int w = 0; w < 5; w++)
+        for (int b = 0; b < 32; b++)
+            if (in[w] & (1u << b))
+                for (int k = 0; k < 5; k++) r[k] ^= m[w * 32 + b][k];
+    memcpy(out, r, sizeof(r));
+}
+
+const JumpTable &jump_table() {
+    static JumpTable *jt = nullptr;
+    if (jt) return *jt;
+    auto *t = new JumpTable;
+    // A: one step of the 160-bit linear part
+    static uint32_t a[160][5], b[160][5];
+    for (int w = 0; w < 5; w++)
+        for (int bit = 0; bit < 32; bit++) {
+            uint32_t v[5] = {0, 0, 0, 0, 0};
+            v[w] = 1u << bit;
+            xorwow_linear_step(v);
+            memcpy(a[w * 32 + bit], v, sizeof(v));
+        }
+    // square 67 times: A^(2^67)
+    for (int s = 0; s < 67; s++) {
+        for (int i = 0; i < 160; i++) matvec160(a, a[i], b[i]);
+        memcpy(a, b, sizeof(a));
+    }
+    memcpy(t->row, a, sizeof(a));
+    for (int byte = 0; byte < 20; byte++)
+        for (int val = 0; val < 256; val++) {
+            uint32_t r[5] = {0, 0, 0, 0, 0};
+            for (int bit = 0; bit < 8; bit++)
+                if (val & (1 << bit))
+                    for (int k = 0; k < 5; k++) r[k] ^= a[byte * 8 + bit][k];
+            memcpy(t->byte_lut[byte][val], r, sizeof(r));
+        }
+    jt = t;
+    return *jt;
+}
+
+inline void jump_once(const JumpTable &jt, uint32_t v[5]) {
+    uint32_t r[5] = {0, 0, 0, 0, 0};
+    for (int w = 0; w < 5; w++)
+        for (int by = 0; by < 4; by++) {
+            const uint32_t *e = jt.byte_lut[w * 4 + by][(v[w] >> (8 * by)) & 0xff];
+            for (int k = 0; k < 5; k++) r[k] ^= e[k];
+        }
+    memcpy(v, r, sizeof(r));
+}
+
+// curand_init(seed, subsequence = 0, offset = 0): seed scramble only
+Xorwow xorwow_seed(uint64_t seed) {
+    uint32_t s0 = ((uint32_t)seed) ^ 0xaad26b49u;
+    uint32_t s1 = ((uint32_t)(seed >> 32)) ^ 0xf7dcefddu;
+    uint32_t t0 = 1099087573u * s0;
+    uint32_t t1 = 2591861531u * s1;
+    Xorwow st;
+    st.d = 6615241u + t1 + t0;
+    st.v[0] = 123456789u + t0;
+    st.v[1] = 362436069u ^ t0;
+    st.v[2] = 521288629u + t1;
+    st.v[3] = 88675123u ^ t1;
+    st.v[4] = 5783321u + t0;
+    return st;
+}
+
+// curand_init(seed, subsequence, 0): skip subsequence * 2^67 draws.  d is unchanged because
+// 362437 * 2^67 == 0 (mod 2^32).
+Xorwow xorwow_init(uint64_t seed, uint32_t subsequence) {
+    const JumpTable &jt = jump_table();
+    Xorwow st = xorwow_seed(seed);
+    // J^subsequence by square-and-multiply on the vector would need J^(2^k); the table only
+    // holds J, so walk.  Callers that need many consecutive subsequences use xorwow_init_range.
+    for (uint32_t i = 0; i < subsequence; i++) jump_once(jt, st.v);
+    return st;
+}
+
+// states for subsequences [first, first+count): one jump per state
+void xorwow_init_range(uint64_t seed, uint32_t first, uint32_t count, Xorwow *out) {
+    if (count == 0) return;
+    const JumpTable &jt = jump_table();
+    Xorwow st = xorwow_seed(seed);
+    // reach `first` with base-4096 giant steps cached lazily
+    static std::vector<std::array<uint32_t, 5>> giant;  // state at multiples of 4096 (seed-specific)
+    static uint64_t giant_seed = ~0ull;
+    if (giant_seed != seed) {
+        giant.clear();
+        giant_seed = seed;
+    }
+    uint32_t g = first / 4096;
+    if (giant.empty()) giant.push_back({st.v[0], st.v[1], st.v[2], st.v[3], st.v[4]});
+    while (giant.size() <= g) {
+        uint32_t v[5];
+        memcpy(v, giant.back().data(), sizeof(v));
+        for (int i = 0; i < 4096; i++) jump_once(jt, v);
+        giant.push_back({v[0], v[1], v[2], v[3], v[4]});
+    }
+    memcpy(st.v, giant[g].data(), sizeof(st.v));
+    for (uint32_t i = g * 4096; i < first; i++) jump_once(jt, st.v);
+    for (uint32_t i = 0; i < count; i++) {
+        out[i] = st;
+        jump_once(jt, st.v);
+    }
+}
+
+inline uint32_t xorwow_next(Xorwow &s) {
+    uint32_t t = s.v[0] ^ (s.v[0] >> 2);
+    s.v[0] = s.v[1];
+    s.v[1] = s.v[2];
+    s.v[2] = s.v[3];
+    s.v[3] = s.v[4];
+    s.v[4] = (s.v[4] ^ (s.v[4] << 4)) ^ (t ^ (t << 1));
+    s.d += 362437u;
+    return s.v[4] + s.d;
+}
+
+inline float uniform_from_u32(uint32_t x) { return (float)x * 2.3283064e-10f + (2.3283064e-10f / 2.0f); }
+inline float rnd(Xorwow &s) { return uniform_from_u32(xorwow_next(s)); }
+
+// ---------------------------------------------------------------- geometry
+struct Ray {
+    V3 o, d;
+    float tmax;
+};
+struct Isect {
+    float t, u, v;
+};
+struct BBox {
+    float b[6];  // bounding_box.cuh:15
+    void reset() {
+        b[0] = b[2] = b[4] = FLT_MAX;
+        b[1] = b[3] = b[5] = -FLT_MAX;
+    }
+    void extend(const BBox &o) {
+        b[0] = fminf(b[0], o.b[0]);
+        b[1] = fmaxf(b[1], o.b[1]);
+        b[2] = fminf(b[2], o.b[2]);
+        b[3] = fmaxf(b[3], o.b[3]);
+        b[4] = fminf(b[4], o.b[4]);
+        b[5] = fmaxf(b[5], o.b[5]);
+    }
+    float half_area() const {
+        float e1 = b[1] - b[0];
+        float e2 = b[3] - b[2];
+        float e3 = b[5] - b[4];
+        return (e1 + e2) * e3 + e1 * e2;
+    }
+};
+
+struct Tri {  // triangle.cuh:6-7
+    V3 p0, e1, e2, n;
+    Tri() {}
+    Tri(V3 a, V3 b, V3 c) : p0(a), e1(sub(a, b)), e2(sub(c, a)), n(cross(sub(a, b), sub(c, a))) {}
+    V3 p1() const { return sub(p0, e1); }
+    V3 p2() const { return add(p0, e2); }
+    V3 center() const { return scale(add(add(p0, p1()), p2()), 1.f / 3.f); }
+    BBox bbox() const {
+        BBox r;
+        V3 a = p1(), c = p2();
+        r.b[0] = fminf(p0.x, fminf(a.x, c.x));
+        r.b[2] = fminf(p0.y, fminf(a.y, c.y));
+        r.b[4] = fminf(p0.z, fminf(a.z, c.z));
+        r.b[1] = fmaxf(p0.x, fmaxf(a.x, c.x));
+        r.b[3] = fmaxf(p0.y, fmaxf(a.y, c.y));
+        r.b[5] = fmaxf(p0.z, fmaxf(a.z, c.z));
+        return r;
+    }
+    // triangle.cuh:39-58
+    bool intersect(const Ray &ray, Isect &is) const {
+        V3 c = sub(p0, ray.o);
+        V3 r = cross(ray.d, c);
+        float inv_det = 1.f / dot(ray.d, n);
+        float u = inv_det * dot(e2, r);
+        float v = inv_det * dot(e1, r);
+        if (u >= 0.0f && v >= 0.0f && (u + v) <= 1.0f) {
+            float t = inv_det * dot(c, n);
+            if (0 < t && t <= ray.tmax) {
+                is.t = t;
+                is.u = u;
+                is.v = v;
+                return true;
+            }
+        }
+        return false;
+    }
+    V3 p(float u, float v) const { return add(sub(p0, scale(e1, u)), scale(e2, v)); }  // :15
+    float area() const { return (float)(0.5 * len(n)); }                                 // :84-86
+    V3 sample_p(Xorwow &rs, float &pdf) const {                                          // :78-82
+        pdf = 1.f / area();
+        float a = sqrtf(rnd(rs));
+        float u2 = rnd(rs);
+        return p(1 - a, u2 * a);
+    }
+};
+
+struct Material {  // material.cuh:10-23; type 0 MATTE, 1 MIRROR, 2 GLASS
+    V3 albedo;
+    float ior;
+    int type;
+};
+struct Light {  // light.cuh:9-27; type 0 POINT, 1 AREA
+    int type;
+    V3 pos;
+    int tri;  // index into Scene::tris (reference: Triangle*)
+    V3 L;     // I for point light
+};
+struct Prim {  // primitive.cuh:4-12 with pointers flattened to indices
+    int tri, mat, light;  // light = -1 when none
+};
+struct Node {  // bvh.cuh:5-14
+    BBox bbox;
+    int num_prims;
+    int index;  // left_node_index / first_primitive_index
+};
+
+struct TravStats {
+    uint64_t rays = 0, node_pairs = 0, tri_tests = 0;
+    int max_stack = 0;
+};
+
+struct Scene {
+    std::vector<Tri> tris;
+    std::vector<Material> mats;
+    std::vector<Light> lights;
+    std::vector<Prim> prims;  // reordered by the BVH builder (bvh.cuh:208)
+    std::vector<Node> nodes;
+    int max_depth = 0;
+    mutable TravStats st_closest, st_any;
+    bool collect_stats = false;
+};
+
+// ---------------------------------------------------------------- BVH builder (bvh.cuh:30-219)
+void build_bvh(Scene &sc, const std::vector<Prim> &prims_in) {
+    const int n = (int)sc.tris.size();
+    std::vector<BBox> bboxes(n);
+    std::vector<V3> centers(n);
+    std::vector<float> costs(n);
+    std::vector<char> marks(n);
+    std::vector<int> refs_data(3 * (size_t)n);
+    int *refs[3] = {refs_data.data(), refs_data.data() + n, refs_data.data() + 2 * (size_t)n};
+    std::vector<Node> nodes(2 * (size_t)std::max(n, 1));
+    int num_nodes = 1, max_depth = 0;
+    nodes[0].bbox.reset();
+    for (int i = 0; i < n; i++) {
+        bboxes[i] = sc.tris[i].bbox();
+        nodes[0].bbox.extend(bboxes[i]);
+        centers[i] = sc.tris[i].center();
+    }
+    for (int axis = 0; axis < 3; axis++) {
+        std::iota(refs[axis], refs[axis] + n, 0);
+        if (axis == 0)
+            std::sort(refs[0], refs[0] + n, [&](int i, int j) { return centers[i].x < centers[j].x; });
+        else if (axis == 1)
+            std::sort(refs[1], refs[1] + n, [&](int i, int j) { return centers[i].y < centers[j].y; });
+        else
+            std::sort(refs[2], refs[2] + n, [&](int i, int j) { return centers[i].z < centers[j].z; });
+    }
+    std::stack<std::array<int, 4>> stk;
+    int node_index = 0, begin = 0, end = n, depth = 0;
+    auto pop = [&]() -> bool {
+        if (stk.empty()) return false;
+        node_index = stk.top()[0];
+        begin = stk.top()[1];
+        end = stk.top()[2];
+        depth = stk.top()[3];
+        stk.pop();
+        return true;
+    };
+    while (true) {
+        Node &cur = nodes[node_index];
+        int cnt = end - begin;
+        if (cnt <= 1 || depth >= kBvhMaxDepth) {
+            cur.num_prims = cnt;
+            cur.index = begin;
+            if (pop()) continue;
+            break;
+        }
+        float best_cost = FLT_MAX;
+        int best_axis = -1, best_split = -1;
+        for (int axis = 0; axis < 3; axis++) {
+            BBox tmp;
+            tmp.reset();
+            for (int i = end - 1; i > begin; i--) {
+                tmp.extend(bboxes[refs[axis][i]]);
+                costs[i] = tmp.half_area() * (end - i);
+            }
+            tmp.reset();
+            for (int i = begin; i < end - 1; i++) {
+                tmp.extend(bboxes[refs[axis][i]]);
+                float cost = tmp.half_area() * (i + 1 - begin) + costs[i + 1];
+                if (cost < best_cost) {
+                    best_cost = cost;
+                    best_axis = axis;
+                    best_split = i + 1;
+                }
+            }
+        }
+        float max_split_cost = cur.bbox.half_area() * (cnt - 1);
+        if (best_cost >= max_split_cost) {
+            cur.num_prims = cnt;
+            cur.index = begin;
+            if (pop()) continue;
+            break;
+        }
+        int li = num_nodes, ri = num_nodes + 1;
+        nodes[li].bbox.reset();
+        nodes[ri].bbox.reset();
+        for (int i = begin; i < best_split; i++) {
+            nodes[li].bbox.extend(bboxes[refs[best_axis][i]]);
+            marks[refs[best_axis][i]] = 1;
+        }
+        for (int i = best_split; i < end; i++) {
+            nodes[ri].bbox.extend(bboxes[refs[best_axis][i]]);
+            marks[refs[best_axis][i]] = 0;
+        }
+        int oa[2] = {(best_axis + 1) % 3, (best_axis + 2) % 3};
+        std::stable_partition(refs[oa[0]] + begin, refs[oa[0]] + end, [&](int i) { return marks[i] != 0; });
+        std::stable_partition(refs[oa[1]] + begin, refs[oa[1]] + end, [&](int i) { return marks[i] != 0; });
+        num_nodes += 2;
+        nodes[node_index].num_prims = 0;
+        nodes[node_index].index = li;
+        max_depth = std::max(max_depth, depth + 1);
+        int left_size = best_split - begin, right_size = end - best_split;
+        if (left_size < right_size) {
+            stk.push({ri, best_split, end, depth + 1});
+            node_index = li;
+            end = best_split;
+            depth = depth + 1;
+        } else {
+            stk.push({li, begin, best_split, depth + 1});
+            node_index = ri;
+            begin = best_split;
+            depth = depth + 1;
+        }
+    }
+    sc.prims.resize(n);
+    for (int i = 0; i < n; i++) sc.prims[i] = prims_in[refs[0][i]];
+    nodes.resize(num_nodes);
+    sc.nodes.swap(nodes);
+    sc.max_depth = max_depth;
+}
+
+// ---------------------------------------------------------------- traversal
+struct AabbIsect {  // aabb_intersector.cuh:14-36
+    int ox, oy, oz;
+    V3 inv, so;
+    explicit AabbIsect(const Ray &ray) {
+        ox = ray.d.x < 0 ? 1 : 0;
+        oy = ray.d.y < 0 ? 1 : 0;
+        oz = ray.d.z < 0 ? 1 : 0;
+        float ix = 1.f / ((fabsf(ray.d.x) < FLT_EPSILON) ? copysignf(FLT_EPSILON, ray.d.x) : ray.d.x);
+        float iy = 1.f / ((fabsf(ray.d.y) < FLT_EPSILON) ? copysignf(FLT_EPSILON, ray.d.y) : ray.d.y);
+        float iz = 1.f / ((fabsf(ray.d.z) < FLT_EPSILON) ? copysignf(FLT_EPSILON, ray.d.z) : ray.d.z);
+        inv = mk(ix, iy, iz);
+        so = mul(neg(ray.o), inv);
+    }
+    bool hit(const BBox &bb, float &entry) const {
+        float ex = inv.x * bb.b[0 + ox] + so.x;
+        float ey = inv.y * bb.b[2 + oy] + so.y;
+        float ez = inv.z * bb.b[4 + oz] + so.z;
+        entry = fmaxf(ex, fmaxf(ey, ez));
+        float xx = inv.x * bb.b[1 - ox] + so.x;
+        float xy = inv.y * bb.b[3 - oy] + so.y;
+        float xz = inv.z * bb.b[5 - oz] + so.z;
+        float exit = fminf(xx, fminf(xy, xz));
+        return entry <= exit;
+    }
+};
+
+struct Stack {  // device_stack.cuh:4-11
+    int data[kBvhMaxDepth - 1];
+    int size = 0;
+    void push(int v) { data[size++] = v; }
+    int pop() { return data[--size]; }
+    bool empty() const { return size == 0; }
+};
+
+// bvh.cuh:222-236
+bool leaf_closest(const Scene &sc, const Node &nd, Ray &ray, Isect &is, int &prim, TravStats *st) {
+    bool hit = false;
+    for (int i = nd.index; i < nd.index + nd.num_prims; i++) {
+        if (st) st->tri_tests++;
+        if (sc.tris[sc.prims[i].tri].intersect(ray, is)) {
+            hit = true;
+            prim = i;
+            ray.tmax = is.t;
+        }
+    }
+    return hit;
+}
+// bvh.cuh:239-248
+bool leaf_any(const Scene &sc, int excluded_tri, const Node &nd, const Ray &ray, TravStats *st) {
+    for (int i = nd.index; i < nd.index + nd.num_prims; i++) {
+        if (st) st->tri_tests++;
+        Isect tmp;
+        if (sc.tris[sc.prims[i].tri].intersect(ray, tmp) && sc.prims[i].tri != excluded_tri) return true;
+    }
+    return false;
+}
+
+// bvh.cuh:251-303
+bool traverse_closest(const Scene &sc, Ray &ray, Isect &is, int &prim, TravStats *st) {
+    if (st) st->rays++;
+    const Node *nodes = sc.nodes.data();
+    if (nodes[0].num_prims > 0) return leaf_closest(sc, nodes[0], ray, is, prim, st);
+    bool hit = false;
+    AabbIsect ai(ray);
+    Stack stack;
+    int left = nodes[0].index;
+    while (true) {
+        if (st) st->node_pairs++;
+        int right = left + 1;
+        bool lv = true, rv = true;
+        float el, er;
+        if (ai.hit(nodes[left].bbox, el)) {
+            if (nodes[left].num_prims > 0) {
+                hit |= leaf_closest(sc, nodes[left], ray, is, prim, st);
+                lv = false;
+            }
+        } else {
+            lv = false;
+        }
+        if (ai.hit(nodes[right].bbox, er)) {
+            if (nodes[right].num_prims > 0) {
+                hit |= leaf_closest(sc, nodes[right], ray, is, prim, st);
+                rv = false;
+            }
+        } else {
+            rv = false;
+        }
+        if (lv) {
+            if (rv) {
+                if (el > er) {
+                    stack.push(nodes[left].index);
+                    left = nodes[right].index;
+                } else {
+                    stack.push(nodes[right].index);
+                    left = nodes[left].index;
+                }
+                if (st && stack.size > st->max_stack) st->max_stack = stack.size;
+            } else {
+                left = nodes[left].index;
+            }
+        } else if (rv) {
+            left = nodes[right].index;
+        } else {
+            if (stack.empty()) break;
+            left = stack.pop();
+        }
+    }
+    return hit;
+}
+
+// bvh.cuh:306-357
+bool traverse_any(const Scene &sc, int excluded_tri, const Ray &ray, TravStats *st) {
+    if (st) st->rays++;
+    const Node *nodes = sc.nodes.data();
+    if (nodes[0].num_prims > 0) return leaf_any(sc, excluded_tri, nodes[0], ray, st);
+    AabbIsect ai(ray);
+    Stack stack;
+    int left = nodes[0].index;
+    while (true) {
+        if (st) st->node_pairs++;
+        int right = left + 1;
+        bool lv = true, rv = true;
+        float el, er;
+        if (ai.hit(nodes[left].bbox, el)) {
+            if (nodes[left].num_prims > 0) {
+                if (leaf_any(sc, excluded_tri, nodes[left], ray, st)) return true;
+                lv = false;
+            }
+        } else {
+            lv = false;
+        }
+        if (ai.hit(nodes[right].bbox, er)) {
+            if (nodes[right].num_prims > 0) {
+                if (leaf_any(sc, excluded_tri, nodes[right], ray, st)) return true;
+                rv = false;
+            }
+        } else {
+            rv = false;
+        }
+        if (lv) {
+            if (rv) {
+                if (el > er) {
+                    stack.push(nodes[left].index);
+                    left = nodes[right].index;
+                } else {
+                    stack.push(nodes[right].index);
+                    left = nodes[left].index;
+                }
+                if (st && stack.size > st->max_stack) st->max_stack = stack.size;
+            } else {
+                left = nodes[left].index;
+            }
+        } else if (rv) {
+            left = nodes[right].index;
+        } else {
+            if (stack.empty()) break;
+            left = stack.pop();
+        }
+    }
+    return false;
+}
+
+// ---------------------------------------------------------------- utility.cuh
+// :31-47
+V3 offset_ray_origin(V3 p, V3 n) {
+    const float int_scale = 256.f;
+    const float float_scale = 1.f / 65536.f;
+    const float origin = 1.f / 32.f;
+    int ox = (int)(int_scale * n.x);
+    int oy = (int)(int_scale * n.y);
+    int oz = (int)(int_scale * n.z);
+    float px = int_as_float(float_as_int(p.x) + (p.x < 0 ? -ox : ox));
+    float py = int_as_float(float_as_int(p.y) + (p.y < 0 ? -oy : oy));
+    float pz = int_as_float(float_as_int(p.z) + (p.z < 0 ? -oz : oz));
+    return mk(fabsf(p.x) < origin ? p.x + float_scale * n.x : px,
+              fabsf(p.y) < origin ? p.y + float_scale * n.y : py,
+              fabsf(p.z) < origin ? p.z + float_scale * n.z : pz);
+}
+Ray spawn_offset_ray(V3 o, V3 n, V3 d, float tmax = FLT_MAX) { return Ray{offset_ray_origin(o, n), d, tmax}; }
+
+// :53-56 -- g_pdf is an int parameter: the float argument truncates.  Out-of-range conversions
+// are UB in C++ and saturate on CUDA; neither reaches the image, so
+// the conversion is made well-defined here (saturate) and the square wraps.
+float power_heuristic(float f_pdf, float g_pdf_float) {
+    int g;
+    if (!(g_pdf_float == g_pdf_float)) g = 0;
+    else if (g_pdf_float >= 2147483648.f) g = INT_MAX;
+    else if (g_pdf_float <= -2147483648.f) g = INT_MIN;
+    else g = (int)g_pdf_float;
+    float f2 = f_pdf * f_pdf;
+    int gg = (int)((uint32_t)g * (uint32_t)g);
+    return f2 / (f2 + gg);
+}
+inline bool same_hemisphere(V3 wo, V3 wi, V3 n) { return dot(wo, n) * dot(wi, n) < 0.f; }  // :58-60
+
+inline void orc_sincosf(float x, float *s, float *c) {
+#ifdef ORC_LIBM
+    sincosf(x, s, c);
+#else
+    rt_sincosf(x, s, c);
+#endif
+}
+inline float orc_pow5(float x) {
+#ifdef ORC_LIBM
+    return powf(x, 5);
+#else
+    return rt_pow5f(x);
+#endif
+}
+
+// :70-77
+V3 uniform_sample_sphere(Xorwow &rs) {
+    float z = 1 - 2 * rnd(rs);
+    float r = sqrtf(1 - z * z);
+    float phi = kTwoPi * rnd(rs);
+    float x, y;
+    orc_sincosf(phi, &y, &x);
+    return mk(r * x, r * y, z);
+}
+
+// ---------------------------------------------------------------- material.cuh
+// :47-57
+bool mat_get_f(const Material &m, V3 wo, V3 wi, V3 n, V3 &f, float &pdf) {
+    if (m.type == 0) {
+        if (same_hemisphere(wo, wi, n)) {
+            f = scale(m.albedo, kInvPi);
+            pdf = dot(wi, n) * kInvPi;
+            return true;
+        }
+    }
+    return false;
+}
+// :60-109 (mutates n so that n and wi share a hemisphere)
+V3 mat_sample_f(const Material &m, V3 wo, Xorwow &rs, V3 &n, V3 &wi, float &pdf) {
+    if (m.type == 0 || m.type == 1) {
+        if (dot(wo, n) > 0.f) n = neg(n);
+        if (m.type == 0) {
+            wi = unit(add(n, uniform_sample_sphere(rs)));
+            pdf = dot(wi, n) * kInvPi;
+            return scale(m.albedo, kInvPi);
+        } else {
+            wi = reflect(wo, n);
+            pdf = 1.f;
+            return divf(m.albedo, dot(wi, n));
+        }
+    } else {
+        float cos_theta = dot(wo, n);
+        bool front = cos_theta < 0.f;
+        if (front) cos_theta = -cos_theta;
+        float inv_cos = 1.f / cos_theta;
+        float eta = front ? 1.f / m.ior : m.ior;
+        float sin_theta = sqrtf(1.f - cos_theta * cos_theta);
+        bool cannot_refract = eta * sin_theta > 1.f;
+        if (cannot_refract) {
+            if (!front) n = neg(n);
+            wi = reflect(wo, n);
+            pdf = 1.f;
+            return mk(inv_cos, inv_cos, inv_cos);
+        }
+        float r0 = (1 - m.ior) / (1 + m.ior);
+        r0 = r0 * r0;
+        float reflectance = r0 + (1 - r0) * orc_pow5(1 - cos_theta);
+        if (rnd(rs) < reflectance) {
+            if (!front) n = neg(n);
+            wi = reflect(wo, n);
+            pdf = reflectance;
+            float v = pdf * inv_cos;
+            return mk(v, v, v);
+        } else {
+            if (!front) n = neg(n);
+            wi = refract4(wo, n, eta, cos_theta);
+            n = neg(n);
+            pdf = 1.f - reflectance;
+            float v = pdf * eta * eta / dot(wi, n);
+            return mk(v, v, v);
+        }
+    }
+}
+
+// ---------------------------------------------------------------- light.cuh
+// :29-48
+bool light_sample_Li(const Scene &sc, const Light &l, V3 p, Xorwow &rs, V3 &wi, V3 &Li, float &t, float &pdf) {
+    if (l.type == 0) {
+        wi = sub(l.pos, p);
+        t = len(wi);
+        Li = divf(l.L, t * t);
+        wi = divf(wi, t);
+        pdf = 1.f;
+        return true;
+    } else {
+        const Tri &tr = sc.tris[l.tri];
+        V3 tp = tr.sample_p(rs, pdf);
+        wi = sub(tp, p);
+        t = len(wi);
+        wi = divf(wi, t);
+        Li = l.L;
+        pdf *= len2(sub(tp, p)) / fabsf(dot(unit(tr.n), wi));
+        return true;
+    }
+}
+// :50-64
+float light_pdf_Li(const Scene &sc, const Light &l, V3 p, V3 wi) {
+    if (l.type == 0) return 0.f;
+    const Tri &tr = sc.tris[l.tri];
+    Ray r{p, wi, FLT_MAX};
+    Isect is;
+    if (tr.intersect(r, is)) {
+        V3 lp = tr.p(is.u, is.v);
+        V3 ln = unit(tr.n);
+        return len2(sub(lp, p)) / (tr.area() * fabsf(dot(ln, wi)));
+    }
+    return 0.f;
+}
+
+// ---------------------------------------------------------------- camera.cuh
+struct Camera {
+    V3 lookfrom, upper_left, horizontal, vertical;
+};
+Camera make_camera(V3 lookfrom, V3 lookat, V3 up, float vfov, float aspect) {  // :15-29
+    Camera c;
+    c.lookfrom = lookfrom;
+    float vfov_rad = vfov * (kPi / 180.f);
+    float vh = 2.f * tanf(vfov_rad * 0.5f);
+    float vw = vh * aspect;
+    V3 w = unit(sub(lookfrom, lookat));
+    V3 v = unit(sub(up, scale(w, dot(up, w))));
+    V3 u = cross(v, w);
+    c.horizontal = scale(u, vw);
+    c.vertical = scale(v, -vh);
+    c.upper_left = sub(sub(sub(lookfrom, w), scale(c.horizontal, 0.5f)), scale(c.vertical, 0.5f));
+    return c;
+}
+Ray camera_get_ray(const Camera &c, float x, float y) {  // :31-34
+    V3 dir = sub(add(add(c.upper_left, scale(c.horizontal, x)), scale(c.vertical, y)), c.lookfrom);
+    return Ray{c.lookfrom, unit(dir), FLT_MAX};
+}
+
+// ---------------------------------------------------------------- render (render.cuh)
+struct RenderStats {
+    int64_t iterations;
+    int64_t sum_mat, sum_gen, sum_ah, sum_ch;
+    int64_t emission_adds, ah_adds, ch_adds;
+    int64_t rr_draws, rr_kills;
+    double seconds_loop, seconds_rng_init;
+    // traversal statistics (filled when collect_stats)
+    int64_t ch_rays, ch_node_pairs, ch_tri_tests, ah_rays, ah_node_pairs, ah_tri_tests;
+    int32_t max_stack;
+    int32_t n_iter_records;
+};
+
+struct Pools {
+    // RayPool :5-8
+    std::vector<int> pixel_idx;  // 3W
+    std::vector<Ray> ray;        // 3W
+    // PathRayPayload :10-18
+    std::vector<char> hit;
+    std::vector<Isect> isect;
+    std::vector<int> isect_prim;
+    std::vector<int> bounces;
+    std::vector<V3> beta;
+    // ShadowRayPayload x2 :20-23
+    std::vector<int> ah_target, ch_target;
+    std::vector<V3> ah_L, ch_L;
+    // queues :33-46
+    std::vector<int> mat_q, gen_q, ah_q, ch_q;
+    std::vector<char> mat_v, gen_v, ah_v, ch_v;
+    std::vector<int> mat_c, gen_c, ah_c, ch_c;
+    std::vector<Xorwow> rng;
+};
+
+int compact(int n, const int *in, const char *flags, int *out) {  // CUB Flagged: stable select
+    int k = 0;
+    for (int i = 0; i < n; i++)
+        if (flags[i]) out[k++] = in[i];
+    return k;
+}
+
+double now_s() {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec + 1e-9 * ts.tv_nsec;
+}
+
+// Literal restatement of render() (render.cuh:366-457).  slot_lo/slot_hi restrict the slots that
+// are allowed to generate camera rays (used to check partition invariance: the image is the sum of
+// the shards because slot s only ever serves camera rays c == s (mod W)); the full render is
+// [0, W).  fb_sum receives the raw sums, fb_out (optional) the post-processed image.
+void render_literal(const Scene &sc, const Camera &cam, int width, int height, int spp, int max_bounces,
+                    uint64_t seed, int slot_lo, int slot_hi, int threads, float *fb_sum, float *fb_out,
+                    RenderStats *stats, int32_t *iter_counts, int iter_cap) {
+    const int W = kW;
+    const int P = width * height;
+    int cam_start = 0;
+    const int cam_end = P * spp;
+    const int num_lights = (int)sc.lights.size();
+    Pools p;
+    p.pixel_idx.assign(3 * (size_t)W, 0);
+    p.ray.resize(3 * (size_t)W);
+    p.hit.assign(W, 0);
+    p.isect.resize(W);
+    p.isect_prim.assign(W, -1);
+    p.bounces.assign(W, INT_MAX);  // init_path_ray_payload :75-82
+    p.beta.resize(W);
+    p.ah_target.assign(W, -1);
+    p.ch_target.assign(W, -1);
+    p.ah_L.resize(W);
+    p.ch_L.resize(W);
+    p.mat_q.resize(W);
+    p.gen_q.resize(W);
+    p.ah_q.resize(W);
+    p.ch_q.resize(3 * (size_t)W);
+    p.mat_v.resize(W);
+    p.gen_v.resize(W);
+    p.ah_v.resize(W);
+    p.ch_v.resize(3 * (size_t)W);
+    p.mat_c.resize(W);
+    p.gen_c.resize(W);
+    p.ah_c.resize(W);
+    p.ch_c.resize(3 * (size_t)W);
+    p.rng.resize(W);
+    std::vector<V3> fb(P, mk(0, 0, 0));  // init_framebuffer :61-66
+    RenderStats st;
+    memset(&st, 0, sizeof(st));
+    double t0 = now_s();
+    // init_rand_states :68-73 -- one 2^67 jump per slot (byte-LUT mat-vec, ~100 word ops each)
+    xorwow_init_range(seed, 0, W, p.rng.data());
+    double t1 = now_s();
+    st.seconds_rng_init = t1 - t0;
+    std::vector<char> deposit(3 * (size_t)W);
+    const bool cs = sc.collect_stats;
+    int nrec = 0;
+    while (true) {
+        // ---- init() :84-137
+        for (int s = 0; s < W; s++) {
+            p.gen_v[s] = 0;
+            p.mat_v[s] = 0;
+            p.ah_v[s] = 0;
+            p.ch_v[s] = 0;
+            p.ch_v[W + s] = 0;
+            p.ch_v[2 * (size_t)W + s] = 0;
+            bool hit = p.hit[s] != 0;
+            int bounces = p.bounces[s];
+            if (bounces == 0) {
+                if (hit) {
+                    int li = sc.prims[p.isect_prim[s]].light;
+                    if (li >= 0) {
+                        V3 &px = fb[p.pixel_idx[s]];
+                        px.x += sc.lights[li].L.x;
+                        px.y += sc.lights[li].L.y;
+                        px.z += sc.lights[li].L.z;
+                        st.emission_adds++;
+                    }
+                }
+            }
+            bool cont = bounces < max_bounces;
+            if (cont && hit && bounces > kRrStart) {
+                V3 beta = p.beta[s];
+                float bm = max3(beta);
+                if (bm < kRrThreshold) {
+                    float pt = fmaxf(0.05f, 1 - bm);
+                    st.rr_draws++;
+                    if (rnd(p.rng[s]) < pt) {
+                        hit = false;  // local only
+                        st.rr_kills++;
+                    } else {
+                        p.beta[s] = divf(beta, 1 - pt);
+                    }
+                }
+            }
+            p.bounces[s] = (int)((uint32_t)bounces + 1u);  // INT_MAX + 1 wraps (:126)
+            if (cont) {
+                if (hit) {
+                    p.mat_q[s] = s;
+                    p.mat_v[s] = 1;
+                }
+            } else {
+                p.gen_q[s] = s;
+                p.gen_v[s] = 1;
+            }
+        }
+        int n_mat = compact(W, p.mat_q.data(), p.mat_v.data(), p.mat_c.data());
+        int n_gen = compact(W, p.gen_q.data(), p.gen_v.data(), p.gen_c.data());
+        if (n_mat == 0 && cam_start >= cam_end) {  // :436
+            if (iter_counts && nrec < iter_cap) {
+                iter_counts[4 * nrec + 0] = n_mat;
+                iter_counts[4 * nrec + 1] = n_gen;
+                iter_counts[4 * nrec + 2] = 0;
+                iter_counts[4 * nrec + 3] = 0;
+            }
+            nrec++;
+            st.iterations++;
+            st.sum_gen += n_gen;
+            break;
+        }
+        // ---- mat() :139-248
+#pragma omp parallel for num_threads(threads) schedule(static, 4096)
+        for (int tid = 0; tid < n_mat; tid++) {
+            int s = p.mat_c[tid];
+            int pixel = p.pixel_idx[s];
+            V3 wo = p.ray[s].d;
+            Isect is = p.isect[s];
+            const Prim &prim = sc.prims[p.isect_prim[s]];
+            const Material &m = sc.mats[prim.mat];
+            const Tri &tri = sc.tris[prim.tri];
+            V3 multiplier = scale(p.beta[s], (float)num_lights);
+            V3 isect_p = tri.p(is.u, is.v);
+            V3 isect_n = neg(unit(tri.n));
+            Xorwow rs = p.rng[s];
+            {
+                V3 n = isect_n, wi;
+                float pdf;
+                V3 f = mat_sample_f(m, wo, rs, n, wi, pdf);
+                p.ray[s] = spawn_offset_ray(isect_p, n, wi);
+                p.beta[s] = mul(p.beta[s], divf(scale(f, dot(wi, n)), pdf));
+                p.ch_q[W + tid] = s;
+                p.ch_v[W + tid] = 1;
+            }
+            if (num_lights == 0) {
+                p.rng[s] = rs;
+                continue;
+            }
+            int light_idx = std::min((int)(rnd(rs) * num_lights), num_lights - 1);
+            const Light light = sc.lights[light_idx];
+            {
+                V3 wi, Li;
+                float lt, lpdf;
+                if (light_sample_Li(sc, light, isect_p, rs, wi, Li, lt, lpdf)) {
+                    V3 n = dot(isect_n, wi) > 0.f ? isect_n : neg(isect_n);
+                    V3 f;
+                    float spdf;
+                    if (mat_get_f(m, wo, wi, n, f, spdf)) {
+                        f = scale(f, dot(wi, n));
+                        int ah_id = W + s;
+                        p.pixel_idx[ah_id] = pixel;
+                        p.ray[ah_id] = spawn_offset_ray(isect_p, n, wi, lt);
+                        p.ah_target[s] = light.type == 1 ? light.tri : -1;
+                        if (light.type == 0) {
+                            p.ah_L[s] = divf(mul(mul(multiplier, f), Li), lpdf);
+                        } else {
+                            float weight = power_heuristic(lpdf, spdf);
+                            p.ah_L[s] = divf(scale(mul(mul(multiplier, f), Li), weight), lpdf);
+                        }
+                        p.ah_q[tid] = ah_id;
+                        p.ah_v[tid] = 1;
+                    }
+                }
+            }
+            if (light.type != 0) {
+                V3 n = isect_n, wi;
+                float spdf;
+                V3 f = mat_sample_f(m, wo, rs, n, wi, spdf);
+                f = scale(f, dot(wi, n));
+                float weight = 1.f;
+                bool spawn = true;
+                if (!(m.type == 1 || m.type == 2)) {
+                    float lpdf = light_pdf_Li(sc, light, isect_p, wi);
+                    if (lpdf == 0.f) spawn = false;
+                    else weight = power_heuristic(spdf, lpdf);
+                }
+                if (spawn) {
+                    int ch_id = 2 * W + s;
+                    p.pixel_idx[ch_id] = pixel;
+                    p.ray[ch_id] = spawn_offset_ray(isect_p, n, wi);
+                    p.ch_target[s] = prim.tri;  // the SHADING triangle
+                    p.ch_L[s] = divf(scale(mul(mul(multiplier, f), light.L), weight), spdf);
+                    p.ch_q[2 * (size_t)W + tid] = ch_id;
+                    p.ch_v[2 * (size_t)W + tid] = 1;
+                }
+            }
+            p.rng[s] = rs;
+        }
+        // ---- gen() :250-275
+#pragma omp parallel for num_threads(threads) schedule(static, 4096)
+        for (int tid = 0; tid < n_gen; tid++) {
+            int cid = cam_start + tid;
+            if (cid >= cam_end) continue;
+            int s = p.gen_c[tid];
+            if (s < slot_lo || s >= slot_hi) {
+                // sharding hook (no-op for [0, W)): a slot owned by another shard idles through
+                // this generation in lockstep -- it traces nothing and deposits nothing here.
+                p.bounces[s] = 0;
+                p.hit[s] = 0;
+                continue;
+            }
+            int pixel = cid / spp;
+            int i = pixel % width;
+            int j = pixel / width;
+            Xorwow rs = p.rng[s];
+            p.pixel_idx[s] = pixel;
+            float jx = rnd(rs);  // x first, then y
+            float jy = rnd(rs);
+            p.ray[s] = camera_get_ray(cam, (i + jx) / width, (j + jy) / height);
+            p.bounces[s] = 0;
+            p.beta[s] = mk(1.f, 1.f, 1.f);
+            p.rng[s] = rs;
+            p.ch_q[tid] = s;
+            p.ch_v[tid] = 1;
+        }
+        cam_start += n_gen;
+        int n_ah = compact(W, p.ah_q.data(), p.ah_v.data(), p.ah_c.data());
+        int n_ch = compact(3 * W, p.ch_q.data(), p.ch_v.data(), p.ch_c.data());
+        if (iter_counts && nrec < iter_cap) {
+            iter_counts[4 * nrec + 0] = n_mat;
+            iter_counts[4 * nrec + 1] = n_gen;
+            iter_counts[4 * nrec + 2] = n_ah;
+            iter_counts[4 * nrec + 3] = n_ch;
+        }
+        nrec++;
+        st.iterations++;
+        st.sum_mat += n_mat;
+        st.sum_gen += n_gen;
+        st.sum_ah += n_ah;
+        st.sum_ch += n_ch;
+        // ---- ah() :278-294 (traversal in parallel, deposits applied serially in queue order)
+        {
+            std::vector<TravStats> tst(threads > 0 ? threads : 1);
+#pragma omp parallel for num_threads(threads) schedule(dynamic, 1024)
+            for (int tid = 0; tid < n_ah; tid++) {
+                int ah_id = p.ah_c[tid];
+                int s = ah_id - W;
+                TravStats *ts = nullptr;
+#ifdef _OPENMP
+                if (cs) ts = &tst[omp_get_thread_num()];
+#else
+                if (cs) ts = &tst[0];
+#endif
+                deposit[tid] = traverse_any(sc, p.ah_target[s], p.ray[ah_id], ts) ? 0 : 1;
+            }
+            for (auto &t : tst) {
+                sc.st_any.rays += t.rays;
+                sc.st_any.node_pairs += t.node_pairs;
+                sc.st_any.tri_tests += t.tri_tests;
+                sc.st_any.max_stack = std::max(sc.st_any.max_stack, t.max_stack);
+            }
+            for (int tid = 0; tid < n_ah; tid++)
+                if (deposit[tid]) {
+                    int ah_id = p.ah_c[tid];
+                    int s = ah_id - W;
+                    V3 &px = fb[p.pixel_idx[ah_id]];
+                    px.x += p.ah_L[s].x;
+                    px.y += p.ah_L[s].y;
+                    px.z += p.ah_L[s].z;
+                    st.ah_adds++;
+                }
+        }
+        // ---- ch() :297-328
+        {
+            std::vector<TravStats> tst(threads > 0 ? threads : 1);
+#pragma omp parallel for num_threads(threads) schedule(dynamic, 1024)
+            for (int tid = 0; tid < n_ch; tid++) {
+                int rid = p.ch_c[tid];
+                TravStats *ts = nullptr;
+#ifdef _OPENMP
+                if (cs) ts = &tst[omp_get_thread_num()];
+#else
+                if (cs) ts = &tst[0];
+#endif
+                Ray ray = p.ray[rid];
+                Isect is;
+                is.t = is.u = is.v = 0.f;
+                int prim = -1;
+                bool hit = traverse_closest(sc, ray, is, prim, ts);
+                deposit[tid] = 0;
+                if (rid < W) {
+                    p.hit[rid] = hit ? 1 : 0;
+                    p.isect[rid] = is;
+                    p.isect_prim[rid] = prim;
+                } else {
+                    int s = rid - 2 * W;
+                    if (hit && p.ch_target[s] == sc.prims[prim].tri) deposit[tid] = 1;
+                }
+            }
+            for (auto &t : tst) {
+                sc.st_closest.rays += t.rays;
+                sc.st_closest.node_pairs += t.node_pairs;
+                sc.st_closest.tri_tests += t.tri_tests;
+                sc.st_closest.max_stack = std::max(sc.st_closest.max_stack, t.max_stack);
+            }
+            for (int tid = 0; tid < n_ch; tid++)
+                if (deposit[tid]) {
+                    int rid = p.ch_c[tid];
+                    int s = rid - 2 * W;
+                    V3 &px = fb[p.pixel_idx[rid]];
+                    px.x += p.ch_L[s].x;
+                    px.y += p.ch_L[s].y;
+                    px.z += p.ch_L[s].z;
+                    st.ch_adds++;
+                }
+        }
+    }
+    st.seconds_loop = now_s() - t1;
+    st.n_iter_records = nrec;
+    st.ch_rays = sc.st_closest.rays;
+    st.ch_node_pairs = sc.st_closest.node_pairs;
+    st.ch_tri_tests = sc.st_closest.tri_tests;
+    st.ah_rays = sc.st_any.rays;
+    st.ah_node_pairs = sc.st_any.node_pairs;
+    st.ah_tri_tests = sc.st_any.tri_tests;
+    st.max_stack = std::max(sc.st_closest.max_stack, sc.st_any.max_stack);
+    if (fb_sum) memcpy(fb_sum, fb.data(), sizeof(float) * 3 * (size_t)P);
+    if (fb_out) {  // post_process_framebuffer :330-338
+        float inv = 1.f / (float)spp;
+        for (int i = 0; i < P; i++) {
+            fb_out[3 * i + 0] = sqrtf(fb[i].x * inv);
+            fb_out[3 * i + 1] = sqrtf(fb[i].y * inv);
+            fb_out[3 * i + 2] = sqrtf(fb[i].z * inv);
+        }
+    }
+    if (stats) *stats = st;
+}
+
+}  // namespace
+
+// ================================================================= C interface (ctypes)
+extern "C" {
+
+struct orc_material {
+    float albedo[3];
+    float ior;
+    int32_t type;
+};
+struct orc_light {
+    int32_t type;
+    float pos[3];
+    int32_t tri;
+    float L[3];
+};
+
+const char *orc_build_info() {
+#ifdef ORC_LIBM
+    return "libm";
+#else
+    return "pinned";
+#endif
+}
+
+// ---- XORWOW
+void orc_xorwow_init(uint64_t seed, uint32_t subsequence, uint32_t *state6) {
+    Xorwow st = xorwow_init(seed, subsequence);
+    state6[0] = st.d;
+    memcpy(state6 + 1, st.v, 20);
+}
+void orc_xorwow_init_range(uint64_t seed, uint32_t first, uint32_t count, uint32_t *state6) {
+    std::vector<Xorwow> v(count);
+    xorwow_init_range(seed, first, count, v.data());
+    for (uint32_t i = 0; i < count; i++) {
+        state6[6 * i] = v[i].d;
+        memcpy(state6 + 6 * i + 1, v[i].v, 20);
+    }
+}
+void orc_xorwow_draw(uint32_t *state6, int n, uint32_t *raw, float *uni) {
+    Xorwow st;
+    st.d = state6[0];
+    memcpy(st.v, state6 + 1, 20);
+    for (int i = 0; i < n; i++) {
+        uint32_t x = xorwow_next(st);
+        if (raw) raw[i] = x;
+        if (uni) uni[i] = uniform_from_u32(x);
+    }
+    state6[0] = st.d;
+    memcpy(state6 + 1, st.v, 20);
+}
+float orc_uniform_from_u32(uint32_t x) { return uniform_from_u32(x); }
+void orc_jump_row(int bit, uint32_t *out5) { memcpy(out5, jump_table().row[bit], 20); }
+
+// ---- unit functions
+void orc_camera(const float *lookfrom, const float *lookat, const float *up, float vfov, float aspect, float *out12) {
+    Camera c = make_camera(mk(lookfrom[0], lookfrom[1], lookfrom[2]), mk(lookat[0], lookat[1], lookat[2]),
+                           mk(up[0], up[1], up[2]), vfov, aspect);
+    memcpy(out12, &c, 48);
+}
+void orc_camera_get_ray(const float *cam12, float x, float y, float *out_o3_d3) {
+    Camera c;
+    memcpy(&c, cam12, 48);
+    Ray r = camera_get_ray(c, x, y);
+    memcpy(out_o3_d3, &r, 24);
+}
+void orc_offset_ray_origin(const float *p, const float *n, float *out) {
+    V3 r = offset_ray_origin(mk(p[0], p[1], p[2]), mk(n[0], n[1], n[2]));
+    memcpy(out, &r, 12);
+}
+float orc_power_heuristic(float f, float g) { return power_heuristic(f, g); }
+void orc_triangle(const float *p9, float *out12, float *area) {
+    Tri t(mk(p9[0], p9[1], p9[2]), mk(p9[3], p9[4], p9[5]), mk(p9[6], p9[7], p9[8]));
+    memcpy(out12, &t, 48);
+    *area = t.area();
+}
+int orc_triangle_intersect(const float *p9, const float *o, const float *d, float tmax, float *tuv) {
+    Tri t(mk(p9[0], p9[1], p9[2]), mk(p9[3], p9[4], p9[5]), mk(p9[6], p9[7], p9[8]));
+    Ray r{mk(o[0], o[1], o[2]), mk(d[0], d[1], d[2]), tmax};
+    Isect is{0, 0, 0};
+    bool h = t.intersect(r, is);
+    tuv[0] = is.t;
+    tuv[1] = is.u;
+    tuv[2] = is.v;
+    return h ? 1 : 0;
+}
+void orc_sincos(float x, float *s, float *c) { orc_sincosf(x, s, c); }
+float orc_pow5(float x) { return ::orc_pow5(x); }
+// sample_f on a batch: returns f(3) wi(3) n(3) pdf, advances the rng state
+void orc_sample_f(const orc_material *m, const float *wo, const float *n_in, uint32_t *state6, float *out10) {
+    Material mm{mk(m->albedo[0], m->albedo[1], m->albedo[2]), m->ior, m->type};
+    Xorwow st;
+    st.d = state6[0];
+    memcpy(st.v, state6 + 1, 20);
+    V3 n = mk(n_in[0], n_in[1], n_in[2]), wi = mk(0, 0, 0);
+    float pdf = 0;
+    V3 f = mat_sample_f(mm, mk(wo[0], wo[1], wo[2]), st, n, wi, pdf);
+    memcpy(out10, &f, 12);
+    memcpy(out10 + 3, &wi, 12);
+    memcpy(out10 + 6, &n, 12);
+    out10[9] = pdf;
+    state6[0] = st.d;
+    memcpy(state6 + 1, st.v, 20);
+}
+
+// ---- scene
+struct orc_scene {
+    Scene sc;
+};
+
+orc_scene *orc_scene_create(const float *tri_p0p1p2, int n_tris, const int32_t *tri_material,
+                            const int32_t *tri_light, const orc_material *mats, int n_mats,
+                            const orc_light *lights, int n_lights) {
+    auto *h = new orc_scene;
+    Scene &sc = h->sc;
+    sc.tris.resize(n_tris);
+    std::vector<Prim> prims(n_tris);
+    for (int i = 0; i < n_tris; i++) {
+        const float *q = tri_p0p1p2 + 9 * (size_t)i;
+        sc.tris[i] = Tri(mk(q[0], q[1], q[2]), mk(q[3], q[4], q[5]), mk(q[6], q[7], q[8]));
+        prims[i] = Prim{i, tri_material[i], tri_light ? tri_light[i] : -1};
+    }
+    for (int i = 0; i < n_mats; i++)
+        sc.mats.push_back(Material{mk(mats[i].albedo[0], mats[i].albedo[1], mats[i].albedo[2]), mats[i].ior, mats[i].type});
+    for (int i = 0; i < n_lights; i++)
+        sc.lights.push_back(Light{lights[i].type, mk(lights[i].pos[0], lights[i].pos[1], lights[i].pos[2]),
+                                  lights[i].tri, mk(lights[i].L[0], lights[i].L[1], lights[i].L[2])});
+    build_bvh(sc, prims);
+    return h;
+}
+void orc_scene_destroy(orc_scene *h) { delete h; }
+
+// out: [num_nodes, num_prims, max_depth, num_leaves, leaf_hist[1..8]]
+void orc_scene_bvh_stats(const orc_scene *h, int64_t *out12, float *root_bounds6) {
+    const Scene &sc = h->sc;
+    memset(out12, 0, 12 * sizeof(int64_t));
+    out12[0] = (int64_t)sc.nodes.size();
+    out12[1] = (int64_t)sc.prims.size();
+    out12[2] = sc.max_depth;
+    for (const Node &n : sc.nodes)
+        if (n.num_prims > 0 || sc.nodes.size() == 1) {
+            out12[3]++;
+            int k = std::min(n.num_prims, 8);
+            if (k >= 1) out12[3 + k]++;
+        }
+    memcpy(root_bounds6, sc.nodes[0].bbox.b, 24);
+}
+// BVH export for structural tests: nodes as 8 x float/int words each
+void orc_scene_nodes(const orc_scene *h, float *bounds6n, int32_t *num_prims, int32_t *index, int32_t *prim_tri) {
+    const Scene &sc = h->sc;
+    for (size_t i = 0; i < sc.nodes.size(); i++) {
+        memcpy(bounds6n + 6 * i, sc.nodes[i].bbox.b, 24);
+        num_prims[i] = sc.nodes[i].num_prims;
+        index[i] = sc.nodes[i].index;
+    }
+    for (size_t i = 0; i < sc.prims.size(); i++) prim_tri[i] = sc.prims[i].tri;
+}
+
+// closest hit for n rays given as SoA-free o3,d3,tmax arrays.  hit_tri is the ORIGINAL triangle
+// index (-1 on miss); t,u,v valid on hit.
+void orc_trace_closest(const orc_scene *h, int n, const float *o3, const float *d3, const float *tmax,
+                       int32_t *hit_tri, float *t, float *u, float *v, int threads) {
+    const Scene &sc = h->sc;
+#pragma omp parallel for num_threads(threads > 0 ? threads : 1) schedule(dynamic, 1024)
+    for (int i = 0; i < n; i++) {
+        Ray r{mk(o3[3 * i], o3[3 * i + 1], o3[3 * i + 2]), mk(d3[3 * i], d3[3 * i + 1], d3[3 * i + 2]), tmax[i]};
+        Isect is{0, 0, 0};
+        int prim = -1;
+        bool hit = traverse_closest(sc, r, is, prim, nullptr);
+        hit_tri[i] = hit ? sc.prims[prim].tri : -1;
+        t[i] = is.t;
+        u[i] = is.u;
+        v[i] = is.v;
+    }
+}
+// all (tri, t) candidates with t equal to the closest t (tie diagnosis); returns count of ties
+int orc_closest_ties(const orc_scene *h, const float *o3, const float *d3, float tmax, float t_ref, int32_t *tris, int cap) {
+    const Scene &sc = h->sc;
+    Ray r{mk(o3[0], o3[1], o3[2]), mk(d3[0], d3[1], d3[2]), tmax};
+    int k = 0;
+    for (size_t i = 0; i < sc.tris.size(); i++) {
+        Isect is;
+        if (sc.tris[i].intersect(r, is) && is.t == t_ref) {
+            if (k < cap) tris[k] = (int)i;
+            k++;
+        }
+    }
+    return k;
+}
+void orc_trace_any(const orc_scene *h, int n, const float *o3, const float *d3, const float *tmax,
+                   const int32_t *excluded_tri, int32_t *occluded, int threads) {
+    const Scene &sc = h->sc;
+#pragma omp parallel for num_threads(threads > 0 ? threads : 1) schedule(dynamic, 1024)
+    for (int i = 0; i < n; i++) {
+        Ray r{mk(o3[3 * i], o3[3 * i + 1], o3[3 * i + 2]), mk(d3[3 * i], d3[3 * i + 1], d3[3 * i + 2]), tmax[i]};
+        occluded[i] = traverse_any(sc, excluded_tri[i], r, nullptr) ? 1 : 0;
+    }
+}
+
+// literal render.  stats_out: RenderStats as 20 int64/double slots (see oracle.py);
+// iter_counts: iter_cap x 4 int32 (mat, gen, ah, ch)
+void orc_render(orc_scene *h, const float *cam12, int width, int height, int spp, int max_bounces,
+                uint64_t seed, int slot_lo, int slot_hi, int threads, int collect_stats, float *fb_sum,
+                float *fb_out, double *stats_out, int32_t *iter_counts, int iter_cap) {
+    Camera c;
+    memcpy(&c, cam12, 48);
+    Scene &sc = h->sc;
+    sc.collect_stats = collect_stats != 0;
+    sc.st_closest = TravStats();
+    sc.st_any = TravStats();
+    RenderStats st;
+    if (threads < 1) threads = 1;
+    render_literal(sc, c, width, height, spp, max_bounces, seed, slot_lo, slot_hi, threads, fb_sum, fb_out, &st,
+                   iter_counts, iter_cap);
+    if (stats_out) {
+        double *o = stats_out;
+        o[0] = (double)st.iterations;
+        o[1] = (double)st.sum_mat;
+        o[2] = (double)st.sum_gen;
+        o[3] = (double)st.sum_ah;
+        o[4] = (double)st.sum_ch;
+        o[5] = (double)st.emission_adds;
+        o[6] = (double)st.ah_adds;
+        o[7] = (double)st.ch_adds;
+        o[8] = (double)st.rr_draws;
+        o[9] = (double)st.rr_kills;
+        o[10] = st.seconds_loop;
+        o[11] = st.seconds_rng_init;
+        o[12] = (double)st.ch_rays;
+        o[13] = (double)st.ch_node_pairs;
+        o[14] = (double)st.ch_tri_tests;
+        o[15] = (double)st.ah_rays;
+        o[16] = (double)st.ah_node_pairs;
+        o[17] = (double)st.ah_tri_tests;
+        o[18] = (double)st.max_stack;
+        o[19] = (double)st.n_iter_records;
+    }
+}
+
+}  // extern "C"
