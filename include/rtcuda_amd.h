@@ -1,0 +1,148 @@
+/* rtcuda_amd.h -- C-ABI of the MI355X-native render path (drop-in for lashhw/rtcuda's render()).
+ *
+ * Plain C: opaque handles, plain pointers and sizes, int status codes.  No torch / HIP types.
+ * Every entry point names the reference interface it replaces (file:line into the reference
+ * tree).  The C++ host API that keeps the reference's class names (Vec3 / Triangle / Material /
+ * Light / Primitive / Bvh / Scene / Camera / render) is include/rtcuda/rtcuda.hpp -- a
+ * header-only layer over exactly these functions.
+ *
+ * Conventions
+ *   - return 0 on success, non-zero on failure; rt_last_error() gives the message
+ *     (the reference prints and exit()s instead: utility.cuh:6-13).
+ *   - all device memory is owned by the library behind rt_scene* / an internal per-device
+ *     context (the reference leaks every allocation: main.cu:50,121,136; bvh.cuh:211-217;
+ *     render.cuh:374-391).
+ *   - "current device" is the calling thread's current HIP device (hipSetDevice /
+ *     torch.cuda.set_device); one process per GPU is the intended deployment.
+ *   - triangle, material and light POINTERS of the reference API become INDICES here.
+ */
+#ifndef RTCUDA_AMD_H
+#define RTCUDA_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_NUM_WORKING_PATHS 1048576 /* constant.hpp:8 -- number of path slots == RNG streams */
+
+enum { RT_MATTE = 0, RT_MIRROR = 1, RT_GLASS = 2 };  /* material.cuh:4-8 */
+enum { RT_POINT_LIGHT = 0, RT_AREA_LIGHT = 1 };      /* light.cuh:4-7 */
+
+/* material.cuh:20-22 (same field order, 20 bytes) */
+typedef struct rt_material {
+    float albedo[3];
+    float index_of_refraction;
+    int32_t type;
+} rt_material;
+
+/* light.cuh:20-26 with `Triangle *d_triangle` flattened to a triangle index (32 bytes) */
+typedef struct rt_light {
+    int32_t type;
+    float pos[3];     /* point light */
+    int32_t triangle; /* area light: index into the scene's triangle array */
+    float L[3];       /* radiance (area) or intensity I (point) */
+} rt_light;
+
+/* camera.cuh:11-14 (48 bytes): what Camera's constructor leaves in the object */
+typedef struct rt_camera {
+    float lookfrom[3];
+    float upper_left[3];
+    float horizontal[3];
+    float vertical[3];
+} rt_camera;
+
+typedef struct rt_scene rt_scene;
+
+/* Per-render counters (the reference has only stdout).  All counts are for THIS shard. */
+typedef struct rt_stats {
+    int64_t camera_rays;     /* gen events      (render.cuh:250)  */
+    int64_t shade_events;    /* mat events      (render.cuh:139)  */
+    int64_t closest_rays;    /* rays traced by the closest-hit kernel */
+    int64_t any_rays;        /* rays traced by the any-hit kernel */
+    int64_t emission_adds;   /* bounce-0 emission deposits (render.cuh:98-103) */
+    int64_t shadow_adds;     /* unoccluded NEE deposits    (render.cuh:291-293) */
+    int64_t rr_draws;        /* Russian-roulette draws     (render.cuh:117) */
+    int64_t iterations;      /* stage rounds launched */
+    int64_t bvh_nodes;       /* node records of the device BVH */
+    int64_t bvh_depth;
+    double seconds_render;   /* device time of the render loop (HIP events), excl. RNG init */
+    double seconds_rng_init; /* device time of the one-off XORWOW state initialisation */
+    double seconds_closest;  /* summed HIP-event time of the closest-hit kernel (0 unless timing on) */
+    double seconds_any;
+    double seconds_advance;
+    int64_t launches_closest;
+    int64_t reserved[7];
+} rt_stats;
+
+/* Flags for rt_render / rt_render_shard */
+#define RT_FLAG_TIME_KERNELS 1u /* bracket every stage kernel with HIP events (slower; fills seconds_*) */
+
+/* ---- scene -------------------------------------------------------------------------------
+ * Replaces: Triangle(p0,p1,p2) x n (triangle.cuh:6-7), cudaMalloc/Memcpy of triangles,
+ * materials and lights (main.cu:50-51,119-122,136-137), Primitive(tri*,mat*,light*)
+ * (primitive.cuh:6-7), Bvh(triangles, primitives) (bvh.cuh:30-219) and the Scene aggregate
+ * (scene.cuh:4-8).  tri_p0p1p2 is n_tris x 9 floats; tri_light[i] is the index into `lights`
+ * of the area light that triangle i carries, or -1 (may be NULL = no area lights).
+ * The light ORDER is the caller's (the reference's comes from unordered_map iteration,
+ * main.cu:128).  Uploads to the current device. */
+int rt_scene_create(const float *tri_p0p1p2, int n_tris, const int32_t *tri_material,
+                    const int32_t *tri_light, const rt_material *materials, int n_materials,
+                    const rt_light *lights, int n_lights, rt_scene **out_scene);
+void rt_scene_destroy(rt_scene *scene);
+
+/* out[0]=node records, out[1]=triangles, out[2]=max depth, out[3]=leaves */
+int rt_scene_info(const rt_scene *scene, int64_t out[4]);
+
+/* Replaces Camera::Camera(lookfrom, lookat, up, vfov_deg, aspect) (camera.cuh:15-29). Host only. */
+int rt_camera_make(const float lookfrom[3], const float lookat[3], const float up[3], float vfov_deg,
+                   float aspect_ratio, rt_camera *out);
+
+/* ---- render ------------------------------------------------------------------------------
+ * Replaces render(width, height, num_samples, max_bounces, camera, scene, framebuffer)
+ * (render.cuh:366-457) with RAND_SEED (render.cuh:417) exposed as `seed` (reference: 1).
+ * out_rgb: HOST buffer of width*height*3 floats, row-major, top row first, each channel
+ * sqrt(sum/spp) exactly as post_process_framebuffer leaves it (render.cuh:330-338). */
+int rt_render(const rt_scene *scene, const rt_camera *camera, int width, int height, int num_samples,
+              int max_bounces, uint64_t seed, uint32_t flags, float *out_rgb, rt_stats *stats);
+
+/* Multi-GPU building block: render only the camera rays owned by path slots
+ * [shard_index*W/shard_count, (shard_index+1)*W/shard_count) -- slot s serves exactly the camera
+ * rays c with c % W == s, so shards are disjoint and their raw sums add up to the 1-GPU image.
+ * d_sum_rgb: DEVICE buffer of width*height*3 floats on the current device; contributions are
+ * ADDED to it (zero it first).  stream: hipStream_t (NULL = default stream).  The call is
+ * synchronous on that stream when it returns.  shard_count must divide W. */
+int rt_render_shard(const rt_scene *scene, const rt_camera *camera, int width, int height, int num_samples,
+                    int max_bounces, uint64_t seed, int shard_index, int shard_count, uint32_t flags,
+                    float *d_sum_rgb, void *stream, rt_stats *stats);
+
+/* post_process_framebuffer (render.cuh:330-338) on a DEVICE buffer: c = sqrt(c * (1/spp)). */
+int rt_post_process(float *d_rgb, int num_pixels, int num_samples, void *stream);
+
+/* ---- stage-level entry points (parity tests call these; HOST pointers, AoS xyz triples) -----
+ * Closest hit (Bvh::traverse, bvh.cuh:251-303; ch(), render.cuh:297-328): hit_tri = index of
+ * the hit triangle in the caller's ORIGINAL order or -1; t,u,v as Intersection
+ * (intersection.hpp:4-6), undefined on a miss. */
+int rt_trace_closest(const rt_scene *scene, int n, const float *origin_xyz, const float *dir_xyz,
+                     const float *tmax, int32_t *hit_tri, float *t, float *u, float *v);
+/* Any hit excluding one triangle (bvh.cuh:306-357; ah(), render.cuh:278-294): occluded[i] in {0,1}. */
+int rt_trace_any(const rt_scene *scene, int n, const float *origin_xyz, const float *dir_xyz,
+                 const float *tmax, const int32_t *excluded_tri, int32_t *occluded);
+/* curand_init(seed, subsequence, 0) for subsequences [first, first+count) (render.cuh:68-73):
+ * state6 receives count x {d, v0..v4}.  Then `draws` uniforms per state into uniforms
+ * (count x draws, may be 0 / NULL), advancing the returned states. */
+int rt_xorwow_states(uint64_t seed, uint32_t first, uint32_t count, int draws, uint32_t *state6,
+                     float *uniforms);
+
+/* Measured device copy bandwidth in bytes/s (float4 copy of `bytes` bytes, best of `reps`):
+ * the HBM roofline denominator SURVEY.md section 8d asks to be measured in the same run. */
+int rt_measure_copy_bandwidth(int64_t bytes, int reps, double *out_bytes_per_s);
+
+const char *rt_last_error(void);
+const char *rt_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTCUDA_AMD_H */

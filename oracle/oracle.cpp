@@ -1361,6 +1361,27 @@ void orc_trace_closest(const orc_scene *h, int n, const float *o3, const float *
         v[i] = is.v;
     }
 }
+// exhaustive closest hit (every triangle, original order, same triangle test): measures how often the
+// reference's fp32 slab test makes its BVH traversal miss a triangle the triangle test accepts
+void orc_trace_closest_brute(const orc_scene *h, int n, const float *o3, const float *d3, const float *tmax,
+                             int32_t *hit_tri, float *t, float *u, float *v, int threads) {
+    const Scene &sc = h->sc;
+#pragma omp parallel for num_threads(threads > 0 ? threads : 1) schedule(dynamic, 64)
+    for (int i = 0; i < n; i++) {
+        Ray r{mk(o3[3 * i], o3[3 * i + 1], o3[3 * i + 2]), mk(d3[3 * i], d3[3 * i + 1], d3[3 * i + 2]), tmax[i]};
+        Isect is{0, 0, 0};
+        int tri = -1;
+        for (size_t k = 0; k < sc.tris.size(); k++)
+            if (sc.tris[k].intersect(r, is)) {
+                tri = (int)k;
+                r.tmax = is.t;
+            }
+        hit_tri[i] = tri;
+        t[i] = is.t;
+        u[i] = is.u;
+        v[i] = is.v;
+    }
+}
 // all (tri, t) candidates with t equal to the closest t (tie diagnosis); returns count of ties
 int orc_closest_ties(const orc_scene *h, const float *o3, const float *d3, float tmax, float t_ref, int32_t *tris, int cap) {
     const Scene &sc = h->sc;

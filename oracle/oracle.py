@@ -67,6 +67,7 @@ class Oracle:
         L.orc_scene_nodes.argtypes = [ctypes.c_void_p, _fp, _fp, _fp, _fp]
         L.orc_trace_closest.argtypes = [ctypes.c_void_p, ctypes.c_int, _fp, _fp, _fp, _fp, _fp, _fp, _fp,
                                         ctypes.c_int]
+        L.orc_trace_closest_brute.argtypes = L.orc_trace_closest.argtypes
         L.orc_closest_ties.argtypes = [ctypes.c_void_p, _fp, _fp, ctypes.c_float, ctypes.c_float, _fp,
                                        ctypes.c_int]
         L.orc_closest_ties.restype = ctypes.c_int
@@ -195,6 +196,17 @@ class OracleScene:
         t, u, v = (np.zeros(n, np.float32) for _ in range(3))
         self.o.lib.orc_trace_closest(self.h, n, _ptr(o3), _ptr(d3), _ptr(tmax), _ptr(tri), _ptr(t), _ptr(u),
                                      _ptr(v), threads)
+        return tri, t, u, v
+
+    def trace_closest_brute(self, o3, d3, tmax, threads: int = 8):
+        o3 = np.ascontiguousarray(o3, np.float32)
+        d3 = np.ascontiguousarray(d3, np.float32)
+        tmax = np.ascontiguousarray(tmax, np.float32)
+        n = o3.shape[0]
+        tri = np.zeros(n, np.int32)
+        t, u, v = (np.zeros(n, np.float32) for _ in range(3))
+        self.o.lib.orc_trace_closest_brute(self.h, n, _ptr(o3), _ptr(d3), _ptr(tmax), _ptr(tri), _ptr(t),
+                                           _ptr(u), _ptr(v), threads)
         return tri, t, u, v
 
     def closest_ties(self, o, d, tmax, t_ref):

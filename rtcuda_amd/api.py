@@ -1,0 +1,209 @@
+"""ctypes binding of ``librtcuda_amd.so`` (the C-ABI in ``include/rtcuda_amd.h``).
+
+Mirrors the reference's host interface for the render path -- ``Scene`` construction from
+triangles / materials / lights, ``Camera(lookfrom, lookat, up, vfov, aspect)`` and
+``render(width, height, spp, max_bounces, camera, scene)`` (render.cuh:366-367) -- on top of the
+library.  Nothing here computes pixels: every call goes to the HIP library and raises
+``RtError`` if it fails or ``ImportError`` if the library has not been built.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+from .scenes import SceneArrays
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "librtcuda_amd.so")
+CSRC = os.path.join(_PKG, "csrc")
+
+W = 1 << 20  # RT_NUM_WORKING_PATHS
+FLAG_TIME_KERNELS = 1
+
+EXPORTS = [
+    "rt_scene_create", "rt_scene_destroy", "rt_scene_info", "rt_camera_make", "rt_render",
+    "rt_render_shard", "rt_post_process", "rt_trace_closest", "rt_trace_any", "rt_xorwow_states",
+    "rt_measure_copy_bandwidth", "rt_last_error", "rt_version",
+]
+
+
+class RtError(RuntimeError):
+    pass
+
+
+class RtStats(ctypes.Structure):
+    _fields_ = [
+        ("camera_rays", ctypes.c_int64), ("shade_events", ctypes.c_int64), ("closest_rays", ctypes.c_int64),
+        ("any_rays", ctypes.c_int64), ("emission_adds", ctypes.c_int64), ("shadow_adds", ctypes.c_int64),
+        ("rr_draws", ctypes.c_int64), ("iterations", ctypes.c_int64), ("bvh_nodes", ctypes.c_int64),
+        ("bvh_depth", ctypes.c_int64), ("seconds_render", ctypes.c_double), ("seconds_rng_init", ctypes.c_double),
+        ("seconds_closest", ctypes.c_double), ("seconds_any", ctypes.c_double), ("seconds_advance", ctypes.c_double),
+        ("launches_closest", ctypes.c_int64), ("reserved", ctypes.c_int64 * 7),
+    ]
+
+    def as_dict(self) -> dict:
+        return {n: getattr(self, n) for n, _ in self._fields_ if n != "reserved"}
+
+
+def build(verbose: bool = False) -> str:
+    """Compile the library in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+    out = None if verbose else subprocess.DEVNULL
+    subprocess.check_call(["make", "-C", CSRC], stdout=out)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """Load the library (once).  Raises ImportError with the build command if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: the HIP library is the product and there is no fallback. "
+            f"Build it with `make -C {CSRC}` (or python -c 'import __graft_entry__ as g; g.build()').")
+    L = ctypes.CDLL(LIB_PATH)
+    vp, ci, cf = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
+    L.rt_last_error.restype = ctypes.c_char_p
+    L.rt_version.restype = ctypes.c_char_p
+    L.rt_scene_create.argtypes = [vp, ci, vp, vp, vp, ci, vp, ci, ctypes.POINTER(vp)]
+    L.rt_scene_destroy.argtypes = [vp]
+    L.rt_scene_destroy.restype = None
+    L.rt_scene_info.argtypes = [vp, vp]
+    L.rt_camera_make.argtypes = [vp, vp, vp, cf, cf, vp]
+    L.rt_render.argtypes = [vp, vp, ci, ci, ci, ci, ctypes.c_uint64, ctypes.c_uint32, vp, ctypes.POINTER(RtStats)]
+    L.rt_render_shard.argtypes = [vp, vp, ci, ci, ci, ci, ctypes.c_uint64, ci, ci, ctypes.c_uint32, vp, vp,
+                                  ctypes.POINTER(RtStats)]
+    L.rt_post_process.argtypes = [vp, ci, ci, vp]
+    L.rt_trace_closest.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp, vp]
+    L.rt_trace_any.argtypes = [vp, ci, vp, vp, vp, vp, vp]
+    L.rt_xorwow_states.argtypes = [ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, ci, vp, vp]
+    L.rt_measure_copy_bandwidth.argtypes = [ctypes.c_int64, ci, ctypes.POINTER(ctypes.c_double)]
+    _lib = L
+    return L
+
+
+def _check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise RtError(f"{what}: {lib().rt_last_error().decode(errors='replace')}")
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data
+
+
+def make_camera(lookfrom=(0.5, 0.5, 1.5), lookat=(0.5, 0.5, 0.0), up=(0.0, 1.0, 0.0), vfov=37.8,
+                aspect=1.0) -> np.ndarray:
+    """``Camera(lookfrom, lookat, up, vfov, aspect)`` (camera.cuh:15-29) -> the 12-float POD."""
+    a, b, c = (np.asarray(v, np.float32) for v in (lookfrom, lookat, up))
+    out = np.zeros(12, np.float32)
+    _check(lib().rt_camera_make(_p(a), _p(b), _p(c), float(vfov), float(aspect), _p(out)), "rt_camera_make")
+    return out
+
+
+class Scene:
+    """Device-resident scene (triangles, materials, lights, BVH) on the current HIP device."""
+
+    def __init__(self, arrays: SceneArrays):
+        L = lib()
+        self.arrays = arrays
+        tris = np.ascontiguousarray(arrays.tris, np.float32)
+        tm = np.ascontiguousarray(arrays.tri_material, np.int32)
+        tl = np.ascontiguousarray(arrays.tri_light, np.int32)
+        mats = np.ascontiguousarray(arrays.materials)
+        lights = np.ascontiguousarray(arrays.lights)
+        assert mats.dtype.itemsize == 20 and lights.dtype.itemsize == 32
+        h = ctypes.c_void_p()
+        _check(L.rt_scene_create(_p(tris), tris.shape[0], _p(tm), _p(tl), _p(mats), mats.shape[0], _p(lights),
+                                 lights.shape[0], ctypes.byref(h)), "rt_scene_create")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().rt_scene_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def info(self) -> dict:
+        out = np.zeros(4, np.int64)
+        _check(lib().rt_scene_info(self.h, _p(out)), "rt_scene_info")
+        return {"pairs": int(out[0]), "tris": int(out[1]), "max_depth": int(out[2]), "leaves": int(out[3])}
+
+    # ---- render(): the drop-in entry point
+    def render(self, camera: np.ndarray, width: int, height: int, spp: int, max_bounces: int = 10,
+               seed: int = 1, flags: int = 0):
+        """Whole frame on the current device -> (image (h, w, 3) float32 post-processed, stats)."""
+        cam = np.ascontiguousarray(camera, np.float32)
+        out = np.zeros((height, width, 3), np.float32)
+        st = RtStats()
+        _check(lib().rt_render(self.h, _p(cam), width, height, spp, max_bounces, seed, flags, _p(out),
+                               ctypes.byref(st)), "rt_render")
+        return out, st.as_dict()
+
+    def render_shard(self, camera: np.ndarray, width: int, height: int, spp: int, shard_index: int,
+                     shard_count: int, d_sum_ptr: int, max_bounces: int = 10, seed: int = 1, flags: int = 0,
+                     stream: int = 0) -> dict:
+        """Adds this shard's raw sums into the DEVICE buffer at ``d_sum_ptr`` (w*h*3 floats)."""
+        cam = np.ascontiguousarray(camera, np.float32)
+        st = RtStats()
+        _check(lib().rt_render_shard(self.h, _p(cam), width, height, spp, max_bounces, seed, shard_index,
+                                     shard_count, flags, ctypes.c_void_p(d_sum_ptr), ctypes.c_void_p(stream),
+                                     ctypes.byref(st)), "rt_render_shard")
+        return st.as_dict()
+
+    # ---- stage-level entry points (parity tests)
+    def trace_closest(self, o3, d3, tmax):
+        o3 = np.ascontiguousarray(o3, np.float32)
+        d3 = np.ascontiguousarray(d3, np.float32)
+        tmax = np.ascontiguousarray(tmax, np.float32)
+        n = o3.shape[0]
+        tri = np.zeros(n, np.int32)
+        t, u, v = (np.zeros(n, np.float32) for _ in range(3))
+        _check(lib().rt_trace_closest(self.h, n, _p(o3), _p(d3), _p(tmax), _p(tri), _p(t), _p(u), _p(v)),
+               "rt_trace_closest")
+        return tri, t, u, v
+
+    def trace_any(self, o3, d3, tmax, excluded):
+        o3 = np.ascontiguousarray(o3, np.float32)
+        d3 = np.ascontiguousarray(d3, np.float32)
+        tmax = np.ascontiguousarray(tmax, np.float32)
+        excluded = np.ascontiguousarray(excluded, np.int32)
+        n = o3.shape[0]
+        occ = np.zeros(n, np.int32)
+        _check(lib().rt_trace_any(self.h, n, _p(o3), _p(d3), _p(tmax), _p(excluded), _p(occ)), "rt_trace_any")
+        return occ
+
+
+def post_process(d_ptr: int, num_pixels: int, spp: int, stream: int = 0) -> None:
+    _check(lib().rt_post_process(ctypes.c_void_p(d_ptr), num_pixels, spp, ctypes.c_void_p(stream)),
+           "rt_post_process")
+
+
+def xorwow_states(seed: int, first: int, count: int, draws: int = 0):
+    st = np.zeros((count, 6), np.uint32)
+    uni = np.zeros((count, max(draws, 1)), np.float32)
+    _check(lib().rt_xorwow_states(seed, first, count, draws, _p(st), _p(uni)), "rt_xorwow_states")
+    return st, uni[:, :draws]
+
+
+def measure_copy_bandwidth(nbytes: int = 1 << 30, reps: int = 5) -> float:
+    out = ctypes.c_double(0.0)
+    _check(lib().rt_measure_copy_bandwidth(nbytes, reps, ctypes.byref(out)), "rt_measure_copy_bandwidth")
+    return out.value
+
+
+def render(width: int, height: int, num_samples: int, max_bounces: int, camera: np.ndarray, scene: Scene,
+           seed: int = 1):
+    """Same argument order as the reference's ``render()`` (render.cuh:366-367); returns the framebuffer."""
+    img, _ = scene.render(camera, width, height, num_samples, max_bounces, seed)
+    return img

@@ -1,0 +1,241 @@
+// rt_device.h -- device-side math, sampling and BSDF code of the render path (gfx950).
+//
+// Every function that feeds the image is written as an explicit sequence of fp32 operations in
+// the evaluation order the reference's expressions have (vec3.cuh operator forms, SURVEY.md
+// Appendix A.8); the translation unit is compiled with -ffp-contract=off, so these are the same
+// roundings the CPU oracle performs and per-ray results can be compared bit for bit.  Where FMA
+// is wanted (box tests, which only cull) it is requested explicitly with __builtin_fmaf.
+#ifndef RT_DEVICE_H
+#define RT_DEVICE_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rt_pinned_math.h"
+
+#define RT_DEV __device__ __forceinline__
+
+namespace rt {
+
+constexpr float kInvPi = 0.31830988618379067153f;  // constant.hpp:6
+constexpr float kTwoPi = 6.28318530717958647692f;  // constant.hpp:5
+constexpr int kRrStart = 4;                        // constant.hpp:10
+constexpr float kRrThreshold = 1.f;                // constant.hpp:9
+constexpr float kFltMax = 3.402823466e+38f;
+constexpr float kFltEps = 1.192092896e-07f;
+
+struct V3 {
+    float x, y, z;
+};
+RT_DEV V3 mk(float x, float y, float z) { return V3{x, y, z}; }
+RT_DEV V3 neg(V3 a) { return mk(-a.x, -a.y, -a.z); }
+RT_DEV V3 add(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+RT_DEV V3 sub(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+RT_DEV V3 mul(V3 a, V3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+RT_DEV V3 scale(V3 a, float t) { return mk(a.x * t, a.y * t, a.z * t); }
+RT_DEV V3 divf(V3 a, float t) {  // vec3.cuh:56-59: multiply by the reciprocal
+    float inv_t = 1.f / t;
+    return mk(a.x * inv_t, a.y * inv_t, a.z * inv_t);
+}
+RT_DEV float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+RT_DEV V3 cross(V3 a, V3 b) {
+    return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+RT_DEV float len2(V3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
+RT_DEV float len(V3 a) { return sqrtf(a.x * a.x + a.y * a.y + a.z * a.z); }
+RT_DEV V3 unit(V3 a) {
+    float inv_len = 1.f / len(a);
+    return mk(a.x * inv_len, a.y * inv_len, a.z * inv_len);
+}
+RT_DEV float max3(V3 a) { return fmaxf(fmaxf(a.x, a.y), a.z); }
+RT_DEV V3 reflect(V3 v, V3 n) { return sub(v, scale(n, 2.f * dot(v, n))); }  // vec3.cuh:71-73
+RT_DEV V3 refract4(V3 unit_v, V3 unit_n, float eta_ratio, float cos_theta) {  // vec3.cuh:82-86
+    V3 v_parallel = scale(add(unit_v, scale(unit_n, cos_theta)), eta_ratio);
+    V3 v_perp = scale(unit_n, -sqrtf(1.f - len2(v_parallel)));
+    return add(v_parallel, v_perp);
+}
+
+// ------------------------------------------------------------------ XORWOW (cuRAND's generator)
+struct Rng {
+    uint32_t d, v0, v1, v2, v3, v4;
+};
+RT_DEV uint32_t rng_next(Rng &s) {
+    uint32_t t = s.v0 ^ (s.v0 >> 2);
+    s.v0 = s.v1;
+    s.v1 = s.v2;
+    s.v2 = s.v3;
+    s.v3 = s.v4;
+    s.v4 = (s.v4 ^ (s.v4 << 4)) ^ (t ^ (t << 1));
+    s.d += 362437u;
+    return s.v4 + s.d;
+}
+// curand_uniform: (0, 1]
+RT_DEV float rng_uniform(Rng &s) { return (float)rng_next(s) * 2.3283064e-10f + (2.3283064e-10f / 2.0f); }
+
+// ------------------------------------------------------------------ triangle (triangle.cuh)
+struct Tri {
+    V3 p0, e1, e2, n;
+};
+// 48-byte record = 3 x float4: (p0.xyz, e1.x) (e1.yz, e2.xy) (e2.z, n.xyz)
+RT_DEV Tri load_tri(const float4 *__restrict__ tris, int k) {
+    float4 a = tris[3 * k + 0];
+    float4 b = tris[3 * k + 1];
+    float4 c = tris[3 * k + 2];
+    Tri t;
+    t.p0 = mk(a.x, a.y, a.z);
+    t.e1 = mk(a.w, b.x, b.y);
+    t.e2 = mk(b.z, b.w, c.x);
+    t.n = mk(c.y, c.z, c.w);
+    return t;
+}
+// triangle.cuh:39-58 -- the ONE triangle test; closest-hit, any-hit and Light::pdf_Li all use it
+RT_DEV bool tri_intersect(const Tri &tr, V3 o, V3 d, float tmax, float &t_out, float &u_out, float &v_out) {
+    V3 c = sub(tr.p0, o);
+    V3 r = cross(d, c);
+    float inv_det = 1.f / dot(d, tr.n);
+    float u = inv_det * dot(tr.e2, r);
+    float v = inv_det * dot(tr.e1, r);
+    if (u >= 0.0f && v >= 0.0f && (u + v) <= 1.0f) {
+        float t = inv_det * dot(c, tr.n);
+        if (0 < t && t <= tmax) {
+            t_out = t;
+            u_out = u;
+            v_out = v;
+            return true;
+        }
+    }
+    return false;
+}
+RT_DEV V3 tri_point(const Tri &tr, float u, float v) { return add(sub(tr.p0, scale(tr.e1, u)), scale(tr.e2, v)); }
+RT_DEV float tri_area(const Tri &tr) { return 0.5f * len(tr.n); }  // 0.5 * x is exact in any precision
+
+// ------------------------------------------------------------------ utility.cuh
+RT_DEV V3 offset_ray_origin(V3 p, V3 n) {  // :31-47
+    const float int_scale = 256.f;
+    const float float_scale = 1.f / 65536.f;
+    const float origin = 1.f / 32.f;
+    int ox = (int)(int_scale * n.x);
+    int oy = (int)(int_scale * n.y);
+    int oz = (int)(int_scale * n.z);
+    float px = __int_as_float(__float_as_int(p.x) + (p.x < 0 ? -ox : ox));
+    float py = __int_as_float(__float_as_int(p.y) + (p.y < 0 ? -oy : oy));
+    float pz = __int_as_float(__float_as_int(p.z) + (p.z < 0 ? -oz : oz));
+    return mk(fabsf(p.x) < origin ? p.x + float_scale * n.x : px,
+              fabsf(p.y) < origin ? p.y + float_scale * n.y : py,
+              fabsf(p.z) < origin ? p.z + float_scale * n.z : pz);
+}
+// :53-56 with the int parameter made explicit; only called where g < 2^31 (NEE: g = cos/pi < 1)
+RT_DEV float power_heuristic(float f_pdf, float g_pdf_float) {
+    int g = (int)g_pdf_float;
+    float f2 = f_pdf * f_pdf;
+    return f2 / (f2 + (float)(g * g));
+}
+RT_DEV bool same_hemisphere(V3 wo, V3 wi, V3 n) { return dot(wo, n) * dot(wi, n) < 0.f; }  // :58-60
+RT_DEV V3 uniform_sample_sphere(Rng &rs) {  // :70-77
+    float z = 1 - 2 * rng_uniform(rs);
+    float r = sqrtf(1 - z * z);
+    float phi = kTwoPi * rng_uniform(rs);
+    float x, y;
+    rt_sincosf(phi, &y, &x);
+    return mk(r * x, r * y, z);
+}
+
+// ------------------------------------------------------------------ material.cuh
+struct Material {
+    float ax, ay, az;  // albedo
+    float ior;
+    int type;  // 0 MATTE 1 MIRROR 2 GLASS
+};
+RT_DEV bool mat_get_f(const Material &m, V3 wo, V3 wi, V3 n, V3 &f, float &pdf) {  // :47-57
+    if (m.type == 0) {
+        if (same_hemisphere(wo, wi, n)) {
+            f = scale(mk(m.ax, m.ay, m.az), kInvPi);
+            pdf = dot(wi, n) * kInvPi;
+            return true;
+        }
+    }
+    return false;
+}
+// :60-109 -- mutates n so that n and wi share a hemisphere
+RT_DEV V3 mat_sample_f(const Material &m, V3 wo, Rng &rs, V3 &n, V3 &wi, float &pdf) {
+    if (m.type == 0 || m.type == 1) {
+        if (dot(wo, n) > 0.f) n = neg(n);
+        if (m.type == 0) {
+            wi = unit(add(n, uniform_sample_sphere(rs)));
+            pdf = dot(wi, n) * kInvPi;
+            return scale(mk(m.ax, m.ay, m.az), kInvPi);
+        } else {
+            wi = reflect(wo, n);
+            pdf = 1.f;
+            return divf(mk(m.ax, m.ay, m.az), dot(wi, n));
+        }
+    } else {
+        float cos_theta = dot(wo, n);
+        bool front = cos_theta < 0.f;
+        if (front) cos_theta = -cos_theta;
+        float inv_cos = 1.f / cos_theta;
+        float eta = front ? 1.f / m.ior : m.ior;
+        float sin_theta = sqrtf(1.f - cos_theta * cos_theta);
+        bool cannot_refract = eta * sin_theta > 1.f;
+        if (cannot_refract) {
+            if (!front) n = neg(n);
+            wi = reflect(wo, n);
+            pdf = 1.f;
+            return mk(inv_cos, inv_cos, inv_cos);
+        }
+        float r0 = (1 - m.ior) / (1 + m.ior);
+        r0 = r0 * r0;
+        float reflectance = r0 + (1 - r0) * rt_pow5f(1 - cos_theta);
+        if (rng_uniform(rs) < reflectance) {
+            if (!front) n = neg(n);
+            wi = reflect(wo, n);
+            pdf = reflectance;
+            float v = pdf * inv_cos;
+            return mk(v, v, v);
+        } else {
+            if (!front) n = neg(n);
+            wi = refract4(wo, n, eta, cos_theta);
+            n = neg(n);
+            pdf = 1.f - reflectance;
+            float v = pdf * eta * eta / dot(wi, n);
+            return mk(v, v, v);
+        }
+    }
+}
+// The RNG draws the SECOND sample_f call of mat() consumes (render.cuh:218).  Its ray (the
+// "CH shadow ray") targets the shading triangle itself and can never be credited
+// (render.cuh:236,321), so only its side effect on the RNG stream is kept.
+RT_DEV void mat_sample_f_burn(const Material &m, V3 wo, V3 n, Rng &rs) {
+    if (m.type == 0) {
+        rng_next(rs);
+        rng_next(rs);
+    } else if (m.type == 2) {
+        float cos_theta = dot(wo, n);
+        bool front = cos_theta < 0.f;
+        if (front) cos_theta = -cos_theta;
+        float eta = front ? 1.f / m.ior : m.ior;
+        float sin_theta = sqrtf(1.f - cos_theta * cos_theta);
+        if (!(eta * sin_theta > 1.f)) rng_next(rs);
+    }
+}
+
+// ------------------------------------------------------------------ light.cuh
+struct Light {
+    int type;  // 0 POINT 1 AREA
+    float px, py, pz;
+    int tri;  // leaf-order triangle index
+    float lx, ly, lz;
+};
+
+// ------------------------------------------------------------------ camera.cuh:31-34
+struct Camera {
+    V3 lookfrom, upper_left, horizontal, vertical;
+};
+RT_DEV void camera_get_ray(const Camera &c, float x, float y, V3 &o, V3 &d) {
+    V3 dir = sub(add(add(c.upper_left, scale(c.horizontal, x)), scale(c.vertical, y)), c.lookfrom);
+    o = c.lookfrom;
+    d = unit(dir);
+}
+
+}  // namespace rt
+#endif  // RT_DEVICE_H

@@ -1,0 +1,1200 @@
+// rtcuda_amd.hip -- HIP kernels and the C-ABI of the MI355X-native render path (gfx950 only).
+//
+// The hot path of lashhw/rtcuda (render.cuh:61-457) re-designed for CDNA4:
+//
+//   * Path state lives in structure-of-arrays pools indexed by path SLOT (the reference keeps
+//     28-byte AoS rays and pointer-chasing payloads: render.cuh:5-23).
+//   * Slot s owns RNG stream s and serves exactly the camera rays c with c % W == s
+//     (W = 1048576): in the reference every slot regenerates in lockstep (bounces is incremented
+//     unconditionally, render.cuh:126, and reset only by gen, :268), so the rank of a slot in the
+//     compacted gen queue is always the slot id itself.  A slot's history therefore never depends
+//     on any other slot, and a slot may start its next camera ray as soon as its current path can
+//     do nothing more.  That removes the reference's idle iterations (the
+//     active fraction decays 100 % -> 2 % inside every 11-iteration generation) without changing
+//     one random number, and makes the image invariant under any partition of the slots -- which
+//     is how the work is sharded over GPUs.
+//   * One round = three kernels, no host synchronisation inside the loop (the reference does four
+//     blocking 4-byte read-backs per iteration: render.cuh:433-434,444-445):
+//       k_advance        init() + mat() + gen() fused per slot (render.cuh:84-275): emission,
+//                        Russian roulette (repeated for "killed" slots exactly as the reference
+//                        re-rolls them), BSDF sampling, NEE; writes the next path ray in place and
+//                        appends the shadow ray to a compact queue with one atomic per wave
+//                        (ballot + mbcnt) instead of flag arrays + CUB select (render.cuh:348-364)
+//       k_trace_closest  ch() (render.cuh:297-328): BVH closest hit, traversal stack in LDS
+//       k_trace_any      ah() (render.cuh:278-294): any-hit over the shadow queue, float atomics
+//                        into the raw-sum framebuffer
+//   * BVH: 64-byte pair records (both child boxes + links in one line), triangles as 48-byte
+//     {p0,e1,e2,n} records in leaf order (rt_bvh.h).
+//
+// No MFMA anywhere: there is no dense contraction on this path.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/rtcuda_amd.h"
+#include "rt_bvh.h"
+#include "rt_device.h"
+
+using namespace rt;
+
+// ============================================================================ error handling
+namespace {
+thread_local std::string g_last_error;
+int fail(const std::string &msg) {
+    g_last_error = msg;
+    return 1;
+}
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess)                                                                  \
+            return fail(std::string(#expr) + ": " + hipGetErrorString(_e) + " (" __FILE__ ":" + \
+                        std::to_string(__LINE__) + ")");                                       \
+    } while (0)
+
+constexpr int kW = RT_NUM_WORKING_PATHS;
+constexpr int kBlock = 256;       // 4 waves per workgroup
+constexpr int kStackDepth = 32;   // LDS traversal stack entries per lane (tree depth is checked against it)
+}  // namespace
+
+// ============================================================================ device structures
+struct DScene {
+    const float4 *pairs;   // 4 x float4 per pair record
+    const float4 *tris;    // 3 x float4 per triangle, leaf order
+    const int2 *tri_info;  // leaf order: {material index, light index or -1}
+    const Material *mats;
+    const Light *lights;
+    int num_lights;
+};
+
+// Structure-of-arrays path state for the slots of one shard (n slots each)
+struct DPools {
+    float *ox, *oy, *oz, *dx, *dy, *dz;  // current path ray
+    int *hit_tri;                        // leaf-order triangle of the last closest hit, -1 = miss
+    float *hit_u, *hit_v;
+    float *br, *bg, *bb;  // beta
+    int *bounces;         // as PathRayPayload::bounces; kDone marks an exhausted slot
+    int *pixel;
+    int *gen;  // index of the slot's NEXT camera-ray generation
+    uint32_t *rd, *r0, *r1, *r2, *r3, *r4;  // XORWOW state
+    // shadow-ray queue (compact)
+    float *sox, *soy, *soz, *sdx, *sdy, *sdz, *stmax, *slr, *slg, *slb;
+    int *spixel, *starget;
+};
+
+struct DCounters {
+    unsigned long long camera_rays, shade_events, closest_rays, any_rays, emission_adds, shadow_adds, rr_draws;
+    unsigned long long pad;
+    unsigned int shadow_count[2];  // queue fill, double-buffered by round parity
+    unsigned int pad2[2];
+};
+
+constexpr int kDone = -0x7fffffff;
+
+// ============================================================================ wave helpers
+__device__ __forceinline__ unsigned lane_id() {
+    return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+}
+// number of set bits of `mask` below this lane
+__device__ __forceinline__ unsigned prefix_popc(unsigned long long mask) {
+    return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+}
+// one atomic per wave: add popc(ballot(pred)) to *counter
+__device__ __forceinline__ void wave_count(unsigned long long *counter, bool pred) {
+    unsigned long long m = __ballot(pred);
+    if (m != 0 && prefix_popc(m) == 0 && pred) atomicAdd(counter, (unsigned long long)__popcll(m));
+}
+
+// ============================================================================ RNG init kernel
+// curand_init(seed, slot, 0) (render.cuh:68-73): the seed-scrambled state advanced by slot * 2^67
+// draws.  The 2^67-draw jump is the GF(2)-linear map J on the 160 state bits; jump_pow holds
+// J^(2^k), k = 0..19, as 160 rows x 5 words each (row b = image of basis bit b), so J^slot is at
+// most 20 mat-vecs selected by the bits of the slot id.
+__global__ void k_rng_init(DPools p, int n, int slot_lo, Rng seed_state, const uint32_t *__restrict__ jump_pow) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t slot = (uint32_t)(slot_lo + i);
+    uint32_t v[5] = {seed_state.v0, seed_state.v1, seed_state.v2, seed_state.v3, seed_state.v4};
+    for (int k = 0; k < 20; k++) {
+        if (!((slot >> k) & 1u)) continue;
+        const uint32_t *m = jump_pow + (size_t)k * 160 * 5;
+        uint32_t r[5] = {0, 0, 0, 0, 0};
+#pragma unroll
+        for (int w = 0; w < 5; w++) {
+            uint32_t bits = v[w];
+            for (int b = 0; b < 32; b++) {
+                uint32_t sel = 0u - ((bits >> b) & 1u);
+                const uint32_t *row = m + (w * 32 + b) * 5;
+                r[0] ^= row[0] & sel;
+                r[1] ^= row[1] & sel;
+                r[2] ^= row[2] & sel;
+                r[3] ^= row[3] & sel;
+                r[4] ^= row[4] & sel;
+            }
+        }
+#pragma unroll
+        for (int w = 0; w < 5; w++) v[w] = r[w];
+    }
+    p.rd[i] = seed_state.d;
+    p.r0[i] = v[0];
+    p.r1[i] = v[1];
+    p.r2[i] = v[2];
+    p.r3[i] = v[3];
+    p.r4[i] = v[4];
+}
+
+// init_path_ray_payload (render.cuh:75-82): every slot starts "finished" so the first round
+// routes it to gen.  (The reference stores INT_MAX and relies on INT_MAX+1 wrapping; any value
+// >= max_bounces has the same effect on the first init().)
+__global__ void k_pool_init(DPools p, int n, int max_bounces) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    p.hit_tri[i] = -1;
+    p.bounces[i] = max_bounces;
+    p.gen[i] = 0;
+    p.pixel[i] = 0;
+}
+
+// ============================================================================ k_advance
+struct AdvanceParams {
+    int n;        // slots in this shard
+    int slot_lo;  // global id of local slot 0
+    int width, height, spp, max_bounces;
+    long long cam_end;  // width*height*spp
+    int round;
+};
+
+__global__ void __launch_bounds__(kBlock)
+k_advance(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__ fb, DCounters *__restrict__ ctr) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool in_range = i < ap.n;
+    int bounces = in_range ? p.bounces[i] : kDone;
+    bool alive = bounces != kDone;
+
+    bool did_gen = false, did_shade = false, has_shadow = false, did_emit = false;
+    int rr_draws = 0;
+    // shadow ray registers
+    V3 s_o = mk(0, 0, 0), s_d = mk(0, 0, 0), s_L = mk(0, 0, 0);
+    float s_tmax = 0.f;
+    int s_target = -1, pixel = 0;
+
+    if (alive) {
+        Rng rs{p.rd[i], p.r0[i], p.r1[i], p.r2[i], p.r3[i], p.r4[i]};
+        int hit_tri = p.hit_tri[i];
+        pixel = p.pixel[i];
+        V3 beta = mk(p.br[i], p.bg[i], p.bb[i]);
+        bool beta_dirty = false;
+        // Emulate consecutive init() calls (render.cuh:84-137) until one of them ends in mat() or
+        // gen(): a slot whose path missed idles (no RNG use) until bounces reaches max_bounces,
+        // a slot that Russian roulette "killed" is re-rolled every iteration (Appendix A.1).
+        while (true) {
+            bool hit = hit_tri >= 0;
+            if (bounces == 0 && hit) {  // :98-103 emission only at bounce 0
+                int li = sc.tri_info[hit_tri].y;
+                if (li >= 0) {
+                    const Light &l = sc.lights[li];
+                    atomicAdd(&fb[3 * (size_t)pixel + 0], l.lx);
+                    atomicAdd(&fb[3 * (size_t)pixel + 1], l.ly);
+                    atomicAdd(&fb[3 * (size_t)pixel + 2], l.lz);
+                    did_emit = true;
+                }
+            }
+            bool cont = bounces < ap.max_bounces;  // :109
+            bool local_hit = hit;
+            if (cont && hit && bounces > kRrStart) {  // :112-124
+                float bm = max3(beta);
+                if (bm < kRrThreshold) {
+                    float pt = fmaxf(0.05f, 1 - bm);
+                    rr_draws++;
+                    if (rng_uniform(rs) < pt) {
+                        local_hit = false;
+                    } else {
+                        beta = divf(beta, 1 - pt);
+                        beta_dirty = true;
+                    }
+                }
+            }
+            bounces = bounces + 1;  // :126
+            if (cont) {
+                if (local_hit) {
+                    did_shade = true;
+                    break;
+                }
+                if (!hit) bounces = ap.max_bounces;  // idle iterations consume nothing: skip them
+                continue;
+            }
+            // ---- gen() :250-275.  Camera ray id = generation * W + slot (see file header).
+            long long cid = (long long)p.gen[i] * kW + (ap.slot_lo + i);
+            if (cid >= ap.cam_end) {
+                bounces = kDone;
+                break;
+            }
+            p.gen[i] = p.gen[i] + 1;
+            pixel = (int)(cid / ap.spp);
+            int px = pixel % ap.width;
+            int py = pixel / ap.width;
+            float jx = rng_uniform(rs);  // x first, then y (Appendix A.7)
+            float jy = rng_uniform(rs);
+            V3 o, d;
+            camera_get_ray(cam, (px + jx) / ap.width, (py + jy) / ap.height, o, d);
+            p.ox[i] = o.x;
+            p.oy[i] = o.y;
+            p.oz[i] = o.z;
+            p.dx[i] = d.x;
+            p.dy[i] = d.y;
+            p.dz[i] = d.z;
+            p.pixel[i] = pixel;
+            bounces = 0;
+            beta = mk(1.f, 1.f, 1.f);
+            beta_dirty = true;
+            did_gen = true;
+            break;
+        }
+
+        if (did_shade) {
+            // ---- mat() :139-248
+            V3 wo = mk(p.dx[i], p.dy[i], p.dz[i]);
+            float hu = p.hit_u[i], hv = p.hit_v[i];
+            Tri tri = load_tri(sc.tris, hit_tri);
+            int2 info = sc.tri_info[hit_tri];
+            Material m = sc.mats[info.x];
+            V3 multiplier = scale(beta, (float)sc.num_lights);  // taken BEFORE the beta update (:150)
+            V3 isect_p = tri_point(tri, hu, hv);
+            V3 isect_n = neg(unit(tri.n));
+            {
+                V3 n = isect_n, wi;
+                float pdf;
+                V3 f = mat_sample_f(m, wo, rs, n, wi, pdf);
+                V3 o = offset_ray_origin(isect_p, n);
+                p.ox[i] = o.x;
+                p.oy[i] = o.y;
+                p.oz[i] = o.z;
+                p.dx[i] = wi.x;
+                p.dy[i] = wi.y;
+                p.dz[i] = wi.z;
+                beta = mul(beta, divf(scale(f, dot(wi, n)), pdf));  // :166
+                beta_dirty = true;
+            }
+            if (sc.num_lights > 0) {
+                int light_idx = min((int)(rng_uniform(rs) * sc.num_lights), sc.num_lights - 1);  // :178
+                Light light = sc.lights[light_idx];
+                V3 wi, Li;
+                float lt, lpdf;
+                // Light::sample_Li light.cuh:29-48
+                if (light.type == 0) {
+                    wi = sub(mk(light.px, light.py, light.pz), isect_p);
+                    lt = len(wi);
+                    Li = divf(mk(light.lx, light.ly, light.lz), lt * lt);
+                    wi = divf(wi, lt);
+                    lpdf = 1.f;
+                } else {
+                    Tri lt_tri = load_tri(sc.tris, light.tri);
+                    lpdf = 1.f / tri_area(lt_tri);  // Triangle::sample_p triangle.cuh:78-82
+                    float a = sqrtf(rng_uniform(rs));
+                    float u2 = rng_uniform(rs);
+                    V3 tp = tri_point(lt_tri, 1 - a, u2 * a);
+                    wi = sub(tp, isect_p);
+                    lt = len(wi);
+                    wi = divf(wi, lt);
+                    Li = mk(light.lx, light.ly, light.lz);
+                    lpdf *= len2(sub(tp, isect_p)) / fabsf(dot(unit(lt_tri.n), wi));
+                }
+                V3 n = dot(isect_n, wi) > 0.f ? isect_n : neg(isect_n);  // :187
+                V3 f;
+                float spdf;
+                if (mat_get_f(m, wo, wi, n, f, spdf)) {
+                    f = scale(f, dot(wi, n));
+                    s_o = offset_ray_origin(isect_p, n);
+                    s_d = wi;
+                    s_tmax = lt;
+                    s_target = light.type == 1 ? light.tri : -1;
+                    if (light.type == 0) {
+                        s_L = divf(mul(mul(multiplier, f), Li), lpdf);  // :199
+                    } else {
+                        float weight = power_heuristic(lpdf, spdf);  // :201 (int-truncating)
+                        s_L = divf(scale(mul(mul(multiplier, f), Li), weight), lpdf);  // :202
+                    }
+                    has_shadow = true;
+                }
+                // "sample BSDF with MIS" block :213-245: its ray cannot contribute; keep its draws
+                if (light.type != 0) mat_sample_f_burn(m, wo, isect_n, rs);
+            }
+        }
+        if (beta_dirty) {
+            p.br[i] = beta.x;
+            p.bg[i] = beta.y;
+            p.bb[i] = beta.z;
+        }
+        p.bounces[i] = bounces;
+        p.rd[i] = rs.d;
+        p.r0[i] = rs.v0;
+        p.r1[i] = rs.v1;
+        p.r2[i] = rs.v2;
+        p.r3[i] = rs.v3;
+        p.r4[i] = rs.v4;
+    }
+
+    // ---- shadow queue append: one atomic per wave
+    unsigned long long m = __ballot(has_shadow);
+    if (m != 0) {
+        unsigned rank = prefix_popc(m);
+        unsigned base = 0;
+        int leader = __builtin_ctzll(m);
+        if ((int)lane_id() == leader) base = atomicAdd(&ctr->shadow_count[ap.round & 1], (unsigned)__popcll(m));
+        base = __shfl(base, leader);
+        if (has_shadow) {
+            unsigned q = base + rank;
+            p.sox[q] = s_o.x;
+            p.soy[q] = s_o.y;
+            p.soz[q] = s_o.z;
+            p.sdx[q] = s_d.x;
+            p.sdy[q] = s_d.y;
+            p.sdz[q] = s_d.z;
+            p.stmax[q] = s_tmax;
+            p.slr[q] = s_L.x;
+            p.slg[q] = s_L.y;
+            p.slb[q] = s_L.z;
+            p.spixel[q] = pixel;
+            p.starget[q] = s_target;
+        }
+    }
+    // ---- counters (one atomic per wave each)
+    wave_count(&ctr->camera_rays, did_gen);
+    wave_count(&ctr->shade_events, did_shade);
+    wave_count(&ctr->closest_rays, did_gen || did_shade);
+    wave_count(&ctr->any_rays, has_shadow);
+    wave_count(&ctr->emission_adds, did_emit);
+    if (__ballot(rr_draws != 0)) {
+        int tot = rr_draws;
+        for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off);
+        if (lane_id() == 0) atomicAdd(&ctr->rr_draws, (unsigned long long)tot);
+    }
+}
+
+// ============================================================================ traversal
+// Conservative slab test of one child box (boxes are padded by the builder, the exit distance is
+// widened by 2 ulp): may accept a box the ray misses, never rejects one it hits.
+struct RayPrep {
+    V3 o, d, inv;
+};
+__device__ __forceinline__ RayPrep prep_ray(V3 o, V3 d) {
+    RayPrep r;
+    r.o = o;
+    r.d = d;
+    // aabb_intersector.cuh:17-19 clamps |d| away from 0 the same way before inverting
+    float ix = 1.f / ((fabsf(d.x) < kFltEps) ? copysignf(kFltEps, d.x) : d.x);
+    float iy = 1.f / ((fabsf(d.y) < kFltEps) ? copysignf(kFltEps, d.y) : d.y);
+    float iz = 1.f / ((fabsf(d.z) < kFltEps) ? copysignf(kFltEps, d.z) : d.z);
+    r.inv = mk(ix, iy, iz);
+    return r;
+}
+__device__ __forceinline__ bool box_hit(const RayPrep &r, float lox, float loy, float loz, float hix, float hiy,
+                                        float hiz, float tmax, float &entry) {
+    float ax = (lox - r.o.x) * r.inv.x, bx = (hix - r.o.x) * r.inv.x;
+    float ay = (loy - r.o.y) * r.inv.y, by = (hiy - r.o.y) * r.inv.y;
+    float az = (loz - r.o.z) * r.inv.z, bz = (hiz - r.o.z) * r.inv.z;
+    float t_in = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+    float t_out = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+    entry = t_in;
+    t_out = t_out * 1.0000004f;
+    return t_in <= t_out && t_out >= 0.f && t_in <= tmax;
+}
+
+// Closest hit (Bvh::traverse, bvh.cuh:251-303).  Returns leaf-order triangle or -1.
+// stack: this lane's column of the LDS stack, element k at stack[k * kBlock].
+__device__ __forceinline__ int traverse_closest(const DScene &sc, V3 o, V3 d, float tmax, int *stack, float &t_hit,
+                                                float &u_hit, float &v_hit) {
+    RayPrep r = prep_ray(o, d);
+    int best = -1;
+    int sp = 0;
+    int node = 0;
+    while (true) {
+        const float4 *q = sc.pairs + 4 * (size_t)node;
+        float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+        int llink = __float_as_int(q3.x), rlink = __float_as_int(q3.y);
+        int lcount = __float_as_int(q3.z), rcount = __float_as_int(q3.w);
+        float el, er;
+        bool hl = box_hit(r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tmax, el);
+        bool hr = box_hit(r, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tmax, er);
+        if (hl && lcount > 0) {
+            for (int k = llink; k < llink + lcount; k++) {
+                Tri tr = load_tri(sc.tris, k);
+                if (tri_intersect(tr, o, d, tmax, t_hit, u_hit, v_hit)) {
+                    tmax = t_hit;
+                    best = k;
+                }
+            }
+        }
+        if (hr && rcount > 0) {
+            for (int k = rlink; k < rlink + rcount; k++) {
+                Tri tr = load_tri(sc.tris, k);
+                if (tri_intersect(tr, o, d, tmax, t_hit, u_hit, v_hit)) {
+                    tmax = t_hit;
+                    best = k;
+                }
+            }
+        }
+        bool il = hl && lcount == 0 && llink >= 0;
+        bool ir = hr && rcount == 0 && rlink >= 0;
+        if (il && ir) {
+            int near = el > er ? rlink : llink;
+            int far = el > er ? llink : rlink;
+            stack[sp * kBlock] = far;
+            sp++;
+            node = near;
+        } else if (il) {
+            node = llink;
+        } else if (ir) {
+            node = rlink;
+        } else {
+            if (sp == 0) break;
+            sp--;
+            node = stack[sp * kBlock];
+        }
+    }
+    return best;
+}
+
+// Any hit excluding one triangle (bvh.cuh:306-357): true if occluded.
+__device__ __forceinline__ bool traverse_any(const DScene &sc, V3 o, V3 d, float tmax, int excluded, int *stack) {
+    RayPrep r = prep_ray(o, d);
+    int sp = 0;
+    int node = 0;
+    while (true) {
+        const float4 *q = sc.pairs + 4 * (size_t)node;
+        float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+        int llink = __float_as_int(q3.x), rlink = __float_as_int(q3.y);
+        int lcount = __float_as_int(q3.z), rcount = __float_as_int(q3.w);
+        float el, er;
+        bool hl = box_hit(r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tmax, el);
+        bool hr = box_hit(r, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tmax, er);
+        float t, u, v;
+        if (hl && lcount > 0) {
+            for (int k = llink; k < llink + lcount; k++) {
+                Tri tr = load_tri(sc.tris, k);
+                if (tri_intersect(tr, o, d, tmax, t, u, v) && k != excluded) return true;
+            }
+        }
+        if (hr && rcount > 0) {
+            for (int k = rlink; k < rlink + rcount; k++) {
+                Tri tr = load_tri(sc.tris, k);
+                if (tri_intersect(tr, o, d, tmax, t, u, v) && k != excluded) return true;
+            }
+        }
+        bool il = hl && lcount == 0 && llink >= 0;
+        bool ir = hr && rcount == 0 && rlink >= 0;
+        if (il && ir) {
+            int near = el > er ? rlink : llink;
+            int far = el > er ? llink : rlink;
+            stack[sp * kBlock] = far;
+            sp++;
+            node = near;
+        } else if (il) {
+            node = llink;
+        } else if (ir) {
+            node = rlink;
+        } else {
+            if (sp == 0) break;
+            sp--;
+            node = stack[sp * kBlock];
+        }
+    }
+    return false;
+}
+
+// ch() for path rays (render.cuh:297-316)
+__global__ void __launch_bounds__(kBlock) k_trace_closest(DScene sc, DPools p, int n) {
+    __shared__ int s_stack[kStackDepth * kBlock];
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (p.bounces[i] == kDone) return;
+    V3 o = mk(p.ox[i], p.oy[i], p.oz[i]);
+    V3 d = mk(p.dx[i], p.dy[i], p.dz[i]);
+    float t = 0.f, u = 0.f, v = 0.f;
+    int best = traverse_closest(sc, o, d, kFltMax, s_stack + threadIdx.x, t, u, v);
+    p.hit_tri[i] = best;
+    p.hit_u[i] = u;
+    p.hit_v[i] = v;
+}
+
+// ah() (render.cuh:278-294) over the compact shadow queue of this round
+__global__ void __launch_bounds__(kBlock)
+k_trace_any(DScene sc, DPools p, int round, float *__restrict__ fb, DCounters *__restrict__ ctr) {
+    __shared__ int s_stack[kStackDepth * kBlock];
+    unsigned count = ctr->shadow_count[round & 1];
+    unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool deposit = false;
+    if (i < count) {
+        V3 o = mk(p.sox[i], p.soy[i], p.soz[i]);
+        V3 d = mk(p.sdx[i], p.sdy[i], p.sdz[i]);
+        bool occluded = traverse_any(sc, o, d, p.stmax[i], p.starget[i], s_stack + threadIdx.x);
+        if (!occluded) {
+            int pixel = p.spixel[i];
+            atomicAdd(&fb[3 * (size_t)pixel + 0], p.slr[i]);
+            atomicAdd(&fb[3 * (size_t)pixel + 1], p.slg[i]);
+            atomicAdd(&fb[3 * (size_t)pixel + 2], p.slb[i]);
+            deposit = true;
+        }
+    }
+    wave_count(&ctr->shadow_adds, deposit);
+    // the other parity's counter is idle during this kernel: clear it for the next round
+    if (blockIdx.x == 0 && threadIdx.x == 0) ctr->shadow_count[(round + 1) & 1] = 0;
+}
+
+// post_process_framebuffer (render.cuh:330-338): c = sqrt(c * (1/spp))
+__global__ void k_post_process(float *fb, int n_values, float inv_spp) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_values) fb[i] = sqrtf(fb[i] * inv_spp);
+}
+
+// ---- stage-level test kernels (rays given as AoS xyz triples)
+__global__ void __launch_bounds__(kBlock)
+k_test_closest(DScene sc, int n, const float *__restrict__ o3, const float *__restrict__ d3,
+               const float *__restrict__ tmax, const int *__restrict__ order, int *__restrict__ hit_tri,
+               float *__restrict__ t_out, float *__restrict__ u_out, float *__restrict__ v_out) {
+    __shared__ int s_stack[kStackDepth * kBlock];
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    V3 o = mk(o3[3 * i], o3[3 * i + 1], o3[3 * i + 2]);
+    V3 d = mk(d3[3 * i], d3[3 * i + 1], d3[3 * i + 2]);
+    float t = 0.f, u = 0.f, v = 0.f;
+    int best = traverse_closest(sc, o, d, tmax[i], s_stack + threadIdx.x, t, u, v);
+    hit_tri[i] = best >= 0 ? order[best] : -1;
+    t_out[i] = t;
+    u_out[i] = u;
+    v_out[i] = v;
+}
+__global__ void __launch_bounds__(kBlock)
+k_test_any(DScene sc, int n, const float *__restrict__ o3, const float *__restrict__ d3,
+           const float *__restrict__ tmax, const int *__restrict__ excluded_leaf, int *__restrict__ occluded) {
+    __shared__ int s_stack[kStackDepth * kBlock];
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    V3 o = mk(o3[3 * i], o3[3 * i + 1], o3[3 * i + 2]);
+    V3 d = mk(d3[3 * i], d3[3 * i + 1], d3[3 * i + 2]);
+    occluded[i] = traverse_any(sc, o, d, tmax[i], excluded_leaf[i], s_stack + threadIdx.x) ? 1 : 0;
+}
+__global__ void k_test_draw(DPools p, int n, int draws, uint32_t *__restrict__ state6, float *__restrict__ uni) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Rng rs{p.rd[i], p.r0[i], p.r1[i], p.r2[i], p.r3[i], p.r4[i]};
+    for (int k = 0; k < draws; k++) uni[(size_t)i * draws + k] = rng_uniform(rs);
+    state6[6 * (size_t)i + 0] = rs.d;
+    state6[6 * (size_t)i + 1] = rs.v0;
+    state6[6 * (size_t)i + 2] = rs.v1;
+    state6[6 * (size_t)i + 3] = rs.v2;
+    state6[6 * (size_t)i + 4] = rs.v3;
+    state6[6 * (size_t)i + 5] = rs.v4;
+}
+__global__ void k_copy_f4(const float4 *__restrict__ src, float4 *__restrict__ dst, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) dst[i] = src[i];
+}
+
+// ============================================================================ host side
+struct rt_scene {
+    int device = 0;
+    int n_tris = 0, n_pairs = 0, max_depth = 0, n_leaves = 0, n_lights = 0, n_mats = 0;
+    float4 *d_pairs = nullptr;
+    float4 *d_tris = nullptr;
+    int2 *d_tri_info = nullptr;
+    Material *d_mats = nullptr;
+    Light *d_lights = nullptr;
+    int *d_order = nullptr;       // leaf order -> original
+    std::vector<int> h_order;     // leaf order -> original
+    std::vector<int> h_inverse;   // original -> leaf order
+    DScene dev() const {
+        DScene s;
+        s.pairs = d_pairs;
+        s.tris = d_tris;
+        s.tri_info = d_tri_info;
+        s.mats = d_mats;
+        s.lights = d_lights;
+        s.num_lights = n_lights;
+        return s;
+    }
+};
+
+namespace {
+
+// ---- XORWOW host pieces: seed scramble and the 2^67 jump matrices J^(2^k)
+Rng xorwow_seed(uint64_t seed) {  // curand_init's scramble (curand_kernel.h)
+    uint32_t s0 = ((uint32_t)seed) ^ 0xaad26b49u;
+    uint32_t s1 = ((uint32_t)(seed >> 32)) ^ 0xf7dcefddu;
+    uint32_t t0 = 1099087573u * s0;
+    uint32_t t1 = 2591861531u * s1;
+    Rng st;
+    st.d = 6615241u + t1 + t0;
+    st.v0 = 123456789u + t0;
+    st.v1 = 362436069u ^ t0;
+    st.v2 = 521288629u + t1;
+    st.v3 = 88675123u ^ t1;
+    st.v4 = 5783321u + t0;
+    return st;
+}
+typedef uint32_t Mat160[160][5];
+void mat160_apply(const Mat160 &m, const uint32_t in[5], uint32_t out[5]) {
+    uint32_t r[5] = {0, 0, 0, 0, 0};
+    for (int w = 0; w < 5; w++)
+        for (int b = 0; b < 32; b++)
+            if (in[w] & (1u << b))
+                for (int k = 0; k < 5; k++) r[k] ^= m[w * 32 + b][k];
+    memcpy(out, r, sizeof(r));
+}
+void mat160_square(Mat160 &m) {
+    static Mat160 tmp;
+    for (int i = 0; i < 160; i++) mat160_apply(m, m[i], tmp[i]);
+    memcpy(m, tmp, sizeof(Mat160));
+}
+// host table: 20 matrices J^(2^k), J = (one xorwow step)^(2^67)
+const std::vector<uint32_t> &jump_powers() {
+    static std::vector<uint32_t> table;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        static Mat160 a;
+        for (int w = 0; w < 5; w++)
+            for (int b = 0; b < 32; b++) {
+                uint32_t v[5] = {0, 0, 0, 0, 0};
+                v[w] = 1u << b;
+                uint32_t t = v[0] ^ (v[0] >> 2);
+                v[0] = v[1];
+                v[1] = v[2];
+                v[2] = v[3];
+                v[3] = v[4];
+                v[4] = (v[4] ^ (v[4] << 4)) ^ (t ^ (t << 1));
+                memcpy(a[w * 32 + b], v, sizeof(v));
+            }
+        for (int s = 0; s < 67; s++) mat160_square(a);
+        table.resize((size_t)20 * 160 * 5);
+        for (int k = 0; k < 20; k++) {
+            memcpy(table.data() + (size_t)k * 800, a, sizeof(Mat160));
+            mat160_square(a);
+        }
+    });
+    return table;
+}
+
+// ---- per-device render context: pools are allocated once per (device, n) and reused
+struct Context {
+    int device = -1;
+    int n = 0;
+    DPools pools{};
+    std::vector<void *> allocs;
+    DCounters *d_ctr = nullptr;
+    DCounters *h_ctr = nullptr;  // pinned ring of snapshots
+    uint32_t *d_jump = nullptr;
+    hipEvent_t ev_ring[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr;
+    // RNG states are a pure function of (seed, slot range): keep them cached across renders
+    uint64_t rng_seed = 0;
+    int rng_lo = -1;
+    bool rng_valid = false;
+    uint32_t *rng_backup = nullptr;  // 6 x n words
+};
+std::mutex g_ctx_mutex;
+std::vector<std::unique_ptr<Context>> g_contexts;
+
+template <typename T>
+int dev_alloc(Context &c, T *&ptr, size_t count) {
+    void *raw = nullptr;
+    HIP_TRY(hipMalloc(&raw, count * sizeof(T)));
+    c.allocs.push_back(raw);
+    ptr = (T *)raw;
+    return 0;
+}
+
+int get_context(int n, Context **out) {
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(g_ctx_mutex);
+    for (auto &c : g_contexts)
+        if (c->device == dev && c->n == n) {
+            *out = c.get();
+            return 0;
+        }
+    auto c = std::make_unique<Context>();
+    c->device = dev;
+    c->n = n;
+    DPools &p = c->pools;
+    float **fptrs[] = {&p.ox, &p.oy, &p.oz, &p.dx, &p.dy, &p.dz, &p.hit_u, &p.hit_v, &p.br, &p.bg, &p.bb,
+                       &p.sox, &p.soy, &p.soz, &p.sdx, &p.sdy, &p.sdz, &p.stmax, &p.slr, &p.slg, &p.slb};
+    for (float **f : fptrs)
+        if (dev_alloc(*c, *f, (size_t)n)) return 1;
+    int **iptrs[] = {&p.hit_tri, &p.bounces, &p.pixel, &p.gen, &p.spixel, &p.starget};
+    for (int **f : iptrs)
+        if (dev_alloc(*c, *f, (size_t)n)) return 1;
+    uint32_t **uptrs[] = {&p.rd, &p.r0, &p.r1, &p.r2, &p.r3, &p.r4};
+    for (uint32_t **f : uptrs)
+        if (dev_alloc(*c, *f, (size_t)n)) return 1;
+    if (dev_alloc(*c, c->rng_backup, (size_t)6 * n)) return 1;
+    if (dev_alloc(*c, c->d_ctr, 1)) return 1;
+    if (dev_alloc(*c, c->d_jump, (size_t)20 * 800)) return 1;
+    HIP_TRY(hipMemcpy(c->d_jump, jump_powers().data(), sizeof(uint32_t) * 20 * 800, hipMemcpyHostToDevice));
+    HIP_TRY(hipHostMalloc((void **)&c->h_ctr, sizeof(DCounters) * 4, hipHostMallocDefault));
+    for (auto &e : c->ev_ring) HIP_TRY(hipEventCreate(&e));
+    HIP_TRY(hipEventCreate(&c->ev_a));
+    HIP_TRY(hipEventCreate(&c->ev_b));
+    HIP_TRY(hipEventCreate(&c->ev_c));
+    *out = c.get();
+    g_contexts.push_back(std::move(c));
+    return 0;
+}
+
+int grid_for(int n) { return (n + kBlock - 1) / kBlock; }
+
+int ensure_rng(Context &c, uint64_t seed, int slot_lo, hipStream_t st, double *seconds) {
+    const size_t bytes = sizeof(uint32_t) * (size_t)c.n;
+    uint32_t *parts[6] = {c.pools.rd, c.pools.r0, c.pools.r1, c.pools.r2, c.pools.r3, c.pools.r4};
+    *seconds = 0.0;
+    if (!(c.rng_valid && c.rng_seed == seed && c.rng_lo == slot_lo)) {
+        HIP_TRY(hipEventRecord(c.ev_a, st));
+        hipLaunchKernelGGL(k_rng_init, dim3(grid_for(c.n)), dim3(kBlock), 0, st, c.pools, c.n, slot_lo,
+                           xorwow_seed(seed), c.d_jump);
+        HIP_TRY(hipGetLastError());
+        for (int k = 0; k < 6; k++)
+            HIP_TRY(hipMemcpyAsync(c.rng_backup + (size_t)k * c.n, parts[k], bytes, hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipEventRecord(c.ev_b, st));
+        HIP_TRY(hipEventSynchronize(c.ev_b));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, c.ev_a, c.ev_b));
+        *seconds = ms * 1e-3;
+        c.rng_valid = true;
+        c.rng_seed = seed;
+        c.rng_lo = slot_lo;
+    } else {
+        for (int k = 0; k < 6; k++)
+            HIP_TRY(hipMemcpyAsync(parts[k], c.rng_backup + (size_t)k * c.n, bytes, hipMemcpyDeviceToDevice, st));
+    }
+    return 0;
+}
+
+int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width, int height, int spp,
+                      int max_bounces, uint64_t seed, int shard_index, int shard_count, uint32_t flags,
+                      float *d_sum, hipStream_t st, rt_stats *stats) {
+    if (!scene || !camera || !d_sum) return fail("rt_render_shard: null argument");
+    if (width <= 0 || height <= 0 || spp <= 0 || max_bounces < 0) return fail("rt_render_shard: bad dimensions");
+    if (shard_count <= 0 || kW % shard_count != 0 || shard_index < 0 || shard_index >= shard_count)
+        return fail("rt_render_shard: shard_count must divide 1048576 and 0 <= shard_index < shard_count");
+    long long cam_end = (long long)width * height * spp;
+    if (cam_end + 13LL * kW >= (1LL << 31))  // the reference's int32 camera_ray ids (render.cuh:370-371,440)
+        return fail("rt_render_shard: width*height*spp exceeds the reference's int32 camera-ray range");
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev != scene->device) return fail("rt_render_shard: scene was created on another device");
+    const int n = kW / shard_count;
+    const int slot_lo = shard_index * n;
+    Context *cp = nullptr;
+    if (get_context(n, &cp)) return 1;
+    Context &c = *cp;
+    double rng_seconds = 0.0;
+    if (ensure_rng(c, seed, slot_lo, st, &rng_seconds)) return 1;
+
+    const bool time_kernels = (flags & RT_FLAG_TIME_KERNELS) != 0;
+    DScene sc = scene->dev();
+    Camera cam;
+    memcpy(&cam, camera, sizeof(Camera));
+    HIP_TRY(hipMemsetAsync(c.d_ctr, 0, sizeof(DCounters), st));
+    hipLaunchKernelGGL(k_pool_init, dim3(grid_for(n)), dim3(kBlock), 0, st, c.pools, n, max_bounces);
+    HIP_TRY(hipGetLastError());
+
+    AdvanceParams ap;
+    ap.n = n;
+    ap.slot_lo = slot_lo;
+    ap.width = width;
+    ap.height = height;
+    ap.spp = spp;
+    ap.max_bounces = max_bounces;
+    ap.cam_end = cam_end;
+    ap.round = 0;
+
+    hipEvent_t ev_start, ev_stop;
+    HIP_TRY(hipEventCreate(&ev_start));
+    HIP_TRY(hipEventCreate(&ev_stop));
+    HIP_TRY(hipEventRecord(ev_start, st));
+
+    // Rounds are enqueued in batches; after each batch the counters are snapshotted into pinned
+    // host memory.  The host looks at the snapshot of batch b-2 before enqueuing batch b, so the
+    // GPU always has work queued, and stops when a whole batch traced no ray.
+    const int kBatch = 8;
+    const long long generations = (cam_end + kW - 1) / kW;
+    const long long max_rounds = (generations + 1) * (long long)(max_bounces + 2) + 64;
+    long long rounds = 0;
+    unsigned long long last_closest = ~0ull;
+    int batch = 0;
+    bool finished = false;
+    double t_adv = 0, t_ch = 0, t_ah = 0;
+    long long n_ch_launch = 0;
+    const dim3 grid(grid_for(n)), block(kBlock);
+    while (!finished && rounds < max_rounds) {
+        for (int k = 0; k < kBatch; k++) {
+            ap.round = (int)(rounds & 0x3fffffff);
+            if (time_kernels) {
+                float ms;
+                HIP_TRY(hipEventRecord(c.ev_a, st));
+                hipLaunchKernelGGL(k_advance, grid, block, 0, st, sc, c.pools, cam, ap, d_sum, c.d_ctr);
+                HIP_TRY(hipEventRecord(c.ev_b, st));
+                hipLaunchKernelGGL(k_trace_closest, grid, block, 0, st, sc, c.pools, n);
+                HIP_TRY(hipEventRecord(c.ev_c, st));
+                HIP_TRY(hipEventSynchronize(c.ev_c));
+                HIP_TRY(hipEventElapsedTime(&ms, c.ev_a, c.ev_b));
+                t_adv += ms;
+                HIP_TRY(hipEventElapsedTime(&ms, c.ev_b, c.ev_c));
+                t_ch += ms;
+                n_ch_launch++;
+                HIP_TRY(hipEventRecord(c.ev_a, st));
+                hipLaunchKernelGGL(k_trace_any, grid, block, 0, st, sc, c.pools, ap.round, d_sum, c.d_ctr);
+                HIP_TRY(hipEventRecord(c.ev_b, st));
+                HIP_TRY(hipEventSynchronize(c.ev_b));
+                HIP_TRY(hipEventElapsedTime(&ms, c.ev_a, c.ev_b));
+                t_ah += ms;
+            } else {
+                hipLaunchKernelGGL(k_advance, grid, block, 0, st, sc, c.pools, cam, ap, d_sum, c.d_ctr);
+                hipLaunchKernelGGL(k_trace_closest, grid, block, 0, st, sc, c.pools, n);
+                hipLaunchKernelGGL(k_trace_any, grid, block, 0, st, sc, c.pools, ap.round, d_sum, c.d_ctr);
+            }
+            rounds++;
+        }
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(&c.h_ctr[batch & 3], c.d_ctr, sizeof(DCounters), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipEventRecord(c.ev_ring[batch & 3], st));
+        if (batch >= 1) {
+            int prev = (batch - 1) & 3;
+            HIP_TRY(hipEventSynchronize(c.ev_ring[prev]));
+            unsigned long long cl = c.h_ctr[prev].closest_rays;
+            if (cl == last_closest) finished = true;  // a whole batch without a single traced ray
+            last_closest = cl;
+        }
+        batch++;
+    }
+    HIP_TRY(hipEventRecord(ev_stop, st));
+    HIP_TRY(hipEventSynchronize(ev_stop));
+    float ms_total = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms_total, ev_start, ev_stop));
+    HIP_TRY(hipEventDestroy(ev_start));
+    HIP_TRY(hipEventDestroy(ev_stop));
+    DCounters fin;
+    HIP_TRY(hipMemcpy(&fin, c.d_ctr, sizeof(DCounters), hipMemcpyDeviceToHost));
+    if (!finished) return fail("rt_render_shard: round limit reached before the path pool drained");
+    if (stats) {
+        memset(stats, 0, sizeof(*stats));
+        stats->camera_rays = (int64_t)fin.camera_rays;
+        stats->shade_events = (int64_t)fin.shade_events;
+        stats->closest_rays = (int64_t)fin.closest_rays;
+        stats->any_rays = (int64_t)fin.any_rays;
+        stats->emission_adds = (int64_t)fin.emission_adds;
+        stats->shadow_adds = (int64_t)fin.shadow_adds;
+        stats->rr_draws = (int64_t)fin.rr_draws;
+        stats->iterations = rounds;
+        stats->bvh_nodes = scene->n_pairs;
+        stats->bvh_depth = scene->max_depth;
+        stats->seconds_render = ms_total * 1e-3;
+        stats->seconds_rng_init = rng_seconds;
+        stats->seconds_closest = t_ch * 1e-3;
+        stats->seconds_any = t_ah * 1e-3;
+        stats->seconds_advance = t_adv * 1e-3;
+        stats->launches_closest = n_ch_launch;
+    }
+    return 0;
+}
+
+}  // namespace
+
+// ============================================================================ C-ABI
+extern "C" {
+
+const char *rt_last_error(void) { return g_last_error.c_str(); }
+const char *rt_version(void) { return "rtcuda_amd 0.1 (gfx950)"; }
+
+int rt_scene_create(const float *tri_p0p1p2, int n_tris, const int32_t *tri_material, const int32_t *tri_light,
+                    const rt_material *materials, int n_materials, const rt_light *lights, int n_lights,
+                    rt_scene **out_scene) {
+    if (!out_scene) return fail("rt_scene_create: out_scene is null");
+    *out_scene = nullptr;
+    if (n_tris < 0 || n_materials < 0 || n_lights < 0) return fail("rt_scene_create: negative count");
+    if (n_tris > 0 && (!tri_p0p1p2 || !tri_material)) return fail("rt_scene_create: null triangle arrays");
+    if (n_tris > 0 && (n_materials == 0 || !materials)) return fail("rt_scene_create: no materials");
+    if (n_lights > 0 && !lights) return fail("rt_scene_create: null lights");
+    for (int i = 0; i < n_tris; i++) {
+        if (tri_material[i] < 0 || tri_material[i] >= n_materials)
+            return fail("rt_scene_create: tri_material[" + std::to_string(i) + "] out of range");
+        if (tri_light && (tri_light[i] < -1 || tri_light[i] >= n_lights))
+            return fail("rt_scene_create: tri_light[" + std::to_string(i) + "] out of range");
+    }
+    for (int i = 0; i < n_materials; i++)
+        if (materials[i].type < RT_MATTE || materials[i].type > RT_GLASS)
+            return fail("rt_scene_create: unknown material type");
+    for (int i = 0; i < n_lights; i++) {
+        if (lights[i].type != RT_POINT_LIGHT && lights[i].type != RT_AREA_LIGHT)
+            return fail("rt_scene_create: unknown light type");
+        if (lights[i].type == RT_AREA_LIGHT && (lights[i].triangle < 0 || lights[i].triangle >= n_tris))
+            return fail("rt_scene_create: area light triangle out of range");
+    }
+    auto sc = std::make_unique<rt_scene>();
+    HIP_TRY(hipGetDevice(&sc->device));
+    rtbvh::Result bvh = rtbvh::build(tri_p0p1p2, n_tris);
+    if (bvh.max_depth > kStackDepth + 1)
+        return fail("rt_scene_create: BVH depth " + std::to_string(bvh.max_depth) + " exceeds the traversal stack");
+    sc->n_tris = n_tris;
+    sc->n_pairs = (int)bvh.pairs.size();
+    sc->max_depth = bvh.max_depth;
+    sc->n_leaves = bvh.num_leaves;
+    sc->n_lights = n_lights;
+    sc->n_mats = n_materials;
+    sc->h_order.assign(bvh.order.begin(), bvh.order.end());
+    sc->h_inverse.assign(n_tris, 0);
+    for (int k = 0; k < n_tris; k++) sc->h_inverse[sc->h_order[k]] = k;
+    // triangle records in leaf order: e1 = p0 - p1, e2 = p2 - p0, n = e1 x e2 (triangle.cuh:6-7),
+    // computed here in fp32 without contraction (this file is built with -ffp-contract=off)
+    std::vector<float> trec((size_t)12 * std::max(n_tris, 1));
+    std::vector<int2> info(std::max(n_tris, 1));
+    for (int k = 0; k < n_tris; k++) {
+        int i = sc->h_order[k];
+        const float *q = tri_p0p1p2 + 9 * (size_t)i;
+        float p0[3] = {q[0], q[1], q[2]};
+        float e1[3] = {q[0] - q[3], q[1] - q[4], q[2] - q[5]};
+        float e2[3] = {q[6] - q[0], q[7] - q[1], q[8] - q[2]};
+        float nn[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+        float *r = trec.data() + 12 * (size_t)k;
+        r[0] = p0[0]; r[1] = p0[1]; r[2] = p0[2];
+        r[3] = e1[0]; r[4] = e1[1]; r[5] = e1[2];
+        r[6] = e2[0]; r[7] = e2[1]; r[8] = e2[2];
+        r[9] = nn[0]; r[10] = nn[1]; r[11] = nn[2];
+        info[k] = make_int2(tri_material[i], tri_light ? tri_light[i] : -1);
+    }
+    std::vector<Light> dl(std::max(n_lights, 1));
+    for (int i = 0; i < n_lights; i++) {
+        memcpy(&dl[i], &lights[i], sizeof(Light));
+        if (lights[i].type == RT_AREA_LIGHT) dl[i].tri = sc->h_inverse[lights[i].triangle];
+    }
+    static_assert(sizeof(Light) == sizeof(rt_light), "light layout");
+    static_assert(sizeof(Material) == sizeof(rt_material), "material layout");
+    static_assert(sizeof(Camera) == sizeof(rt_camera), "camera layout");
+    HIP_TRY(hipMalloc((void **)&sc->d_pairs, sizeof(rtbvh::Pair) * bvh.pairs.size()));
+    HIP_TRY(hipMemcpy(sc->d_pairs, bvh.pairs.data(), sizeof(rtbvh::Pair) * bvh.pairs.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc((void **)&sc->d_tris, sizeof(float) * trec.size()));
+    HIP_TRY(hipMemcpy(sc->d_tris, trec.data(), sizeof(float) * trec.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc((void **)&sc->d_tri_info, sizeof(int2) * info.size()));
+    HIP_TRY(hipMemcpy(sc->d_tri_info, info.data(), sizeof(int2) * info.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc((void **)&sc->d_mats, sizeof(Material) * std::max(n_materials, 1)));
+    if (n_materials)
+        HIP_TRY(hipMemcpy(sc->d_mats, materials, sizeof(Material) * n_materials, hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc((void **)&sc->d_lights, sizeof(Light) * dl.size()));
+    HIP_TRY(hipMemcpy(sc->d_lights, dl.data(), sizeof(Light) * dl.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc((void **)&sc->d_order, sizeof(int) * std::max(n_tris, 1)));
+    if (n_tris) HIP_TRY(hipMemcpy(sc->d_order, sc->h_order.data(), sizeof(int) * n_tris, hipMemcpyHostToDevice));
+    *out_scene = sc.release();
+    return 0;
+}
+
+void rt_scene_destroy(rt_scene *scene) {
+    if (!scene) return;
+    (void)hipFree(scene->d_pairs);
+    (void)hipFree(scene->d_tris);
+    (void)hipFree(scene->d_tri_info);
+    (void)hipFree(scene->d_mats);
+    (void)hipFree(scene->d_lights);
+    (void)hipFree(scene->d_order);
+    delete scene;
+}
+
+int rt_scene_info(const rt_scene *scene, int64_t out[4]) {
+    if (!scene || !out) return fail("rt_scene_info: null argument");
+    out[0] = scene->n_pairs;
+    out[1] = scene->n_tris;
+    out[2] = scene->max_depth;
+    out[3] = scene->n_leaves;
+    return 0;
+}
+
+int rt_camera_make(const float lookfrom[3], const float lookat[3], const float up[3], float vfov_deg,
+                   float aspect_ratio, rt_camera *out) {
+    if (!lookfrom || !lookat || !up || !out) return fail("rt_camera_make: null argument");
+    // camera.cuh:15-29, host fp32 (tanf from the host libm, as in the reference)
+    const float pi = 3.14159265358979323846f;
+    float vfov_rad = vfov_deg * (pi / 180.f);
+    float vh = 2.f * tanf(vfov_rad * 0.5f);
+    float vw = vh * aspect_ratio;
+    auto sub3 = [](const float *a, const float *b, float *r) { r[0] = a[0] - b[0]; r[1] = a[1] - b[1]; r[2] = a[2] - b[2]; };
+    auto dot3 = [](const float *a, const float *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; };
+    auto unit3 = [&](float *a) {
+        float inv = 1.f / sqrtf(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
+        a[0] *= inv; a[1] *= inv; a[2] *= inv;
+    };
+    float w[3], v[3], u[3];
+    sub3(lookfrom, lookat, w);
+    unit3(w);
+    float duw = dot3(up, w);
+    v[0] = up[0] - duw * w[0];
+    v[1] = up[1] - duw * w[1];
+    v[2] = up[2] - duw * w[2];
+    unit3(v);
+    u[0] = v[1] * w[2] - v[2] * w[1];
+    u[1] = v[2] * w[0] - v[0] * w[2];
+    u[2] = v[0] * w[1] - v[1] * w[0];
+    for (int a = 0; a < 3; a++) {
+        out->lookfrom[a] = lookfrom[a];
+        out->horizontal[a] = vw * u[a];
+        out->vertical[a] = -vh * v[a];
+    }
+    for (int a = 0; a < 3; a++)
+        out->upper_left[a] = ((lookfrom[a] - w[a]) - 0.5f * out->horizontal[a]) - 0.5f * out->vertical[a];
+    return 0;
+}
+
+int rt_render_shard(const rt_scene *scene, const rt_camera *camera, int width, int height, int num_samples,
+                    int max_bounces, uint64_t seed, int shard_index, int shard_count, uint32_t flags,
+                    float *d_sum_rgb, void *stream, rt_stats *stats) {
+    return render_shard_impl(scene, camera, width, height, num_samples, max_bounces, seed, shard_index, shard_count,
+                             flags, d_sum_rgb, (hipStream_t)stream, stats);
+}
+
+int rt_post_process(float *d_rgb, int num_pixels, int num_samples, void *stream) {
+    if (!d_rgb || num_pixels <= 0 || num_samples <= 0) return fail("rt_post_process: bad argument");
+    int nv = num_pixels * 3;
+    float inv = 1.f / (float)num_samples;
+    hipLaunchKernelGGL(k_post_process, dim3((nv + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_rgb, nv, inv);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int rt_render(const rt_scene *scene, const rt_camera *camera, int width, int height, int num_samples,
+              int max_bounces, uint64_t seed, uint32_t flags, float *out_rgb, rt_stats *stats) {
+    if (!out_rgb) return fail("rt_render: out_rgb is null");
+    if (width <= 0 || height <= 0) return fail("rt_render: bad dimensions");
+    size_t bytes = sizeof(float) * 3 * (size_t)width * height;
+    float *d_fb = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_fb, bytes));
+    int rc = 0;
+    do {
+        if (hipMemsetAsync(d_fb, 0, bytes, nullptr) != hipSuccess) { rc = fail("rt_render: memset failed"); break; }
+        rc = render_shard_impl(scene, camera, width, height, num_samples, max_bounces, seed, 0, 1, flags, d_fb,
+                               nullptr, stats);
+        if (rc) break;
+        rc = rt_post_process(d_fb, width * height, num_samples, nullptr);
+        if (rc) break;
+        if (hipMemcpy(out_rgb, d_fb, bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = fail("rt_render: copy-back failed");
+    } while (0);
+    (void)hipFree(d_fb);
+    return rc;
+}
+
+int rt_trace_closest(const rt_scene *scene, int n, const float *origin_xyz, const float *dir_xyz, const float *tmax,
+                     int32_t *hit_tri, float *t, float *u, float *v) {
+    if (!scene || n < 0 || (n > 0 && (!origin_xyz || !dir_xyz || !tmax || !hit_tri || !t || !u || !v)))
+        return fail("rt_trace_closest: bad argument");
+    if (n == 0) return 0;
+    float *d_o, *d_d, *d_tm, *d_t, *d_u, *d_v;
+    int *d_h;
+    HIP_TRY(hipMalloc((void **)&d_o, sizeof(float) * 3 * (size_t)n));
+    HIP_TRY(hipMalloc((void **)&d_d, sizeof(float) * 3 * (size_t)n));
+    HIP_TRY(hipMalloc((void **)&d_tm, sizeof(float) * (size_t)n));
+    HIP_TRY(hipMalloc((void **)&d_t, sizeof(float) * (size_t)n));
+    HIP_TRY(hipMalloc((void **)&d_u, sizeof(float) * (size_t)n));
+    HIP_TRY(hipMalloc((void **)&d_v, sizeof(float) * (size_t)n));
+    HIP_TRY(hipMalloc((void **)&d_h, sizeof(int) * (size_t)n));
+    HIP_TRY(hipMemcpy(d_o, origin_xyz, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_d, dir_xyz, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_tm, tmax, sizeof(float) * (size_t)n, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_test_closest, dim3(grid_for(n)), dim3(kBlock), 0, nullptr, scene->dev(), n, d_o, d_d, d_tm,
+                       scene->d_order, d_h, d_t, d_u, d_v);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(hit_tri, d_h, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(t, d_t, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(u, d_u, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(v, d_v, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost));
+    (void)hipFree(d_o); (void)hipFree(d_d); (void)hipFree(d_tm); (void)hipFree(d_t);
+    (void)hipFree(d_u); (void)hipFree(d_v); (void)hipFree(d_h);
+    return 0;
+}
+
+int rt_trace_any(const rt_scene *scene, int n, const float *origin_xyz, const float *dir_xyz, const float *tmax,
+                 const int32_t *excluded_tri, int32_t *occluded) {
+    if (!scene || n < 0 || (n > 0 && (!origin_xyz || !dir_xyz || !tmax || !excluded_tri || !occluded)))
+        return fail("rt_trace_any: bad argument");
+    if (n == 0) return 0;
+    std::vector<int> excl(n);
+    for (int i = 0; i < n; i++) {
+        int e = excluded_tri[i];
+        excl[i] = (e >= 0 && e < scene->n_tris) ? scene->h_inverse[e] : -1;
+    }
+    float *d_o, *d_d, *d_tm;
+    int *d_e, *d_occ;
+    HIP_TRY(hipMalloc((void **)&d_o, sizeof(float) * 3 * (size_t)n));
+    HIP_TRY(hipMalloc((void **)&d_d, sizeof(float) * 3 * (size_t)n));
+    HIP_TRY(hipMalloc((void **)&d_tm, sizeof(float) * (size_t)n));
+    HIP_TRY(hipMalloc((void **)&d_e, sizeof(int) * (size_t)n));
+    HIP_TRY(hipMalloc((void **)&d_occ, sizeof(int) * (size_t)n));
+    HIP_TRY(hipMemcpy(d_o, origin_xyz, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_d, dir_xyz, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_tm, tmax, sizeof(float) * (size_t)n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_e, excl.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_test_any, dim3(grid_for(n)), dim3(kBlock), 0, nullptr, scene->dev(), n, d_o, d_d, d_tm, d_e,
+                       d_occ);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(occluded, d_occ, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost));
+    (void)hipFree(d_o); (void)hipFree(d_d); (void)hipFree(d_tm); (void)hipFree(d_e); (void)hipFree(d_occ);
+    return 0;
+}
+
+int rt_xorwow_states(uint64_t seed, uint32_t first, uint32_t count, int draws, uint32_t *state6, float *uniforms) {
+    if (count == 0) return 0;
+    if (!state6 || draws < 0 || (draws > 0 && !uniforms)) return fail("rt_xorwow_states: bad argument");
+    if ((uint64_t)first + count > (uint64_t)kW) return fail("rt_xorwow_states: subsequence range exceeds W");
+    DPools p{};
+    uint32_t *buf = nullptr, *d_state = nullptr, *d_jump = nullptr;
+    float *d_uni = nullptr;
+    HIP_TRY(hipMalloc((void **)&buf, sizeof(uint32_t) * 6 * (size_t)count));
+    p.rd = buf; p.r0 = buf + count; p.r1 = buf + 2 * (size_t)count; p.r2 = buf + 3 * (size_t)count;
+    p.r3 = buf + 4 * (size_t)count; p.r4 = buf + 5 * (size_t)count;
+    HIP_TRY(hipMalloc((void **)&d_state, sizeof(uint32_t) * 6 * (size_t)count));
+    HIP_TRY(hipMalloc((void **)&d_uni, sizeof(float) * std::max<size_t>(1, (size_t)count * draws)));
+    HIP_TRY(hipMalloc((void **)&d_jump, sizeof(uint32_t) * 20 * 800));
+    HIP_TRY(hipMemcpy(d_jump, jump_powers().data(), sizeof(uint32_t) * 20 * 800, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_rng_init, dim3(grid_for((int)count)), dim3(kBlock), 0, nullptr, p, (int)count, (int)first,
+                       xorwow_seed(seed), d_jump);
+    hipLaunchKernelGGL(k_test_draw, dim3(grid_for((int)count)), dim3(kBlock), 0, nullptr, p, (int)count, draws, d_state,
+                       d_uni);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(state6, d_state, sizeof(uint32_t) * 6 * (size_t)count, hipMemcpyDeviceToHost));
+    if (draws > 0) HIP_TRY(hipMemcpy(uniforms, d_uni, sizeof(float) * (size_t)count * draws, hipMemcpyDeviceToHost));
+    (void)hipFree(buf); (void)hipFree(d_state); (void)hipFree(d_uni); (void)hipFree(d_jump);
+    return 0;
+}
+
+int rt_measure_copy_bandwidth(int64_t bytes, int reps, double *out_bytes_per_s) {
+    if (bytes < 1024 || reps < 1 || !out_bytes_per_s) return fail("rt_measure_copy_bandwidth: bad argument");
+    size_t n4 = (size_t)bytes / 16;
+    float4 *a = nullptr, *b = nullptr;
+    HIP_TRY(hipMalloc((void **)&a, n4 * 16));
+    HIP_TRY(hipMalloc((void **)&b, n4 * 16));
+    HIP_TRY(hipMemset(a, 1, n4 * 16));
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    double best = 0.0;
+    for (int r = 0; r < reps + 1; r++) {
+        HIP_TRY(hipEventRecord(e0, nullptr));
+        hipLaunchKernelGGL(k_copy_f4, dim3(256 * 8), dim3(256), 0, nullptr, a, b, n4);
+        HIP_TRY(hipEventRecord(e1, nullptr));
+        HIP_TRY(hipEventSynchronize(e1));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+        if (r > 0 && ms > 0.f) best = std::max(best, 2.0 * (double)n4 * 16.0 / (ms * 1e-3));
+    }
+    HIP_TRY(hipEventDestroy(e0));
+    HIP_TRY(hipEventDestroy(e1));
+    (void)hipFree(a);
+    (void)hipFree(b);
+    *out_bytes_per_s = best;
+    return 0;
+}
+
+}  // extern "C"

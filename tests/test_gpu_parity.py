@@ -1,0 +1,176 @@
+"""GPU parity tests: the HIP path (through the C-ABI) against the CPU oracle.  Run with -m gpu."""
+import numpy as np
+import pytest
+
+from conftest import default_camera
+import raygen
+
+pytestmark = pytest.mark.gpu
+
+FLT_MAX = np.float32(3.4028234663852886e38)
+
+
+@pytest.fixture(scope="module")
+def api():
+    from rtcuda_amd import api as _api
+    _api.lib()  # raises if the HIP library is missing: there is no fallback
+    return _api
+
+
+@pytest.fixture(scope="module")
+def gpu_matte(api, bunny_matte):
+    return api.Scene(bunny_matte)
+
+
+@pytest.fixture(scope="module")
+def gpu_full(api, bunny_full_bsdf):
+    return api.Scene(bunny_full_bsdf)
+
+
+@pytest.fixture(scope="module")
+def cpu_matte(oracle, bunny_matte):
+    return oracle.scene(bunny_matte)
+
+
+@pytest.fixture(scope="module")
+def cpu_full(oracle, bunny_full_bsdf):
+    return oracle.scene(bunny_full_bsdf)
+
+
+def test_xorwow_states_and_draws_bit_exact(api, oracle):
+    for first, count in [(0, 4096), (1 << 19, 1024), ((1 << 20) - 2048, 2048), (123457, 777)]:
+        st, uni = api.xorwow_states(1, first, count, draws=5)
+        ref = oracle.xorwow_init_range(1, first, count)
+        ref_u = np.zeros((count, 5), np.float32)
+        for i in range(count):
+            s = ref[i].copy()
+            _, ref_u[i] = oracle.xorwow_draw(s, 5)
+            ref[i] = s
+        assert np.array_equal(st, ref)
+        assert np.array_equal(uni.view(np.uint32), ref_u.view(np.uint32))
+    st, _ = api.xorwow_states(0xDEADBEEF12345, 5, 16, draws=0)
+    assert np.array_equal(st, oracle.xorwow_init_range(0xDEADBEEF12345, 5, 16))
+
+
+def _closest_compare(gpu, cpu, o, d, tmax, max_mismatch_frac):
+    g = gpu.trace_closest(o, d, tmax)
+    c = cpu.trace_closest(o, d, tmax)
+    same_tri = g[0] == c[0]
+    n = len(o)
+    bad = np.where(~same_tri)[0]
+    # every disagreement must be an exact tie (equal t on two triangles) or a 1-ulp grazing case
+    for i in bad[:50]:
+        if g[0][i] >= 0 and c[0][i] >= 0:
+            assert abs(float(g[1][i]) - float(c[1][i])) <= 4e-7 * max(1.0, abs(float(c[1][i]))), (i, g[1][i], c[1][i])
+    assert len(bad) <= max_mismatch_frac * n, f"{len(bad)} of {n} rays disagree on the hit triangle"
+    hit = same_tri & (c[0] >= 0)
+    for k in (1, 2, 3):  # t, u, v bit for bit
+        assert np.array_equal(g[k][hit].view(np.uint32), c[k][hit].view(np.uint32))
+    return g, c, len(bad)
+
+
+def test_trace_closest_matches_oracle(api, oracle, gpu_matte, cpu_matte):
+    cam = default_camera(oracle, 16 / 9)
+    o, d = raygen.camera_rays(cam, 1920, 1080, 400_000, seed=11)
+    tmax = np.full(len(o), FLT_MAX, np.float32)
+    g, c, nbad = _closest_compare(gpu_matte, cpu_matte, o, d, tmax, 2e-5)
+    assert 0.4 < (c[0] >= 0).mean() < 0.7  # 53 % of 16:9 primary rays hit the box (SURVEY Appx C)
+    o2, d2 = raygen.bounce_rays(o, d, c[1], c[0] >= 0, seed=12)
+    _closest_compare(gpu_matte, cpu_matte, o2, d2, np.full(len(o2), FLT_MAX, np.float32), 2e-5)
+    # finite tmax (shadow-ray style) and degenerate directions
+    tm = np.random.default_rng(5).uniform(0.05, 1.5, len(o2)).astype(np.float32)
+    _closest_compare(gpu_matte, cpu_matte, o2, d2, tm, 2e-5)
+    o3, d3 = raygen.axis_aligned_rays(50_000, seed=13)
+    _closest_compare(gpu_matte, cpu_matte, o3, d3, np.full(len(o3), FLT_MAX, np.float32), 1e-3)
+
+
+def test_trace_any_matches_oracle(api, oracle, gpu_matte, cpu_matte, bunny_matte):
+    cam = default_camera(oracle, 1.0)
+    o, d = raygen.camera_rays(cam, 512, 512, 100_000, seed=21)
+    c = cpu_matte.trace_closest(o, d, np.full(len(o), FLT_MAX, np.float32))
+    o2, d2 = raygen.bounce_rays(o, d, c[1], c[0] >= 0, seed=22)
+    rng = np.random.default_rng(23)
+    tm = rng.uniform(0.05, 1.2, len(o2)).astype(np.float32)
+    light_tris = np.where(bunny_matte.tri_light >= 0)[0]
+    excl = rng.choice(np.concatenate([light_tris, [-1]]), len(o2)).astype(np.int32)
+    g_occ = gpu_matte.trace_any(o2, d2, tm, excl)
+    c_occ = cpu_matte.trace_any(o2, d2, tm, excl)
+    assert (g_occ != c_occ).sum() <= 2e-5 * len(o2)
+    assert 0.05 < c_occ.mean() < 0.95
+    # empty batch is legal
+    assert len(gpu_matte.trace_any(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32),
+                                   np.zeros(0, np.float32), np.zeros(0, np.int32))) == 0
+
+
+def _rms(a, b):
+    return np.sqrt(np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2, axis=(0, 1)))
+
+
+@pytest.mark.parametrize("w,h,spp", [(64, 36, 8), (64, 64, 4), (32, 32, 16)])
+def test_render_matches_oracle_matte(api, oracle, gpu_matte, cpu_matte, w, h, spp):
+    cam = default_camera(oracle, w / h)
+    img_c, sum_c, st_c = cpu_matte.render(cam, w, h, spp, threads=8)
+    img_g, st_g = gpu_matte.render(api.make_camera(aspect=w / h), w, h, spp)
+    # event counts are integers: exact
+    assert st_g["camera_rays"] == w * h * spp
+    assert st_g["shade_events"] == st_c["sum_mat"]
+    assert st_g["any_rays"] == st_c["sum_ah"]
+    assert st_g["emission_adds"] == st_c["emission_adds"]
+    assert st_g["shadow_adds"] == st_c["ah_adds"]
+    assert st_g["rr_draws"] == st_c["rr_draws"]
+    # pixels: same contributions, only the float summation order differs (atomics)
+    rms = _rms(img_g, img_c)
+    assert rms.max() < 2e-6, rms
+    assert np.abs(img_g - img_c).max() < 1e-4
+
+
+def test_render_matches_oracle_full_bsdf(api, oracle, gpu_full, cpu_full):
+    w, h, spp = 96, 54, 8
+    cam = default_camera(oracle, w / h)
+    img_c, _, st_c = cpu_full.render(cam, w, h, spp, threads=8)
+    img_g, st_g = gpu_full.render(api.make_camera(aspect=w / h), w, h, spp)
+    assert st_c["ch_adds"] == 0  # the BSDF-sampled MIS ray never contributes
+    assert st_g["shade_events"] == st_c["sum_mat"]
+    assert st_g["any_rays"] == st_c["sum_ah"]
+    assert st_g["shadow_adds"] == st_c["ah_adds"]
+    assert st_g["rr_draws"] == st_c["rr_draws"]
+    assert _rms(img_g, img_c).max() < 2e-6
+
+
+def test_camera_matches_oracle(api, oracle):
+    for aspect in (1.0, 16 / 9, 0.5):
+        assert np.array_equal(api.make_camera(aspect=aspect).view(np.uint32),
+                              default_camera(oracle, aspect).view(np.uint32))
+
+
+def test_shards_sum_to_full_image(api, oracle, gpu_matte):
+    """Slot-range shards are disjoint in camera rays: their raw sums add up to the 1-GPU image."""
+    import torch
+    w, h, spp = 80, 45, 16
+    cam = api.make_camera(aspect=w / h)
+    full = torch.zeros(h * w * 3, dtype=torch.float32, device="cuda")
+    st_full = gpu_matte.render_shard(cam, w, h, spp, 0, 1, full.data_ptr())
+    for shards in (2, 8):
+        acc = torch.zeros_like(full)
+        rays = 0
+        for r in range(shards):
+            st = gpu_matte.render_shard(cam, w, h, spp, r, shards, acc.data_ptr())
+            rays += st["camera_rays"]
+        torch.cuda.synchronize()
+        assert rays == st_full["camera_rays"] == w * h * spp
+        a, b = acc.cpu().numpy(), full.cpu().numpy()
+        assert np.allclose(a, b, rtol=2e-5, atol=1e-6)
+
+
+def test_error_paths(api, bunny_matte):
+    import copy
+    bad = copy.copy(bunny_matte)
+    bad.tri_material = bunny_matte.tri_material.copy()
+    bad.tri_material[0] = 99
+    with pytest.raises(api.RtError):
+        api.Scene(bad)
+    sc = api.Scene(bunny_matte)
+    with pytest.raises(api.RtError):
+        sc.render(api.make_camera(), 0, 10, 1)
+    with pytest.raises(api.RtError):  # beyond the reference's int32 camera-ray range
+        sc.render(api.make_camera(), 8192, 8192, 64)
