@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""bench.py -- Msamples/s of the render path on MI355X (BASELINE.json's metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one whole frame of the headline configuration: bun_zipper.ply in the Cornell box,
+full BSDF set (glass bunny, mirror back wall), 1920x1080, 256 spp, max_bounces 10, seed 1
+(BASELINE.json configs[1]).  With N > 1 ranks the SAME frame is sharded by path slot
+(rtcuda_amd/dist.py), each rank renders its slots into a raw-sum framebuffer that is already
+resident in HBM, one RCCL sum-reduce brings the partial framebuffers to rank 0, and rank 0
+post-processes: total work is fixed, so "scaling" is "strong".
+
+Rank 0 prints ONE JSON line with the contract fields plus
+  roofline      dominant kernel (k_trace_closest) against the 8 TB/s HBM peak
+  cpu_baseline  the CPU oracle (a port of the reference's algorithm; the reference itself needs
+                nvcc + cuRAND + CUB and cannot be built here) timed on a bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic bytes of one closest-hit ray with the reference's record sizes:
+# 32 B ray in + 21 B hit out + 64 B per node PAIR visited + 72 B per triangle test
+# (24-B Primitive + 48-B Triangle).  NP / TT are the reference traversal's per-ray averages for the
+# workload; they are re-measured by the cpu_baseline leg (oracle statistics) when it runs and fall
+# back to SURVEY.md Appendix C's values for the named config otherwise.
+APPX_C = {"full_bsdf": (12.15, 4.09), "matte": (8.17, 3.32), "four_bunnies": (17.77, 4.84),
+          "sixteen_lights": (8.31, 3.34)}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def closest_ray_bytes(np_c: float, tt_c: float) -> float:
+    return 53.0 + 64.0 * np_c + 72.0 * tt_c
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--spp", type=int, default=256)
+    ap.add_argument("--max-bounces", type=int, default=10)
+    ap.add_argument("--scene", default="full_bsdf",
+                    choices=["matte", "full_bsdf", "four_bunnies", "sixteen_lights"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-spp", type=int, default=4, help="spp of the bounded CPU-baseline sample")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--save-image", default="")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP library is the product and there is no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from rtcuda_amd import api, scenes, dist as rtdist
+
+    w, h, spp = args.width, args.height, args.spp
+    arrays = scenes.cornell_bunny(args.scene)
+    scene = api.Scene(arrays)
+    cam = api.make_camera(aspect=w / h)
+    fb = torch.zeros(h * w * 3, dtype=torch.float32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    flags = 0 if args.no_kernel_timing else api.FLAG_TIME_KERNELS
+    last_stats = {}
+
+    def step():
+        fb.zero_()
+        st = scene.render_shard(cam, w, h, spp, rank, world, fb.data_ptr(), max_bounces=args.max_bounces, seed=1,
+                                flags=flags, stream=stream)
+        rtdist.reduce_raw_sums(fb, dst=0)
+        if rank == 0:
+            api.post_process(fb.data_ptr(), w * h, spp, stream=stream)
+        last_stats.update(st)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    agg = {"seconds_closest": 0.0, "closest_rays": 0, "launches_closest": 0, "seconds_any": 0.0,
+           "seconds_advance": 0.0, "seconds_render": 0.0, "any_rays": 0, "shade_events": 0}
+    for _ in range(args.steps):
+        step()
+        for k in agg:
+            agg[k] += last_stats[k]
+    fence()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        samples = float(w) * h * spp * args.steps
+        value = samples / elapsed / 1e6
+        out = {
+            "metric": "Msamples/s at 1920x1080, bun_zipper.ply" if (w, h) == (1920, 1080) else f"Msamples/s at {w}x{h}",
+            "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / max(args.steps, 1), 3),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic (Cornell box + Stanford bunny recipe of the reference driver, seed 1)",
+            "config": {"workload": f"bun_zipper.ply {w}x{h} {spp} spp, {args.scene} scene, max_bounces "
+                                   f"{args.max_bounces} (BASELINE configs[1] when 1920x1080x256 full_bsdf)",
+                       "scene": args.scene, "width": w, "height": h, "spp": spp, "max_bounces": args.max_bounces,
+                       "parallelism": f"slot-shard x{world} + 1 RCCL reduce" if world > 1 else "1 GPU"},
+            "ms_per_frame": round(1e3 * elapsed / max(args.steps, 1), 3),
+        }
+        # ---- CPU baseline (rank 0, N = 1 only): the oracle on a bounded sample of the same workload
+        np_c, tt_c = APPX_C[args.scene]
+        np_src = "SURVEY.md Appendix C"
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle.oracle import Oracle
+            cores = max(1, min(os.cpu_count() or 1, 16))
+            orc = Oracle("pinned")
+            osc = orc.scene(arrays)
+            ocam = orc.camera((0.5, 0.5, 1.5), (0.5, 0.5, 0.0), (0.0, 1.0, 0.0), 37.8, w / h)
+            _, _, ost = osc.render(ocam, w, h, args.cpu_spp, args.max_bounces, 1, threads=cores, collect_stats=True)
+            cpu_v = w * h * args.cpu_spp / ost["seconds_loop"] / 1e6
+            out["cpu_baseline"] = {
+                "value": round(cpu_v, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
+                "sample": f"same scene and camera at {w}x{h}, {args.cpu_spp} spp ({w * h * args.cpu_spp} samples), "
+                          f"render loop only ({ost['seconds_loop']:.1f} s; RNG init {ost['seconds_rng_init']:.2f} s "
+                          f"reported apart), literal wavefront schedule, OpenMP over queue entries"}
+            if ost["ch_rays"] > 0:
+                np_c = ost["ch_node_pairs"] / ost["ch_rays"]
+                tt_c = ost["ch_tri_tests"] / ost["ch_rays"]
+                np_src = f"oracle statistics of the cpu_baseline sample ({args.cpu_spp} spp)"
+        else:
+            out["cpu_baseline"] = None
+        # ---- roofline of the dominant kernel
+        if agg["launches_closest"] > 0 and agg["seconds_closest"] > 0:
+            rays_per_launch = agg["closest_rays"] / agg["launches_closest"]
+            avg_s = agg["seconds_closest"] / agg["launches_closest"]
+            bytes_per_launch = closest_ray_bytes(np_c, tt_c) * rays_per_launch
+            achieved = bytes_per_launch / avg_s / 1e9
+            out["roofline"] = {
+                "kernel": "k_trace_closest", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                "bytes_per_ray": round(closest_ray_bytes(np_c, tt_c), 1), "np_tt_source": np_src,
+                "rays_per_launch": round(rays_per_launch, 1), "avg_launch_us": round(avg_s * 1e6, 2),
+                "launches": agg["launches_closest"],
+                "stage_share_of_render": {
+                    "closest": round(agg["seconds_closest"] / max(agg["seconds_render"], 1e-12), 4),
+                    "any": round(agg["seconds_any"] / max(agg["seconds_render"], 1e-12), 4),
+                    "advance": round(agg["seconds_advance"] / max(agg["seconds_render"], 1e-12), 4)},
+                "grays_per_s_closest": round(agg["closest_rays"] / max(agg["seconds_closest"], 1e-12) / 1e9, 3)}
+        else:
+            out["roofline"] = None
+        out["per_frame"] = {"closest_rays": agg["closest_rays"] // max(args.steps, 1),
+                            "any_rays": agg["any_rays"] // max(args.steps, 1),
+                            "shade_events": agg["shade_events"] // max(args.steps, 1),
+                            "rounds": agg["launches_closest"] // max(args.steps, 1),
+                            "shard_note": "per-frame counts are rank 0's shard" if world > 1 else "whole frame"}
+        if args.save_image:
+            img = fb.view(h, w, 3).cpu().numpy()
+            scenes.write_ppm(args.save_image, img)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

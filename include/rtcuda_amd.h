@@ -69,15 +69,16 @@ typedef struct rt_stats {
     int64_t bvh_depth;
     double seconds_render;   /* device time of the render loop (HIP events), excl. RNG init */
     double seconds_rng_init; /* device time of the one-off XORWOW state initialisation */
-    double seconds_closest;  /* summed HIP-event time of the closest-hit kernel (0 unless timing on) */
-    double seconds_any;
-    double seconds_advance;
-    int64_t launches_closest;
-    int64_t reserved[7];
+    double seconds_closest;  /* closest-hit kernel: average launch duration (HIP events on the launch
+                                stream, every 4th round sampled) x launches; 0 unless RT_FLAG_TIME_KERNELS */
+    double seconds_any;      /* same for the any-hit kernel */
+    double seconds_advance;  /* same for the advance kernel */
+    int64_t launches_closest; /* launches of each stage kernel (= iterations) */
+    int64_t reserved[7];     /* reserved[0] = rounds actually sampled by the event timer */
 } rt_stats;
 
 /* Flags for rt_render / rt_render_shard */
-#define RT_FLAG_TIME_KERNELS 1u /* bracket every stage kernel with HIP events (slower; fills seconds_*) */
+#define RT_FLAG_TIME_KERNELS 1u /* time the stage kernels with HIP events on the launch stream (fills seconds_*) */
 
 /* ---- scene -------------------------------------------------------------------------------
  * Replaces: Triangle(p0,p1,p2) x n (triangle.cuh:6-7), cudaMalloc/Memcpy of triangles,

@@ -58,6 +58,32 @@ def build(verbose: bool = False) -> str:
 _lib = None
 
 
+def _preload_hip_runtime() -> None:
+    """Make ONE HIP runtime globally visible before the library is loaded.
+
+    librtcuda_amd.so deliberately carries no DT_NEEDED on libamdhip64 (see csrc/Makefile): a
+    PyTorch-ROCm wheel ships its own libamdhip64.so, and a second runtime in the same process
+    finds no GPU.  When torch is installed its copy is used (bench.py needs torch.distributed in
+    the same process); otherwise the system ROCm runtime.
+    """
+    candidates = []
+    try:
+        import torch  # noqa: F401
+        candidates.append(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+    except ImportError:
+        pass
+    candidates += ["/opt/rocm/lib/libamdhip64.so", "libamdhip64.so"]
+    for c in candidates:
+        if os.path.isabs(c) and not os.path.exists(c):
+            continue
+        try:
+            ctypes.CDLL(c, mode=ctypes.RTLD_GLOBAL)
+            return
+        except OSError:
+            continue
+    raise ImportError("no HIP runtime (libamdhip64.so) could be loaded")
+
+
 def lib():
     """Load the library (once).  Raises ImportError with the build command if it is missing."""
     global _lib
@@ -67,6 +93,7 @@ def lib():
         raise ImportError(
             f"{LIB_PATH} not found: the HIP library is the product and there is no fallback. "
             f"Build it with `make -C {CSRC}` (or python -c 'import __graft_entry__ as g; g.build()').")
+    _preload_hip_runtime()
     L = ctypes.CDLL(LIB_PATH)
     vp, ci, cf = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
     L.rt_last_error.restype = ctypes.c_char_p

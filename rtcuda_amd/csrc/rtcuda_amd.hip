@@ -698,6 +698,7 @@ struct Context {
     int rng_lo = -1;
     bool rng_valid = false;
     uint32_t *rng_backup = nullptr;  // 6 x n words
+    std::vector<hipEvent_t> timing_events;
 };
 std::mutex g_ctx_mutex;
 std::vector<std::unique_ptr<Context>> g_contexts;
@@ -830,31 +831,34 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
     unsigned long long last_closest = ~0ull;
     int batch = 0;
     bool finished = false;
-    double t_adv = 0, t_ch = 0, t_ah = 0;
-    long long n_ch_launch = 0;
     const dim3 grid(grid_for(n)), block(kBlock);
+    // RT_FLAG_TIME_KERNELS: every kTimeStride-th round is bracketed with HIP events on the launch
+    // stream (no host synchronisation); the events are resolved after the loop.
+    const int kTimeStride = 4;
+    std::vector<hipEvent_t> &evs = c.timing_events;
+    size_t ev_used = 0;
+    auto next_event = [&](hipEvent_t *out) -> int {
+        if (ev_used == evs.size()) {
+            hipEvent_t e;
+            HIP_TRY(hipEventCreate(&e));
+            evs.push_back(e);
+        }
+        *out = evs[ev_used++];
+        return 0;
+    };
     while (!finished && rounds < max_rounds) {
         for (int k = 0; k < kBatch; k++) {
             ap.round = (int)(rounds & 0x3fffffff);
-            if (time_kernels) {
-                float ms;
-                HIP_TRY(hipEventRecord(c.ev_a, st));
+            if (time_kernels && (rounds % kTimeStride) == 0) {
+                hipEvent_t e0, e1, e2, e3;
+                if (next_event(&e0) || next_event(&e1) || next_event(&e2) || next_event(&e3)) return 1;
+                HIP_TRY(hipEventRecord(e0, st));
                 hipLaunchKernelGGL(k_advance, grid, block, 0, st, sc, c.pools, cam, ap, d_sum, c.d_ctr);
-                HIP_TRY(hipEventRecord(c.ev_b, st));
+                HIP_TRY(hipEventRecord(e1, st));
                 hipLaunchKernelGGL(k_trace_closest, grid, block, 0, st, sc, c.pools, n);
-                HIP_TRY(hipEventRecord(c.ev_c, st));
-                HIP_TRY(hipEventSynchronize(c.ev_c));
-                HIP_TRY(hipEventElapsedTime(&ms, c.ev_a, c.ev_b));
-                t_adv += ms;
-                HIP_TRY(hipEventElapsedTime(&ms, c.ev_b, c.ev_c));
-                t_ch += ms;
-                n_ch_launch++;
-                HIP_TRY(hipEventRecord(c.ev_a, st));
+                HIP_TRY(hipEventRecord(e2, st));
                 hipLaunchKernelGGL(k_trace_any, grid, block, 0, st, sc, c.pools, ap.round, d_sum, c.d_ctr);
-                HIP_TRY(hipEventRecord(c.ev_b, st));
-                HIP_TRY(hipEventSynchronize(c.ev_b));
-                HIP_TRY(hipEventElapsedTime(&ms, c.ev_a, c.ev_b));
-                t_ah += ms;
+                HIP_TRY(hipEventRecord(e3, st));
             } else {
                 hipLaunchKernelGGL(k_advance, grid, block, 0, st, sc, c.pools, cam, ap, d_sum, c.d_ctr);
                 hipLaunchKernelGGL(k_trace_closest, grid, block, 0, st, sc, c.pools, n);
@@ -882,6 +886,17 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
     HIP_TRY(hipEventDestroy(ev_stop));
     DCounters fin;
     HIP_TRY(hipMemcpy(&fin, c.d_ctr, sizeof(DCounters), hipMemcpyDeviceToHost));
+    double t_adv = 0, t_ch = 0, t_ah = 0;
+    long long n_sampled = (long long)(ev_used / 4);
+    for (size_t q = 0; q + 3 < ev_used; q += 4) {
+        float ms;
+        HIP_TRY(hipEventElapsedTime(&ms, evs[q], evs[q + 1]));
+        t_adv += ms;
+        HIP_TRY(hipEventElapsedTime(&ms, evs[q + 1], evs[q + 2]));
+        t_ch += ms;
+        HIP_TRY(hipEventElapsedTime(&ms, evs[q + 2], evs[q + 3]));
+        t_ah += ms;
+    }
     if (!finished) return fail("rt_render_shard: round limit reached before the path pool drained");
     if (stats) {
         memset(stats, 0, sizeof(*stats));
@@ -897,10 +912,13 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
         stats->bvh_depth = scene->max_depth;
         stats->seconds_render = ms_total * 1e-3;
         stats->seconds_rng_init = rng_seconds;
-        stats->seconds_closest = t_ch * 1e-3;
-        stats->seconds_any = t_ah * 1e-3;
-        stats->seconds_advance = t_adv * 1e-3;
-        stats->launches_closest = n_ch_launch;
+        // sampled every kTimeStride-th round; scaled to all rounds (average launch duration x launches)
+        double scale_up = n_sampled > 0 ? (double)rounds / (double)n_sampled : 0.0;
+        stats->seconds_closest = t_ch * 1e-3 * scale_up;
+        stats->seconds_any = t_ah * 1e-3 * scale_up;
+        stats->seconds_advance = t_adv * 1e-3 * scale_up;
+        stats->launches_closest = rounds;
+        stats->reserved[0] = n_sampled;
     }
     return 0;
 }

@@ -1,0 +1,36 @@
+"""Multi-GPU plumbing for the render path: one process per GPU, torch.distributed (RCCL over xGMI).
+
+The path shards by PATH SLOT, not by pixel: rank r of R owns slots [r*W/R, (r+1)*W/R) and therefore
+exactly the camera rays c with (c % W) in that range (render.cuh:254-261 ties camera ray c to the
+c-th pending slot, and all W slots are pending together).  With spp | W/R that is a round-robin
+deal of W/(R*spp)-pixel strips over the ranks, so every rank sees every part of the image.
+There is no exchange inside the render; the only collective is ONE sum-reduce of the raw
+framebuffers (width*height*3 fp32 = 24.9 MB at 1080p) to rank 0 after the last round.
+"""
+from __future__ import annotations
+
+W = 1 << 20
+
+
+def shard_range(rank: int, world: int):
+    """Slot range [lo, hi) owned by ``rank`` (``world`` must divide W = 1048576)."""
+    if world <= 0 or W % world != 0:
+        raise ValueError("world size must divide 1048576")
+    if not 0 <= rank < world:
+        raise ValueError("rank out of range")
+    n = W // world
+    return rank * n, (rank + 1) * n
+
+
+def owner_of_camera_ray(camera_ray_id: int, world: int) -> int:
+    """Rank that renders camera ray ``camera_ray_id`` (pixel = id // spp, render.cuh:257)."""
+    return (camera_ray_id % W) // (W // world)
+
+
+def reduce_raw_sums(local_sum, dst: int = 0, group=None):
+    """Sum-reduce the per-rank raw framebuffers to ``dst`` (in place on ``dst``).  Works on any
+    torch.distributed backend: "nccl" (= RCCL) on the GPUs, "gloo" in the CPU tests."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.reduce(local_sum, dst=dst, op=dist.ReduceOp.SUM, group=group)
+    return local_sum
