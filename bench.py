@@ -54,6 +54,7 @@ def main():
     ap.add_argument("--cpu-spp", type=int, default=4, help="spp of the bounded CPU-baseline sample")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--save-image", default="")
+    ap.add_argument("--debug-flags", type=int, default=0, help="perf experiments only (results invalid)")
     args = ap.parse_args()
 
     import numpy as np
@@ -80,7 +81,7 @@ def main():
     cam = api.make_camera(aspect=w / h)
     fb = torch.zeros(h * w * 3, dtype=torch.float32, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
-    flags = 0 if args.no_kernel_timing else api.FLAG_TIME_KERNELS
+    flags = (0 if args.no_kernel_timing else api.FLAG_TIME_KERNELS) | args.debug_flags
     last_stats = {}
 
     def step():

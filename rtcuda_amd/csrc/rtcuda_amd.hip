@@ -20,8 +20,8 @@
 //                        re-rolls them), BSDF sampling, NEE; writes the next path ray in place and
 //                        appends the shadow ray to a compact queue with one atomic per wave
 //                        (ballot + mbcnt) instead of flag arrays + CUB select (render.cuh:348-364)
-//       k_trace_closest  ch() (render.cuh:297-328): BVH closest hit, traversal stack in LDS
-//       k_trace_any      ah() (render.cuh:278-294): any-hit over the shadow queue, float atomics
+//       k_trace<POOL_CLOSEST>  ch() (render.cuh:297-328): persistent while-while BVH closest hit, LDS stack
+//       k_trace<QUEUE_ANY>     ah() (render.cuh:278-294): any-hit over the shadow queue, float atomics
 //                        into the raw-sum framebuffer
 //   * BVH: 64-byte pair records (both child boxes + links in one line), triangles as 48-byte
 //     {p0,e1,e2,n} records in leaf order (rt_bvh.h).
@@ -61,7 +61,7 @@ int fail(const std::string &msg) {
 
 constexpr int kW = RT_NUM_WORKING_PATHS;
 constexpr int kBlock = 256;       // 4 waves per workgroup
-constexpr int kStackDepth = 32;   // LDS traversal stack entries per lane (tree depth is checked against it)
+constexpr int kMaxStackDepth = 40; // LDS traversal stack = tree depth entries per lane (dynamic LDS), capped here
 }  // namespace
 
 // ============================================================================ device structures
@@ -72,13 +72,16 @@ struct DScene {
     const Material *mats;
     const Light *lights;
     int num_lights;
+    int num_mats;
 };
 
 // Structure-of-arrays path state for the slots of one shard (n slots each)
 struct DPools {
     float *ox, *oy, *oz, *dx, *dy, *dz;  // current path ray
-    int *hit_tri;                        // leaf-order triangle of the last closest hit, -1 = miss
-    float *hit_u, *hit_v;
+    // hit record of the last closest-hit trace, already in the form mat() consumes:
+    int *hit_info;                       // -1 = miss, else material | (light index + 1) << 16
+    float *hpx, *hpy, *hpz;              // Triangle::p(u, v)                      (render.cuh:152)
+    float *hnx, *hny, *hnz;              // -d_triangle->n.unit_vector()           (render.cuh:153)
     float *br, *bg, *bb;  // beta
     int *bounces;         // as PathRayPayload::bounces; kDone marks an exhausted slot
     int *pixel;
@@ -89,11 +92,20 @@ struct DPools {
     int *spixel, *starget;
 };
 
+// Global words that need atomics / host polling.  Event counters are NOT here: they live in
+// per-wave rows (DWaveRow) that only their owner wave updates, with plain loads and stores --
+// 16384 waves hitting eight shared words with atomics every round was the single largest cost of
+// the first version of k_advance.
 struct DCounters {
-    unsigned long long camera_rays, shade_events, closest_rays, any_rays, emission_adds, shadow_adds, rr_draws;
-    unsigned long long pad;
     unsigned int shadow_count[2];  // queue fill, double-buffered by round parity
+    int last_live_round;           // highest round in which some slot still had a ray to trace
+    int pad;
+    unsigned int trace_head[2];    // work heads of the two persistent trace kernels (zeroed by k_advance)
     unsigned int pad2[2];
+};
+enum { C_CAMERA = 0, C_SHADE, C_CLOSEST, C_ANY, C_EMIT, C_SHADOW_ADD, C_RR, C_UNUSED, C_COUNT };
+struct DWaveRow {
+    unsigned long long c[C_COUNT];  // one 64-byte line per wave
 };
 
 constexpr int kDone = -0x7fffffff;
@@ -106,10 +118,14 @@ __device__ __forceinline__ unsigned lane_id() {
 __device__ __forceinline__ unsigned prefix_popc(unsigned long long mask) {
     return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
 }
-// one atomic per wave: add popc(ballot(pred)) to *counter
-__device__ __forceinline__ void wave_count(unsigned long long *counter, bool pred) {
-    unsigned long long m = __ballot(pred);
-    if (m != 0 && prefix_popc(m) == 0 && pred) atomicAdd(counter, (unsigned long long)__popcll(m));
+__device__ __forceinline__ unsigned wave_index() { return (blockIdx.x * blockDim.x + threadIdx.x) >> 6; }
+// lanes 0..7 of the wave add v[lane] to the wave's own row: one 64-byte load + one 64-byte store
+__device__ __forceinline__ void row_add(DWaveRow *rows, const unsigned long long (&v)[C_COUNT]) {
+    unsigned l = lane_id();
+    unsigned long long mine = 0;
+#pragma unroll
+    for (int k = 0; k < C_COUNT; k++) mine = (l == (unsigned)k) ? v[k] : mine;
+    if (l < C_COUNT && mine != 0) rows[wave_index()].c[l] += mine;
 }
 
 // ============================================================================ RNG init kernel
@@ -156,7 +172,7 @@ __global__ void k_rng_init(DPools p, int n, int slot_lo, Rng seed_state, const u
 __global__ void k_pool_init(DPools p, int n, int max_bounces) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    p.hit_tri[i] = -1;
+    p.hit_info[i] = -1;
     p.bounces[i] = max_bounces;
     p.gen[i] = 0;
     p.pixel[i] = 0;
@@ -169,42 +185,101 @@ struct AdvanceParams {
     int width, height, spp, max_bounces;
     long long cam_end;  // width*height*spp
     int round;
+    int tables_in_lds;  // materials and lights fit the LDS tables below
+    unsigned head_init; // 64 x waves of the persistent trace grid (their first chunk is static)
 };
 
-__global__ void __launch_bounds__(kBlock)
-k_advance(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__ fb, DCounters *__restrict__ ctr) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    bool in_range = i < ap.n;
-    int bounces = in_range ? p.bounces[i] : kDone;
-    bool alive = bounces != kDone;
+constexpr int kLdsTable = 64;  // materials / lights staged in LDS per workgroup (larger scenes read global)
+struct LightPre {              // per-light values that depend on the light triangle only
+    float inv_area;            // 1 / Triangle::area()                (triangle.cuh:79,84-86)
+    float nx, ny, nz;          // d_triangle->n.unit_vector()         (light.cuh:46)
+};
 
+// Every per-slot input of this kernel is indexed by the slot id, so all of a lane's loads are
+// issued together (one memory round trip); the small shared tables (materials, lights, light
+// triangles) are staged in LDS once per workgroup.  The hit record written by k_trace<POOL_CLOSEST>
+// already carries the shading point, the flipped unit normal and the material/light ids, so no
+// triangle is gathered here.
+__global__ void __launch_bounds__(kBlock)
+k_advance(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__ fb, DCounters *__restrict__ ctr,
+          DWaveRow *__restrict__ rows) {
+    __shared__ unsigned s_wave_cnt[kBlock / 64];
+    __shared__ unsigned s_base;
+    __shared__ unsigned s_live;
+    __shared__ Material s_mats[kLdsTable];
+    __shared__ Light s_lights[kLdsTable];
+    __shared__ float s_ltri[kLdsTable][12];
+    __shared__ LightPre s_lpre[kLdsTable];
+
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool in_range = i < ap.n;
+    // ---- issue all per-slot loads up front
+    int bounces = kDone, hit_info = -1, pixel = 0, gen = 0;
+    Rng rs{0, 0, 0, 0, 0, 0};
+    V3 beta = mk(0, 0, 0), wo = mk(0, 0, 0), isect_p = mk(0, 0, 0), isect_n = mk(0, 0, 0);
+    if (in_range) {
+        bounces = p.bounces[i];
+        hit_info = p.hit_info[i];
+        pixel = p.pixel[i];
+        gen = p.gen[i];
+        rs = Rng{p.rd[i], p.r0[i], p.r1[i], p.r2[i], p.r3[i], p.r4[i]};
+        beta = mk(p.br[i], p.bg[i], p.bb[i]);
+        wo = mk(p.dx[i], p.dy[i], p.dz[i]);
+        isect_p = mk(p.hpx[i], p.hpy[i], p.hpz[i]);
+        isect_n = mk(p.hnx[i], p.hny[i], p.hnz[i]);
+    }
+    // ---- stage the shared tables
+    if (threadIdx.x == 0) {
+        s_live = 0;
+        if (blockIdx.x == 0) {  // work heads of this round's two trace kernels
+            ctr->trace_head[0] = ap.head_init;
+            ctr->trace_head[1] = ap.head_init;
+        }
+    }
+    if (ap.tables_in_lds) {
+        int t = threadIdx.x;
+        if (t < sc.num_mats) s_mats[t] = sc.mats[t];
+        if (t < sc.num_lights) {
+            Light l = sc.lights[t];
+            s_lights[t] = l;
+            LightPre pre{0.f, 0.f, 0.f, 0.f};
+            if (l.type == 1) {
+                Tri lt = load_tri(sc.tris, l.tri);
+                const float *src = (const float *)(sc.tris + 3 * (size_t)l.tri);
+#pragma unroll
+                for (int k = 0; k < 12; k++) s_ltri[t][k] = src[k];
+                pre.inv_area = 1.f / tri_area(lt);
+                V3 un = unit(lt.n);
+                pre.nx = un.x;
+                pre.ny = un.y;
+                pre.nz = un.z;
+            }
+            s_lpre[t] = pre;
+        }
+    }
+    __syncthreads();
+
+    const bool alive = bounces != kDone;
     bool did_gen = false, did_shade = false, has_shadow = false, did_emit = false;
     int rr_draws = 0;
-    // shadow ray registers
     V3 s_o = mk(0, 0, 0), s_d = mk(0, 0, 0), s_L = mk(0, 0, 0);
     float s_tmax = 0.f;
-    int s_target = -1, pixel = 0;
+    int s_target = -1;
 
     if (alive) {
-        Rng rs{p.rd[i], p.r0[i], p.r1[i], p.r2[i], p.r3[i], p.r4[i]};
-        int hit_tri = p.hit_tri[i];
-        pixel = p.pixel[i];
-        V3 beta = mk(p.br[i], p.bg[i], p.bb[i]);
         bool beta_dirty = false;
+        const bool hit = hit_info >= 0;
+        const int light_of_hit = hit ? ((hit_info >> 16) & 0xffff) - 1 : -1;
         // Emulate consecutive init() calls (render.cuh:84-137) until one of them ends in mat() or
         // gen(): a slot whose path missed idles (no RNG use) until bounces reaches max_bounces,
         // a slot that Russian roulette "killed" is re-rolled every iteration (Appendix A.1).
         while (true) {
-            bool hit = hit_tri >= 0;
-            if (bounces == 0 && hit) {  // :98-103 emission only at bounce 0
-                int li = sc.tri_info[hit_tri].y;
-                if (li >= 0) {
-                    const Light &l = sc.lights[li];
-                    atomicAdd(&fb[3 * (size_t)pixel + 0], l.lx);
-                    atomicAdd(&fb[3 * (size_t)pixel + 1], l.ly);
-                    atomicAdd(&fb[3 * (size_t)pixel + 2], l.lz);
-                    did_emit = true;
-                }
+            if (bounces == 0 && hit && light_of_hit >= 0) {  // :98-103 emission only at bounce 0
+                Light l = ap.tables_in_lds ? s_lights[light_of_hit] : sc.lights[light_of_hit];
+                atomicAdd(&fb[3 * (size_t)pixel + 0], l.lx);
+                atomicAdd(&fb[3 * (size_t)pixel + 1], l.ly);
+                atomicAdd(&fb[3 * (size_t)pixel + 2], l.lz);
+                did_emit = true;
             }
             bool cont = bounces < ap.max_bounces;  // :109
             bool local_hit = hit;
@@ -231,12 +306,12 @@ k_advance(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__
                 continue;
             }
             // ---- gen() :250-275.  Camera ray id = generation * W + slot (see file header).
-            long long cid = (long long)p.gen[i] * kW + (ap.slot_lo + i);
+            long long cid = (long long)gen * kW + (ap.slot_lo + i);
             if (cid >= ap.cam_end) {
                 bounces = kDone;
                 break;
             }
-            p.gen[i] = p.gen[i] + 1;
+            p.gen[i] = gen + 1;
             pixel = (int)(cid / ap.spp);
             int px = pixel % ap.width;
             int py = pixel / ap.width;
@@ -260,14 +335,9 @@ k_advance(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__
 
         if (did_shade) {
             // ---- mat() :139-248
-            V3 wo = mk(p.dx[i], p.dy[i], p.dz[i]);
-            float hu = p.hit_u[i], hv = p.hit_v[i];
-            Tri tri = load_tri(sc.tris, hit_tri);
-            int2 info = sc.tri_info[hit_tri];
-            Material m = sc.mats[info.x];
+            const int mat_idx = hit_info & 0xffff;
+            Material m = ap.tables_in_lds ? s_mats[mat_idx] : sc.mats[mat_idx];
             V3 multiplier = scale(beta, (float)sc.num_lights);  // taken BEFORE the beta update (:150)
-            V3 isect_p = tri_point(tri, hu, hv);
-            V3 isect_n = neg(unit(tri.n));
             {
                 V3 n = isect_n, wi;
                 float pdf;
@@ -284,7 +354,7 @@ k_advance(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__
             }
             if (sc.num_lights > 0) {
                 int light_idx = min((int)(rng_uniform(rs) * sc.num_lights), sc.num_lights - 1);  // :178
-                Light light = sc.lights[light_idx];
+                Light light = ap.tables_in_lds ? s_lights[light_idx] : sc.lights[light_idx];
                 V3 wi, Li;
                 float lt, lpdf;
                 // Light::sample_Li light.cuh:29-48
@@ -295,16 +365,30 @@ k_advance(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__
                     wi = divf(wi, lt);
                     lpdf = 1.f;
                 } else {
-                    Tri lt_tri = load_tri(sc.tris, light.tri);
-                    lpdf = 1.f / tri_area(lt_tri);  // Triangle::sample_p triangle.cuh:78-82
-                    float a = sqrtf(rng_uniform(rs));
+                    Tri lt_tri;
+                    V3 lun;
+                    if (ap.tables_in_lds) {
+                        const float *q = s_ltri[light_idx];
+                        lt_tri.p0 = mk(q[0], q[1], q[2]);
+                        lt_tri.e1 = mk(q[3], q[4], q[5]);
+                        lt_tri.e2 = mk(q[6], q[7], q[8]);
+                        lt_tri.n = mk(q[9], q[10], q[11]);
+                        LightPre pre = s_lpre[light_idx];
+                        lpdf = pre.inv_area;
+                        lun = mk(pre.nx, pre.ny, pre.nz);
+                    } else {
+                        lt_tri = load_tri(sc.tris, light.tri);
+                        lpdf = 1.f / tri_area(lt_tri);
+                        lun = unit(lt_tri.n);
+                    }
+                    float a = sqrtf(rng_uniform(rs));  // Triangle::sample_p triangle.cuh:78-82
                     float u2 = rng_uniform(rs);
                     V3 tp = tri_point(lt_tri, 1 - a, u2 * a);
                     wi = sub(tp, isect_p);
                     lt = len(wi);
                     wi = divf(wi, lt);
                     Li = mk(light.lx, light.ly, light.lz);
-                    lpdf *= len2(sub(tp, isect_p)) / fabsf(dot(unit(lt_tri.n), wi));
+                    lpdf *= len2(sub(tp, isect_p)) / fabsf(dot(lun, wi));
                 }
                 V3 n = dot(isect_n, wi) > 0.f ? isect_n : neg(isect_n);  // :187
                 V3 f;
@@ -341,65 +425,90 @@ k_advance(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__
         p.r4[i] = rs.v4;
     }
 
-    // ---- shadow queue append: one atomic per wave
+    // ---- shadow queue append: ballot + mbcnt inside the wave, one atomic per WORKGROUP
     unsigned long long m = __ballot(has_shadow);
-    if (m != 0) {
-        unsigned rank = prefix_popc(m);
-        unsigned base = 0;
-        int leader = __builtin_ctzll(m);
-        if ((int)lane_id() == leader) base = atomicAdd(&ctr->shadow_count[ap.round & 1], (unsigned)__popcll(m));
-        base = __shfl(base, leader);
-        if (has_shadow) {
-            unsigned q = base + rank;
-            p.sox[q] = s_o.x;
-            p.soy[q] = s_o.y;
-            p.soz[q] = s_o.z;
-            p.sdx[q] = s_d.x;
-            p.sdy[q] = s_d.y;
-            p.sdz[q] = s_d.z;
-            p.stmax[q] = s_tmax;
-            p.slr[q] = s_L.x;
-            p.slg[q] = s_L.y;
-            p.slb[q] = s_L.z;
-            p.spixel[q] = pixel;
-            p.starget[q] = s_target;
-        }
+    unsigned long long traced = __ballot(did_gen || did_shade);
+    unsigned wave_in_block = threadIdx.x >> 6;
+    if (lane_id() == 0) {
+        s_wave_cnt[wave_in_block] = (unsigned)__popcll(m);
+        if (traced != 0) s_live = 1;
     }
-    // ---- counters (one atomic per wave each)
-    wave_count(&ctr->camera_rays, did_gen);
-    wave_count(&ctr->shade_events, did_shade);
-    wave_count(&ctr->closest_rays, did_gen || did_shade);
-    wave_count(&ctr->any_rays, has_shadow);
-    wave_count(&ctr->emission_adds, did_emit);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned tot = 0;
+#pragma unroll
+        for (int k = 0; k < kBlock / 64; k++) tot += s_wave_cnt[k];
+        s_base = tot ? atomicAdd(&ctr->shadow_count[ap.round & 1], tot) : 0u;
+        if (s_live) ctr->last_live_round = ap.round;  // same value from every writer
+    }
+    __syncthreads();
+    if (has_shadow) {
+        unsigned q = s_base + prefix_popc(m);
+        for (unsigned k = 0; k < wave_in_block; k++) q += s_wave_cnt[k];
+        p.sox[q] = s_o.x;
+        p.soy[q] = s_o.y;
+        p.soz[q] = s_o.z;
+        p.sdx[q] = s_d.x;
+        p.sdy[q] = s_d.y;
+        p.sdz[q] = s_d.z;
+        p.stmax[q] = s_tmax;
+        p.slr[q] = s_L.x;
+        p.slg[q] = s_L.y;
+        p.slb[q] = s_L.z;
+        p.spixel[q] = pixel;
+        p.starget[q] = s_target;
+    }
+    // ---- event counters: this wave's own row, no atomics
+    int rr_tot = rr_draws;
     if (__ballot(rr_draws != 0)) {
-        int tot = rr_draws;
-        for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off);
-        if (lane_id() == 0) atomicAdd(&ctr->rr_draws, (unsigned long long)tot);
+        for (int off = 32; off > 0; off >>= 1) rr_tot += __shfl_xor(rr_tot, off);
+    } else {
+        rr_tot = 0;
     }
+    unsigned long long v[C_COUNT] = {(unsigned long long)__popcll(__ballot(did_gen)),
+                                     (unsigned long long)__popcll(__ballot(did_shade)),
+                                     (unsigned long long)__popcll(traced),
+                                     (unsigned long long)__popcll(m),
+                                     (unsigned long long)__popcll(__ballot(did_emit)),
+                                     0ull,
+                                     (unsigned long long)rr_tot,
+                                     0ull};
+    row_add(rows, v);
 }
 
 // ============================================================================ traversal
-// Conservative slab test of one child box (boxes are padded by the builder, the exit distance is
-// widened by 2 ulp): may accept a box the ray misses, never rejects one it hits.
+// One wave-wide traversal engine serves the four trace entry points (closest-hit over the path
+// pools = ch(), render.cuh:297-328; any-hit over the shadow queue = ah(), :278-294; and the two
+// stage-level test hooks), so the parity tests exercise exactly the code the renderer runs.
+//
+// Structure (wave64, persistent):
+//   * every wave owns 64 lanes = 64 rays in flight and keeps pulling ray indices from a global
+//     head counter in chunks of kChunk (one atomic per 256 rays); finished lanes are finalised and
+//     re-filled together once fewer than kRefillAt lanes are still traversing, so the wave does not
+//     idle on its longest ray;
+//   * "while-while": all lanes first step through inner pair records until each holds a leaf (or
+//     is finished), then all lanes test their leaf's triangles -- node steps run beside node steps
+//     and triangle tests beside triangle tests instead of serialising per lane;
+//   * the traversal stack is a column of LDS per lane (replaces device_stack.cuh's int[29] in
+//     scratch memory); entries are inner pair indices (>= 0) or leaf references (< 0).
+//
+// The box test only culls: it is conservative (boxes padded by the builder, exit distance widened
+// by 2 ulp) and may use any arithmetic.  The triangle test is the reference's, bit for bit.
 struct RayPrep {
     V3 o, d, inv;
 };
-__device__ __forceinline__ RayPrep prep_ray(V3 o, V3 d) {
-    RayPrep r;
-    r.o = o;
-    r.d = d;
+__device__ __forceinline__ V3 inv_dir(V3 d) {
     // aabb_intersector.cuh:17-19 clamps |d| away from 0 the same way before inverting
     float ix = 1.f / ((fabsf(d.x) < kFltEps) ? copysignf(kFltEps, d.x) : d.x);
     float iy = 1.f / ((fabsf(d.y) < kFltEps) ? copysignf(kFltEps, d.y) : d.y);
     float iz = 1.f / ((fabsf(d.z) < kFltEps) ? copysignf(kFltEps, d.z) : d.z);
-    r.inv = mk(ix, iy, iz);
-    return r;
+    return mk(ix, iy, iz);
 }
-__device__ __forceinline__ bool box_hit(const RayPrep &r, float lox, float loy, float loz, float hix, float hiy,
+__device__ __forceinline__ bool box_hit(V3 o, V3 inv, float lox, float loy, float loz, float hix, float hiy,
                                         float hiz, float tmax, float &entry) {
-    float ax = (lox - r.o.x) * r.inv.x, bx = (hix - r.o.x) * r.inv.x;
-    float ay = (loy - r.o.y) * r.inv.y, by = (hiy - r.o.y) * r.inv.y;
-    float az = (loz - r.o.z) * r.inv.z, bz = (hiz - r.o.z) * r.inv.z;
+    float ax = (lox - o.x) * inv.x, bx = (hix - o.x) * inv.x;
+    float ay = (loy - o.y) * inv.y, by = (hiy - o.y) * inv.y;
+    float az = (loz - o.z) * inv.z, bz = (hiz - o.z) * inv.z;
     float t_in = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
     float t_out = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
     entry = t_in;
@@ -407,145 +516,212 @@ __device__ __forceinline__ bool box_hit(const RayPrep &r, float lox, float loy, 
     return t_in <= t_out && t_out >= 0.f && t_in <= tmax;
 }
 
-// Closest hit (Bvh::traverse, bvh.cuh:251-303).  Returns leaf-order triangle or -1.
-// stack: this lane's column of the LDS stack, element k at stack[k * kBlock].
-__device__ __forceinline__ int traverse_closest(const DScene &sc, V3 o, V3 d, float tmax, int *stack, float &t_hit,
-                                                float &u_hit, float &v_hit) {
-    RayPrep r = prep_ray(o, d);
-    int best = -1;
-    int sp = 0;
-    int node = 0;
+constexpr int kEntryDone = (int)0x80000000;  // "nothing left to visit" marker for a lane
+constexpr int kChunk = 64;                   // ray indices a wave takes per refill atomic
+constexpr int kRefillAt = 40;                // finalise + refill once <= this many lanes still traverse
+__device__ __forceinline__ int leaf_ref(int first, int count) { return ~((first << 3) | count); }
+
+enum { MODE_POOL_CLOSEST = 0, MODE_QUEUE_ANY = 1, MODE_TEST_CLOSEST = 2, MODE_TEST_ANY = 3 };
+
+struct TraceParams {
+    int total;               // number of ray indices (MODE_QUEUE_ANY reads it from ctr instead)
+    int round;               // MODE_QUEUE_ANY: queue parity
+    int debug_no_deposit;    // perf experiments only: skip the framebuffer atomics
+    unsigned *head;          // work head counter (zeroed before launch)
+    float *fb;               // MODE_QUEUE_ANY
+    DCounters *ctr;          // MODE_QUEUE_ANY
+    DWaveRow *rows;          // MODE_QUEUE_ANY
+    // test modes
+    const float *o3, *d3, *tmax;
+    const int *order, *excluded;
+    int *out_i;
+    float *out_t, *out_u, *out_v;
+};
+
+template <int MODE>
+__global__ void __launch_bounds__(kBlock) k_trace(DScene sc, DPools p, TraceParams tp) {
+    extern __shared__ int s_stack[];
+    constexpr bool ANY = (MODE == MODE_QUEUE_ANY || MODE == MODE_TEST_ANY);
+    int *stack = s_stack + threadIdx.x;
+    int total = tp.total;
+    if (MODE == MODE_QUEUE_ANY) total = (int)tp.ctr->shadow_count[tp.round & 1];
+
+    // wave-uniform work bookkeeping: the first chunk of every wave is static (wave w owns ray
+    // indices [64 w, 64 w + 64)), so the head counter starts at 64 x (waves in the grid) and only
+    // REfills cost an atomic
+    int chunk_next = (int)min((unsigned)total, wave_index() * 64u);
+    int chunk_end = min(total, chunk_next + 64);
+    bool exhausted = false;
+    // per-lane ray state
+    int idx = -1, cur = kEntryDone, sp = 0, best = -1, excluded = -1;
+    V3 o = mk(0, 0, 0), d = mk(0, 0, 0), inv = mk(0, 0, 0);
+    float tmax = 0.f, hu = 0.f, hv = 0.f;
+    bool occluded = false;
+    unsigned long long deposits = 0;
+
     while (true) {
-        const float4 *q = sc.pairs + 4 * (size_t)node;
-        float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
-        int llink = __float_as_int(q3.x), rlink = __float_as_int(q3.y);
-        int lcount = __float_as_int(q3.z), rcount = __float_as_int(q3.w);
-        float el, er;
-        bool hl = box_hit(r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tmax, el);
-        bool hr = box_hit(r, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tmax, er);
-        if (hl && lcount > 0) {
-            for (int k = llink; k < llink + lcount; k++) {
-                Tri tr = load_tri(sc.tris, k);
-                if (tri_intersect(tr, o, d, tmax, t_hit, u_hit, v_hit)) {
-                    tmax = t_hit;
-                    best = k;
+        unsigned long long act = __ballot(idx >= 0 && cur != kEntryDone);
+        if (__popcll(act) <= kRefillAt) {
+            // ---- finalise finished lanes
+            if (MODE == MODE_QUEUE_ANY)
+                deposits += __popcll(__ballot(idx >= 0 && cur == kEntryDone && !occluded));
+            if (idx >= 0 && cur == kEntryDone) {
+                if (MODE == MODE_POOL_CLOSEST) {
+                    // hit record in the form mat() consumes (render.cuh:152-153)
+                    int info = -1;
+                    if (best >= 0) {
+                        Tri tr = load_tri(sc.tris, best);
+                        int2 ml = sc.tri_info[best];
+                        V3 hp = tri_point(tr, hu, hv);
+                        V3 hn = neg(unit(tr.n));
+                        p.hpx[idx] = hp.x;
+                        p.hpy[idx] = hp.y;
+                        p.hpz[idx] = hp.z;
+                        p.hnx[idx] = hn.x;
+                        p.hny[idx] = hn.y;
+                        p.hnz[idx] = hn.z;
+                        info = (ml.x & 0xffff) | ((ml.y + 1) << 16);
+                    }
+                    p.hit_info[idx] = info;
+                } else if (MODE == MODE_QUEUE_ANY) {
+                    if (!occluded && !tp.debug_no_deposit) {  // render.cuh:291-293
+                        int pixel = p.spixel[idx];
+                        atomicAdd(&tp.fb[3 * (size_t)pixel + 0], p.slr[idx]);
+                        atomicAdd(&tp.fb[3 * (size_t)pixel + 1], p.slg[idx]);
+                        atomicAdd(&tp.fb[3 * (size_t)pixel + 2], p.slb[idx]);
+                    }
+                } else if (MODE == MODE_TEST_CLOSEST) {
+                    tp.out_i[idx] = best >= 0 ? tp.order[best] : -1;
+                    tp.out_t[idx] = best >= 0 ? tmax : 0.f;
+                    tp.out_u[idx] = hu;
+                    tp.out_v[idx] = hv;
+                } else {
+                    tp.out_i[idx] = occluded ? 1 : 0;
+                }
+                idx = -1;
+            }
+            // ---- refill idle lanes
+            if (!exhausted) {
+                if (chunk_next >= chunk_end) {
+                    unsigned base = 0;
+                    if (lane_id() == 0) base = atomicAdd(tp.head, (unsigned)kChunk);
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    if ((int)base >= total || base > 0x7fffff00u) {
+                        exhausted = true;
+                    } else {
+                        chunk_next = (int)base;
+                        chunk_end = min((int)base + kChunk, total);
+                    }
+                }
+                if (!exhausted) {
+                    unsigned long long idle = __ballot(idx < 0);
+                    int my = chunk_next + (int)prefix_popc(idle);
+                    if (idx < 0 && my < chunk_end) {
+                        bool live = true;
+                        if (MODE == MODE_POOL_CLOSEST) {
+                            live = p.bounces[my] != kDone;
+                            if (live) {
+                                o = mk(p.ox[my], p.oy[my], p.oz[my]);
+                                d = mk(p.dx[my], p.dy[my], p.dz[my]);
+                                tmax = kFltMax;
+                            }
+                        } else if (MODE == MODE_QUEUE_ANY) {
+                            o = mk(p.sox[my], p.soy[my], p.soz[my]);
+                            d = mk(p.sdx[my], p.sdy[my], p.sdz[my]);
+                            tmax = p.stmax[my];
+                            excluded = p.starget[my];
+                        } else {
+                            o = mk(tp.o3[3 * my], tp.o3[3 * my + 1], tp.o3[3 * my + 2]);
+                            d = mk(tp.d3[3 * my], tp.d3[3 * my + 1], tp.d3[3 * my + 2]);
+                            tmax = tp.tmax[my];
+                            if (MODE == MODE_TEST_ANY) excluded = tp.excluded[my];
+                        }
+                        if (live) {
+                            idx = my;
+                            inv = inv_dir(d);
+                            cur = 0;  // root pair
+                            sp = 0;
+                            best = -1;
+                            occluded = false;
+                        }
+                    }
+                    chunk_next = min(chunk_end, chunk_next + (int)__popcll(idle));
+                }
+            }
+            act = __ballot(idx >= 0 && cur != kEntryDone);
+            if (act == 0) {
+                if (exhausted && __ballot(idx >= 0) == 0) break;
+                continue;
+            }
+        }
+        // ---- inner phase: step through pair records until no lane holds an inner entry
+        while (__ballot(cur >= 0) != 0) {
+            if (cur >= 0) {
+                const float4 *q = sc.pairs + 4 * (size_t)cur;
+                float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+                int llink = __float_as_int(q3.x), rlink = __float_as_int(q3.y);
+                int lcount = __float_as_int(q3.z), rcount = __float_as_int(q3.w);
+                float el, er;
+                bool hl = box_hit(o, inv, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tmax, el);
+                bool hr = box_hit(o, inv, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tmax, er);
+                // child entries: inner pair index, leaf reference, or "empty" (kEntryDone)
+                int cl = lcount > 0 ? leaf_ref(llink, lcount) : (llink >= 0 ? llink : kEntryDone);
+                int cr = rcount > 0 ? leaf_ref(rlink, rcount) : (rlink >= 0 ? rlink : kEntryDone);
+                hl = hl && cl != kEntryDone;
+                hr = hr && cr != kEntryDone;
+                if (hl && hr) {
+                    bool left_first = !(el > er);
+                    stack[sp * kBlock] = left_first ? cr : cl;
+                    sp++;
+                    cur = left_first ? cl : cr;
+                } else if (hl) {
+                    cur = cl;
+                } else if (hr) {
+                    cur = cr;
+                } else if (sp > 0) {
+                    sp--;
+                    cur = stack[sp * kBlock];
+                } else {
+                    cur = kEntryDone;
                 }
             }
         }
-        if (hr && rcount > 0) {
-            for (int k = rlink; k < rlink + rcount; k++) {
+        // ---- leaf phase: every lane that holds a leaf tests its triangles (triangle.cuh:39-58)
+        if (cur != kEntryDone && cur < 0) {
+            int ref = ~cur;
+            int first = ref >> 3, count = ref & 7;
+            for (int k = first; k < first + count; k++) {
                 Tri tr = load_tri(sc.tris, k);
-                if (tri_intersect(tr, o, d, tmax, t_hit, u_hit, v_hit)) {
-                    tmax = t_hit;
-                    best = k;
+                float t, u, v;
+                if (tri_intersect(tr, o, d, tmax, t, u, v)) {
+                    if (ANY) {
+                        if (k != excluded) {  // bvh.cuh:243: first accepted hit that is not the excluded triangle
+                            occluded = true;
+                            break;
+                        }
+                    } else {  // bvh.cuh:227-231: later equal-t hit wins (t <= tmax)
+                        tmax = t;
+                        hu = u;
+                        hv = v;
+                        best = k;
+                    }
                 }
             }
-        }
-        bool il = hl && lcount == 0 && llink >= 0;
-        bool ir = hr && rcount == 0 && rlink >= 0;
-        if (il && ir) {
-            int near = el > er ? rlink : llink;
-            int far = el > er ? llink : rlink;
-            stack[sp * kBlock] = far;
-            sp++;
-            node = near;
-        } else if (il) {
-            node = llink;
-        } else if (ir) {
-            node = rlink;
-        } else {
-            if (sp == 0) break;
-            sp--;
-            node = stack[sp * kBlock];
-        }
-    }
-    return best;
-}
-
-// Any hit excluding one triangle (bvh.cuh:306-357): true if occluded.
-__device__ __forceinline__ bool traverse_any(const DScene &sc, V3 o, V3 d, float tmax, int excluded, int *stack) {
-    RayPrep r = prep_ray(o, d);
-    int sp = 0;
-    int node = 0;
-    while (true) {
-        const float4 *q = sc.pairs + 4 * (size_t)node;
-        float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
-        int llink = __float_as_int(q3.x), rlink = __float_as_int(q3.y);
-        int lcount = __float_as_int(q3.z), rcount = __float_as_int(q3.w);
-        float el, er;
-        bool hl = box_hit(r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tmax, el);
-        bool hr = box_hit(r, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tmax, er);
-        float t, u, v;
-        if (hl && lcount > 0) {
-            for (int k = llink; k < llink + lcount; k++) {
-                Tri tr = load_tri(sc.tris, k);
-                if (tri_intersect(tr, o, d, tmax, t, u, v) && k != excluded) return true;
+            if (ANY && occluded) {
+                cur = kEntryDone;
+            } else if (sp > 0) {
+                sp--;
+                cur = stack[sp * kBlock];
+            } else {
+                cur = kEntryDone;
             }
         }
-        if (hr && rcount > 0) {
-            for (int k = rlink; k < rlink + rcount; k++) {
-                Tri tr = load_tri(sc.tris, k);
-                if (tri_intersect(tr, o, d, tmax, t, u, v) && k != excluded) return true;
-            }
-        }
-        bool il = hl && lcount == 0 && llink >= 0;
-        bool ir = hr && rcount == 0 && rlink >= 0;
-        if (il && ir) {
-            int near = el > er ? rlink : llink;
-            int far = el > er ? llink : rlink;
-            stack[sp * kBlock] = far;
-            sp++;
-            node = near;
-        } else if (il) {
-            node = llink;
-        } else if (ir) {
-            node = rlink;
-        } else {
-            if (sp == 0) break;
-            sp--;
-            node = stack[sp * kBlock];
-        }
     }
-    return false;
-}
-
-// ch() for path rays (render.cuh:297-316)
-__global__ void __launch_bounds__(kBlock) k_trace_closest(DScene sc, DPools p, int n) {
-    __shared__ int s_stack[kStackDepth * kBlock];
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    if (p.bounces[i] == kDone) return;
-    V3 o = mk(p.ox[i], p.oy[i], p.oz[i]);
-    V3 d = mk(p.dx[i], p.dy[i], p.dz[i]);
-    float t = 0.f, u = 0.f, v = 0.f;
-    int best = traverse_closest(sc, o, d, kFltMax, s_stack + threadIdx.x, t, u, v);
-    p.hit_tri[i] = best;
-    p.hit_u[i] = u;
-    p.hit_v[i] = v;
-}
-
-// ah() (render.cuh:278-294) over the compact shadow queue of this round
-__global__ void __launch_bounds__(kBlock)
-k_trace_any(DScene sc, DPools p, int round, float *__restrict__ fb, DCounters *__restrict__ ctr) {
-    __shared__ int s_stack[kStackDepth * kBlock];
-    unsigned count = ctr->shadow_count[round & 1];
-    unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-    bool deposit = false;
-    if (i < count) {
-        V3 o = mk(p.sox[i], p.soy[i], p.soz[i]);
-        V3 d = mk(p.sdx[i], p.sdy[i], p.sdz[i]);
-        bool occluded = traverse_any(sc, o, d, p.stmax[i], p.starget[i], s_stack + threadIdx.x);
-        if (!occluded) {
-            int pixel = p.spixel[i];
-            atomicAdd(&fb[3 * (size_t)pixel + 0], p.slr[i]);
-            atomicAdd(&fb[3 * (size_t)pixel + 1], p.slg[i]);
-            atomicAdd(&fb[3 * (size_t)pixel + 2], p.slb[i]);
-            deposit = true;
-        }
+    if (MODE == MODE_QUEUE_ANY) {
+        if (deposits != 0 && lane_id() == 0) tp.rows[wave_index()].c[C_SHADOW_ADD] += deposits;
+        // the other parity's queue counter is idle during this kernel: clear it for the next round
+        if (blockIdx.x == 0 && threadIdx.x == 0) tp.ctr->shadow_count[(tp.round + 1) & 1] = 0;
     }
-    wave_count(&ctr->shadow_adds, deposit);
-    // the other parity's counter is idle during this kernel: clear it for the next round
-    if (blockIdx.x == 0 && threadIdx.x == 0) ctr->shadow_count[(round + 1) & 1] = 0;
 }
 
 // post_process_framebuffer (render.cuh:330-338): c = sqrt(c * (1/spp))
@@ -554,33 +730,7 @@ __global__ void k_post_process(float *fb, int n_values, float inv_spp) {
     if (i < n_values) fb[i] = sqrtf(fb[i] * inv_spp);
 }
 
-// ---- stage-level test kernels (rays given as AoS xyz triples)
-__global__ void __launch_bounds__(kBlock)
-k_test_closest(DScene sc, int n, const float *__restrict__ o3, const float *__restrict__ d3,
-               const float *__restrict__ tmax, const int *__restrict__ order, int *__restrict__ hit_tri,
-               float *__restrict__ t_out, float *__restrict__ u_out, float *__restrict__ v_out) {
-    __shared__ int s_stack[kStackDepth * kBlock];
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    V3 o = mk(o3[3 * i], o3[3 * i + 1], o3[3 * i + 2]);
-    V3 d = mk(d3[3 * i], d3[3 * i + 1], d3[3 * i + 2]);
-    float t = 0.f, u = 0.f, v = 0.f;
-    int best = traverse_closest(sc, o, d, tmax[i], s_stack + threadIdx.x, t, u, v);
-    hit_tri[i] = best >= 0 ? order[best] : -1;
-    t_out[i] = t;
-    u_out[i] = u;
-    v_out[i] = v;
-}
-__global__ void __launch_bounds__(kBlock)
-k_test_any(DScene sc, int n, const float *__restrict__ o3, const float *__restrict__ d3,
-           const float *__restrict__ tmax, const int *__restrict__ excluded_leaf, int *__restrict__ occluded) {
-    __shared__ int s_stack[kStackDepth * kBlock];
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    V3 o = mk(o3[3 * i], o3[3 * i + 1], o3[3 * i + 2]);
-    V3 d = mk(d3[3 * i], d3[3 * i + 1], d3[3 * i + 2]);
-    occluded[i] = traverse_any(sc, o, d, tmax[i], excluded_leaf[i], s_stack + threadIdx.x) ? 1 : 0;
-}
+// ---- stage-level test kernels
 __global__ void k_test_draw(DPools p, int n, int draws, uint32_t *__restrict__ state6, float *__restrict__ uni) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -619,6 +769,7 @@ struct rt_scene {
         s.mats = d_mats;
         s.lights = d_lights;
         s.num_lights = n_lights;
+        s.num_mats = n_mats;
         return s;
     }
 };
@@ -690,6 +841,8 @@ struct Context {
     std::vector<void *> allocs;
     DCounters *d_ctr = nullptr;
     DCounters *h_ctr = nullptr;  // pinned ring of snapshots
+    DWaveRow *d_rows = nullptr;  // one row per wave of the stage grid
+    int n_rows = 0;
     uint32_t *d_jump = nullptr;
     hipEvent_t ev_ring[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr;
@@ -725,11 +878,11 @@ int get_context(int n, Context **out) {
     c->device = dev;
     c->n = n;
     DPools &p = c->pools;
-    float **fptrs[] = {&p.ox, &p.oy, &p.oz, &p.dx, &p.dy, &p.dz, &p.hit_u, &p.hit_v, &p.br, &p.bg, &p.bb,
+    float **fptrs[] = {&p.ox, &p.oy, &p.oz, &p.dx, &p.dy, &p.dz, &p.hpx, &p.hpy, &p.hpz, &p.hnx, &p.hny, &p.hnz, &p.br, &p.bg, &p.bb,
                        &p.sox, &p.soy, &p.soz, &p.sdx, &p.sdy, &p.sdz, &p.stmax, &p.slr, &p.slg, &p.slb};
     for (float **f : fptrs)
         if (dev_alloc(*c, *f, (size_t)n)) return 1;
-    int **iptrs[] = {&p.hit_tri, &p.bounces, &p.pixel, &p.gen, &p.spixel, &p.starget};
+    int **iptrs[] = {&p.hit_info, &p.bounces, &p.pixel, &p.gen, &p.spixel, &p.starget};
     for (int **f : iptrs)
         if (dev_alloc(*c, *f, (size_t)n)) return 1;
     uint32_t **uptrs[] = {&p.rd, &p.r0, &p.r1, &p.r2, &p.r3, &p.r4};
@@ -737,6 +890,8 @@ int get_context(int n, Context **out) {
         if (dev_alloc(*c, *f, (size_t)n)) return 1;
     if (dev_alloc(*c, c->rng_backup, (size_t)6 * n)) return 1;
     if (dev_alloc(*c, c->d_ctr, 1)) return 1;
+    c->n_rows = ((n + kBlock - 1) / kBlock) * (kBlock / 64);
+    if (dev_alloc(*c, c->d_rows, (size_t)c->n_rows)) return 1;
     if (dev_alloc(*c, c->d_jump, (size_t)20 * 800)) return 1;
     HIP_TRY(hipMemcpy(c->d_jump, jump_powers().data(), sizeof(uint32_t) * 20 * 800, hipMemcpyHostToDevice));
     HIP_TRY(hipHostMalloc((void **)&c->h_ctr, sizeof(DCounters) * 4, hipHostMallocDefault));
@@ -802,7 +957,19 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
     DScene sc = scene->dev();
     Camera cam;
     memcpy(&cam, camera, sizeof(Camera));
-    HIP_TRY(hipMemsetAsync(c.d_ctr, 0, sizeof(DCounters), st));
+    {
+        DCounters zero;
+        zero.shadow_count[0] = zero.shadow_count[1] = 0;
+        zero.last_live_round = -1;
+        zero.pad = 0;
+        zero.trace_head[0] = zero.trace_head[1] = 0;
+        zero.pad2[0] = zero.pad2[1] = 0;
+        c.h_ctr[0] = zero;  // pinned staging
+        HIP_TRY(hipMemcpyAsync(c.d_ctr, &c.h_ctr[0], sizeof(DCounters), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemsetAsync(c.d_rows, 0, sizeof(DWaveRow) * (size_t)c.n_rows, st));
+        HIP_TRY(hipStreamSynchronize(st));  // h_ctr[0] is reused as a snapshot slot below
+    }
+    const size_t lds_bytes = sizeof(int) * (size_t)kBlock * (size_t)std::max(1, scene->max_depth);
     hipLaunchKernelGGL(k_pool_init, dim3(grid_for(n)), dim3(kBlock), 0, st, c.pools, n, max_bounces);
     HIP_TRY(hipGetLastError());
 
@@ -815,6 +982,7 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
     ap.max_bounces = max_bounces;
     ap.cam_end = cam_end;
     ap.round = 0;
+    ap.tables_in_lds = (scene->n_mats <= kLdsTable && scene->n_lights <= kLdsTable) ? 1 : 0;
 
     hipEvent_t ev_start, ev_stop;
     HIP_TRY(hipEventCreate(&ev_start));
@@ -828,10 +996,27 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
     const long long generations = (cam_end + kW - 1) / kW;
     const long long max_rounds = (generations + 1) * (long long)(max_bounces + 2) + 64;
     long long rounds = 0;
-    unsigned long long last_closest = ~0ull;
     int batch = 0;
     bool finished = false;
     const dim3 grid(grid_for(n)), block(kBlock);
+    // persistent trace kernels: as many workgroups as the chip keeps resident (never more than the
+    // advance grid, whose wave count sizes the counter rows)
+    int dev_cus = 0, occ_c = 0, occ_a = 0;
+    HIP_TRY(hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, dev));
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_c, k_trace<MODE_POOL_CLOSEST>, kBlock, lds_bytes));
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_a, k_trace<MODE_QUEUE_ANY>, kBlock, lds_bytes));
+    const int resident = std::max(1, dev_cus * std::max(1, std::min(occ_c, occ_a)));
+    const dim3 grid_trace(std::min(grid_for(n), resident));
+    TraceParams tpc{};
+    tpc.total = n;
+    tpc.head = &c.d_ctr->trace_head[0];
+    TraceParams tpa{};
+    tpa.head = &c.d_ctr->trace_head[1];
+    tpa.fb = d_sum;
+    tpa.ctr = c.d_ctr;
+    tpa.rows = c.d_rows;
+    tpa.debug_no_deposit = (flags & 0x100u) ? 1 : 0;
+    ap.head_init = grid_trace.x * (unsigned)(kBlock / 64) * 64u;
     // RT_FLAG_TIME_KERNELS: every kTimeStride-th round is bracketed with HIP events on the launch
     // stream (no host synchronisation); the events are resolved after the loop.
     const int kTimeStride = 4;
@@ -853,16 +1038,18 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
                 hipEvent_t e0, e1, e2, e3;
                 if (next_event(&e0) || next_event(&e1) || next_event(&e2) || next_event(&e3)) return 1;
                 HIP_TRY(hipEventRecord(e0, st));
-                hipLaunchKernelGGL(k_advance, grid, block, 0, st, sc, c.pools, cam, ap, d_sum, c.d_ctr);
+                hipLaunchKernelGGL(k_advance, grid, block, 0, st, sc, c.pools, cam, ap, d_sum, c.d_ctr, c.d_rows);
                 HIP_TRY(hipEventRecord(e1, st));
-                hipLaunchKernelGGL(k_trace_closest, grid, block, 0, st, sc, c.pools, n);
+                hipLaunchKernelGGL(k_trace<MODE_POOL_CLOSEST>, grid_trace, block, lds_bytes, st, sc, c.pools, tpc);
                 HIP_TRY(hipEventRecord(e2, st));
-                hipLaunchKernelGGL(k_trace_any, grid, block, 0, st, sc, c.pools, ap.round, d_sum, c.d_ctr);
+                tpa.round = ap.round;
+                hipLaunchKernelGGL(k_trace<MODE_QUEUE_ANY>, grid_trace, block, lds_bytes, st, sc, c.pools, tpa);
                 HIP_TRY(hipEventRecord(e3, st));
             } else {
-                hipLaunchKernelGGL(k_advance, grid, block, 0, st, sc, c.pools, cam, ap, d_sum, c.d_ctr);
-                hipLaunchKernelGGL(k_trace_closest, grid, block, 0, st, sc, c.pools, n);
-                hipLaunchKernelGGL(k_trace_any, grid, block, 0, st, sc, c.pools, ap.round, d_sum, c.d_ctr);
+                hipLaunchKernelGGL(k_advance, grid, block, 0, st, sc, c.pools, cam, ap, d_sum, c.d_ctr, c.d_rows);
+                hipLaunchKernelGGL(k_trace<MODE_POOL_CLOSEST>, grid_trace, block, lds_bytes, st, sc, c.pools, tpc);
+                tpa.round = ap.round;
+                hipLaunchKernelGGL(k_trace<MODE_QUEUE_ANY>, grid_trace, block, lds_bytes, st, sc, c.pools, tpa);
             }
             rounds++;
         }
@@ -872,9 +1059,8 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
         if (batch >= 1) {
             int prev = (batch - 1) & 3;
             HIP_TRY(hipEventSynchronize(c.ev_ring[prev]));
-            unsigned long long cl = c.h_ctr[prev].closest_rays;
-            if (cl == last_closest) finished = true;  // a whole batch without a single traced ray
-            last_closest = cl;
+            // batch b covers rounds [b*kBatch, (b+1)*kBatch): nothing alive in any of them -> done
+            if ((long long)c.h_ctr[prev].last_live_round < (long long)(batch - 1) * kBatch) finished = true;
         }
         batch++;
     }
@@ -884,8 +1070,11 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
     HIP_TRY(hipEventElapsedTime(&ms_total, ev_start, ev_stop));
     HIP_TRY(hipEventDestroy(ev_start));
     HIP_TRY(hipEventDestroy(ev_stop));
-    DCounters fin;
-    HIP_TRY(hipMemcpy(&fin, c.d_ctr, sizeof(DCounters), hipMemcpyDeviceToHost));
+    std::vector<DWaveRow> h_rows((size_t)c.n_rows);
+    HIP_TRY(hipMemcpy(h_rows.data(), c.d_rows, sizeof(DWaveRow) * (size_t)c.n_rows, hipMemcpyDeviceToHost));
+    unsigned long long fin[C_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (const DWaveRow &r : h_rows)
+        for (int k = 0; k < C_COUNT; k++) fin[k] += r.c[k];
     double t_adv = 0, t_ch = 0, t_ah = 0;
     long long n_sampled = (long long)(ev_used / 4);
     for (size_t q = 0; q + 3 < ev_used; q += 4) {
@@ -900,13 +1089,13 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
     if (!finished) return fail("rt_render_shard: round limit reached before the path pool drained");
     if (stats) {
         memset(stats, 0, sizeof(*stats));
-        stats->camera_rays = (int64_t)fin.camera_rays;
-        stats->shade_events = (int64_t)fin.shade_events;
-        stats->closest_rays = (int64_t)fin.closest_rays;
-        stats->any_rays = (int64_t)fin.any_rays;
-        stats->emission_adds = (int64_t)fin.emission_adds;
-        stats->shadow_adds = (int64_t)fin.shadow_adds;
-        stats->rr_draws = (int64_t)fin.rr_draws;
+        stats->camera_rays = (int64_t)fin[C_CAMERA];
+        stats->shade_events = (int64_t)fin[C_SHADE];
+        stats->closest_rays = (int64_t)fin[C_CLOSEST];
+        stats->any_rays = (int64_t)fin[C_ANY];
+        stats->emission_adds = (int64_t)fin[C_EMIT];
+        stats->shadow_adds = (int64_t)fin[C_SHADOW_ADD];
+        stats->rr_draws = (int64_t)fin[C_RR];
         stats->iterations = rounds;
         stats->bvh_nodes = scene->n_pairs;
         stats->bvh_depth = scene->max_depth;
@@ -940,6 +1129,7 @@ int rt_scene_create(const float *tri_p0p1p2, int n_tris, const int32_t *tri_mate
     if (n_tris > 0 && (!tri_p0p1p2 || !tri_material)) return fail("rt_scene_create: null triangle arrays");
     if (n_tris > 0 && (n_materials == 0 || !materials)) return fail("rt_scene_create: no materials");
     if (n_lights > 0 && !lights) return fail("rt_scene_create: null lights");
+    if (n_materials > 65535 || n_lights > 32766) return fail("rt_scene_create: at most 65535 materials and 32766 lights");
     for (int i = 0; i < n_tris; i++) {
         if (tri_material[i] < 0 || tri_material[i] >= n_materials)
             return fail("rt_scene_create: tri_material[" + std::to_string(i) + "] out of range");
@@ -958,7 +1148,7 @@ int rt_scene_create(const float *tri_p0p1p2, int n_tris, const int32_t *tri_mate
     auto sc = std::make_unique<rt_scene>();
     HIP_TRY(hipGetDevice(&sc->device));
     rtbvh::Result bvh = rtbvh::build(tri_p0p1p2, n_tris);
-    if (bvh.max_depth > kStackDepth + 1)
+    if (bvh.max_depth > kMaxStackDepth)
         return fail("rt_scene_create: BVH depth " + std::to_string(bvh.max_depth) + " exceeds the traversal stack");
     sc->n_tris = n_tris;
     sc->n_pairs = (int)bvh.pairs.size();
@@ -1121,15 +1311,36 @@ int rt_trace_closest(const rt_scene *scene, int n, const float *origin_xyz, cons
     HIP_TRY(hipMemcpy(d_o, origin_xyz, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d_d, dir_xyz, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d_tm, tmax, sizeof(float) * (size_t)n, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_test_closest, dim3(grid_for(n)), dim3(kBlock), 0, nullptr, scene->dev(), n, d_o, d_d, d_tm,
-                       scene->d_order, d_h, d_t, d_u, d_v);
+    unsigned *d_head = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_head, sizeof(unsigned)));
+    const int test_grid = std::min(grid_for(n), 2048);
+    {
+        unsigned h0 = (unsigned)test_grid * kBlock;
+        HIP_TRY(hipMemcpy(d_head, &h0, sizeof(unsigned), hipMemcpyHostToDevice));
+    }
+    {
+        TraceParams tp{};
+        tp.total = n;
+        tp.head = d_head;
+        tp.o3 = d_o;
+        tp.d3 = d_d;
+        tp.tmax = d_tm;
+        tp.order = scene->d_order;
+        tp.out_i = d_h;
+        tp.out_t = d_t;
+        tp.out_u = d_u;
+        tp.out_v = d_v;
+        DPools none{};
+        hipLaunchKernelGGL(k_trace<MODE_TEST_CLOSEST>, dim3(test_grid), dim3(kBlock),
+                           sizeof(int) * kBlock * (size_t)std::max(1, scene->max_depth), nullptr, scene->dev(), none, tp);
+    }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(hit_tri, d_h, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(t, d_t, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(u, d_u, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(v, d_v, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost));
     (void)hipFree(d_o); (void)hipFree(d_d); (void)hipFree(d_tm); (void)hipFree(d_t);
-    (void)hipFree(d_u); (void)hipFree(d_v); (void)hipFree(d_h);
+    (void)hipFree(d_u); (void)hipFree(d_v); (void)hipFree(d_h); (void)hipFree(d_head);
     return 0;
 }
 
@@ -1154,11 +1365,30 @@ int rt_trace_any(const rt_scene *scene, int n, const float *origin_xyz, const fl
     HIP_TRY(hipMemcpy(d_d, dir_xyz, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d_tm, tmax, sizeof(float) * (size_t)n, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d_e, excl.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_test_any, dim3(grid_for(n)), dim3(kBlock), 0, nullptr, scene->dev(), n, d_o, d_d, d_tm, d_e,
-                       d_occ);
+    unsigned *d_head = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_head, sizeof(unsigned)));
+    const int test_grid = std::min(grid_for(n), 2048);
+    {
+        unsigned h0 = (unsigned)test_grid * kBlock;
+        HIP_TRY(hipMemcpy(d_head, &h0, sizeof(unsigned), hipMemcpyHostToDevice));
+    }
+    {
+        TraceParams tp{};
+        tp.total = n;
+        tp.head = d_head;
+        tp.o3 = d_o;
+        tp.d3 = d_d;
+        tp.tmax = d_tm;
+        tp.excluded = d_e;
+        tp.out_i = d_occ;
+        DPools none{};
+        hipLaunchKernelGGL(k_trace<MODE_TEST_ANY>, dim3(test_grid), dim3(kBlock),
+                           sizeof(int) * kBlock * (size_t)std::max(1, scene->max_depth), nullptr, scene->dev(), none, tp);
+    }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(occluded, d_occ, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost));
     (void)hipFree(d_o); (void)hipFree(d_d); (void)hipFree(d_tm); (void)hipFree(d_e); (void)hipFree(d_occ);
+    (void)hipFree(d_head);
     return 0;
 }
 
