@@ -73,7 +73,14 @@ struct DScene {
     const Light *lights;
     int num_lights;
     int num_mats;
+    // shading tables in one block of dwords: [materials 5/each][lights 8/each][light triangle
+    // records 12/each][per-light precomputed {1/area, unit normal} 4/each]
+    const float *tables;
+    int tab_dwords;
 };
+__device__ __host__ inline int tab_off_lights(int n_mats) { return 5 * n_mats; }
+__device__ __host__ inline int tab_off_ltri(int n_mats, int n_lights) { return 5 * n_mats + 8 * n_lights; }
+__device__ __host__ inline int tab_off_lpre(int n_mats, int n_lights) { return 5 * n_mats + 20 * n_lights; }
 
 // Structure-of-arrays path state for the slots of one shard (n slots each)
 struct DPools {
@@ -87,9 +94,10 @@ struct DPools {
     int *pixel;
     int *gen;  // index of the slot's NEXT camera-ray generation
     uint32_t *rd, *r0, *r1, *r2, *r3, *r4;  // XORWOW state
-    // shadow-ray queue (compact)
+    // shadow ray of the slot for this round (stmax < 0: none); the any-hit kernel compacts them
+    // wave-locally while it pulls work, so the producer needs no queue, atomics or barriers
     float *sox, *soy, *soz, *sdx, *sdy, *sdz, *stmax, *slr, *slg, *slb;
-    int *spixel, *starget;
+    int *starget;
 };
 
 // Global words that need atomics / host polling.  Event counters are NOT here: they live in
@@ -97,10 +105,8 @@ struct DPools {
 // 16384 waves hitting eight shared words with atomics every round was the single largest cost of
 // the first version of k_advance.
 struct DCounters {
-    unsigned int shadow_count[2];  // queue fill, double-buffered by round parity
-    int last_live_round;           // highest round in which some slot still had a ray to trace
+    int last_live_round;         // highest batch-closing round in which some slot still traced a ray
     int pad;
-    unsigned int trace_head[2];    // work heads of the two persistent trace kernels (zeroed by k_advance)
     unsigned int pad2[2];
 };
 enum { C_CAMERA = 0, C_SHADE, C_CLOSEST, C_ANY, C_EMIT, C_SHADOW_ADD, C_RR, C_UNUSED, C_COUNT };
@@ -125,7 +131,8 @@ __device__ __forceinline__ void row_add(DWaveRow *rows, const unsigned long long
     unsigned long long mine = 0;
 #pragma unroll
     for (int k = 0; k < C_COUNT; k++) mine = (l == (unsigned)k) ? v[k] : mine;
-    if (l < C_COUNT && mine != 0) rows[wave_index()].c[l] += mine;
+    // no-return atomics on a line only this wave touches: fire-and-forget, no load round trip
+    if (l < C_COUNT && mine != 0) atomicAdd(&rows[wave_index()].c[l], mine);
 }
 
 // ============================================================================ RNG init kernel
@@ -185,31 +192,81 @@ struct AdvanceParams {
     int width, height, spp, max_bounces;
     long long cam_end;  // width*height*spp
     int round;
-    int tables_in_lds;  // materials and lights fit the LDS tables below
-    unsigned head_init; // 64 x waves of the persistent trace grid (their first chunk is static)
+    int batch_mask;      // rounds with (round & batch_mask) == batch_mask close a host-polled batch
 };
 
-constexpr int kLdsTable = 64;  // materials / lights staged in LDS per workgroup (larger scenes read global)
-struct LightPre {              // per-light values that depend on the light triangle only
-    float inv_area;            // 1 / Triangle::area()                (triangle.cuh:79,84-86)
-    float nx, ny, nz;          // d_triangle->n.unit_vector()         (light.cuh:46)
-};
+constexpr int kLdsTable = 64;                   // materials / lights staged in LDS per workgroup
+constexpr int kTabDwordsMax = kLdsTable * 29;   // 5 + 8 + 12 + 4 dwords per (material, light)
 
-// Every per-slot input of this kernel is indexed by the slot id, so all of a lane's loads are
-// issued together (one memory round trip); the small shared tables (materials, lights, light
-// triangles) are staged in LDS once per workgroup.  The hit record written by k_trace<POOL_CLOSEST>
-// already carries the shading point, the flipped unit normal and the material/light ids, so no
-// triangle is gathered here.
+// Per-light values that depend on the light triangle only, computed once per scene on the device
+// with the same operations mat() would redo per shade: 1 / Triangle::area() (triangle.cuh:79,84-86)
+// and d_triangle->n.unit_vector() (light.cuh:46).
+__global__ void k_build_tables(const Material *mats, int n_mats, const Light *lights, int n_lights,
+                               const float4 *tris, float *tab) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n_mats) {
+        const float *src = (const float *)&mats[t];
+        for (int k = 0; k < 5; k++) tab[5 * t + k] = src[k];
+    }
+    if (t < n_lights) {
+        const float *src = (const float *)&lights[t];
+        float *dl = tab + tab_off_lights(n_mats) + 8 * t;
+        for (int k = 0; k < 8; k++) dl[k] = src[k];
+        float *dt = tab + tab_off_ltri(n_mats, n_lights) + 12 * t;
+        float *dp = tab + tab_off_lpre(n_mats, n_lights) + 4 * t;
+        Light l = lights[t];
+        if (l.type == 1) {
+            Tri lt = load_tri(tris, l.tri);
+            const float *q = (const float *)(tris + 3 * (size_t)l.tri);
+            for (int k = 0; k < 12; k++) dt[k] = q[k];
+            V3 un = unit(lt.n);
+            dp[0] = 1.f / tri_area(lt);
+            dp[1] = un.x;
+            dp[2] = un.y;
+            dp[3] = un.z;
+        } else {
+            for (int k = 0; k < 12; k++) dt[k] = 0.f;
+            dp[0] = dp[1] = dp[2] = dp[3] = 0.f;
+        }
+    }
+}
+
+__device__ __forceinline__ Material tab_material(const float *tab, int i) {
+    const float *q = tab + 5 * i;
+    Material m;
+    m.ax = q[0];
+    m.ay = q[1];
+    m.az = q[2];
+    m.ior = q[3];
+    m.type = __float_as_int(q[4]);
+    return m;
+}
+__device__ __forceinline__ Light tab_light(const float *tab, int n_mats, int i) {
+    const float *q = tab + tab_off_lights(n_mats) + 8 * i;
+    Light l;
+    l.type = __float_as_int(q[0]);
+    l.px = q[1];
+    l.py = q[2];
+    l.pz = q[3];
+    l.tri = __float_as_int(q[4]);
+    l.lx = q[5];
+    l.ly = q[6];
+    l.lz = q[7];
+    return l;
+}
+
+// init() + mat() + gen() for one slot (render.cuh:84-275).
+// Every per-slot input is indexed by the slot id, so all of a lane's loads are issued together
+// (one memory round trip); the small shared tables are staged in LDS with one more independent
+// round trip; the hit record written by k_trace<POOL_CLOSEST> already carries the shading point,
+// the flipped unit normal and the material / light ids, so no triangle is gathered here.  The
+// kernel has no atomics on shared words and one barrier (the table staging): the shadow ray goes
+// to the slot's own record, event counts go to the wave's own counter row.
+template <bool LDS_TABLES>
 __global__ void __launch_bounds__(kBlock)
 k_advance(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__ fb, DCounters *__restrict__ ctr,
           DWaveRow *__restrict__ rows) {
-    __shared__ unsigned s_wave_cnt[kBlock / 64];
-    __shared__ unsigned s_base;
-    __shared__ unsigned s_live;
-    __shared__ Material s_mats[kLdsTable];
-    __shared__ Light s_lights[kLdsTable];
-    __shared__ float s_ltri[kLdsTable][12];
-    __shared__ LightPre s_lpre[kLdsTable];
+    __shared__ float s_tab[LDS_TABLES ? kTabDwordsMax : 1];
 
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool in_range = i < ap.n;
@@ -228,43 +285,18 @@ k_advance(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__
         isect_p = mk(p.hpx[i], p.hpy[i], p.hpz[i]);
         isect_n = mk(p.hnx[i], p.hny[i], p.hnz[i]);
     }
-    // ---- stage the shared tables
-    if (threadIdx.x == 0) {
-        s_live = 0;
-        if (blockIdx.x == 0) {  // work heads of this round's two trace kernels
-            ctr->trace_head[0] = ap.head_init;
-            ctr->trace_head[1] = ap.head_init;
-        }
+    const float *tab = sc.tables;
+    if (LDS_TABLES) {
+        for (int k = threadIdx.x; k < sc.tab_dwords; k += kBlock) s_tab[k] = sc.tables[k];
+        __syncthreads();
+        tab = s_tab;
     }
-    if (ap.tables_in_lds) {
-        int t = threadIdx.x;
-        if (t < sc.num_mats) s_mats[t] = sc.mats[t];
-        if (t < sc.num_lights) {
-            Light l = sc.lights[t];
-            s_lights[t] = l;
-            LightPre pre{0.f, 0.f, 0.f, 0.f};
-            if (l.type == 1) {
-                Tri lt = load_tri(sc.tris, l.tri);
-                const float *src = (const float *)(sc.tris + 3 * (size_t)l.tri);
-#pragma unroll
-                for (int k = 0; k < 12; k++) s_ltri[t][k] = src[k];
-                pre.inv_area = 1.f / tri_area(lt);
-                V3 un = unit(lt.n);
-                pre.nx = un.x;
-                pre.ny = un.y;
-                pre.nz = un.z;
-            }
-            s_lpre[t] = pre;
-        }
-    }
-    __syncthreads();
+    const int off_ltri = tab_off_ltri(sc.num_mats, sc.num_lights);
+    const int off_lpre = tab_off_lpre(sc.num_mats, sc.num_lights);
 
     const bool alive = bounces != kDone;
     bool did_gen = false, did_shade = false, has_shadow = false, did_emit = false;
     int rr_draws = 0;
-    V3 s_o = mk(0, 0, 0), s_d = mk(0, 0, 0), s_L = mk(0, 0, 0);
-    float s_tmax = 0.f;
-    int s_target = -1;
 
     if (alive) {
         bool beta_dirty = false;
@@ -275,7 +307,7 @@ k_advance(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__
         // a slot that Russian roulette "killed" is re-rolled every iteration (Appendix A.1).
         while (true) {
             if (bounces == 0 && hit && light_of_hit >= 0) {  // :98-103 emission only at bounce 0
-                Light l = ap.tables_in_lds ? s_lights[light_of_hit] : sc.lights[light_of_hit];
+                Light l = tab_light(tab, sc.num_mats, light_of_hit);
                 atomicAdd(&fb[3 * (size_t)pixel + 0], l.lx);
                 atomicAdd(&fb[3 * (size_t)pixel + 1], l.ly);
                 atomicAdd(&fb[3 * (size_t)pixel + 2], l.lz);
@@ -335,8 +367,7 @@ k_advance(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__
 
         if (did_shade) {
             // ---- mat() :139-248
-            const int mat_idx = hit_info & 0xffff;
-            Material m = ap.tables_in_lds ? s_mats[mat_idx] : sc.mats[mat_idx];
+            Material m = tab_material(tab, hit_info & 0xffff);
             V3 multiplier = scale(beta, (float)sc.num_lights);  // taken BEFORE the beta update (:150)
             {
                 V3 n = isect_n, wi;
@@ -354,7 +385,7 @@ k_advance(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__
             }
             if (sc.num_lights > 0) {
                 int light_idx = min((int)(rng_uniform(rs) * sc.num_lights), sc.num_lights - 1);  // :178
-                Light light = ap.tables_in_lds ? s_lights[light_idx] : sc.lights[light_idx];
+                Light light = tab_light(tab, sc.num_mats, light_idx);
                 V3 wi, Li;
                 float lt, lpdf;
                 // Light::sample_Li light.cuh:29-48
@@ -365,23 +396,16 @@ k_advance(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__
                     wi = divf(wi, lt);
                     lpdf = 1.f;
                 } else {
+                    const float *q = tab + off_ltri + 12 * light_idx;
+                    const float *pre = tab + off_lpre + 4 * light_idx;
                     Tri lt_tri;
-                    V3 lun;
-                    if (ap.tables_in_lds) {
-                        const float *q = s_ltri[light_idx];
-                        lt_tri.p0 = mk(q[0], q[1], q[2]);
-                        lt_tri.e1 = mk(q[3], q[4], q[5]);
-                        lt_tri.e2 = mk(q[6], q[7], q[8]);
-                        lt_tri.n = mk(q[9], q[10], q[11]);
-                        LightPre pre = s_lpre[light_idx];
-                        lpdf = pre.inv_area;
-                        lun = mk(pre.nx, pre.ny, pre.nz);
-                    } else {
-                        lt_tri = load_tri(sc.tris, light.tri);
-                        lpdf = 1.f / tri_area(lt_tri);
-                        lun = unit(lt_tri.n);
-                    }
-                    float a = sqrtf(rng_uniform(rs));  // Triangle::sample_p triangle.cuh:78-82
+                    lt_tri.p0 = mk(q[0], q[1], q[2]);
+                    lt_tri.e1 = mk(q[3], q[4], q[5]);
+                    lt_tri.e2 = mk(q[6], q[7], q[8]);
+                    lt_tri.n = mk(q[9], q[10], q[11]);
+                    lpdf = pre[0];                       // 1 / area
+                    V3 lun = mk(pre[1], pre[2], pre[3]);  // unit normal of the light triangle
+                    float a = sqrtf(rng_uniform(rs));     // Triangle::sample_p triangle.cuh:78-82
                     float u2 = rng_uniform(rs);
                     V3 tp = tri_point(lt_tri, 1 - a, u2 * a);
                     wi = sub(tp, isect_p);
@@ -395,16 +419,25 @@ k_advance(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__
                 float spdf;
                 if (mat_get_f(m, wo, wi, n, f, spdf)) {
                     f = scale(f, dot(wi, n));
-                    s_o = offset_ray_origin(isect_p, n);
-                    s_d = wi;
-                    s_tmax = lt;
-                    s_target = light.type == 1 ? light.tri : -1;
+                    V3 s_o = offset_ray_origin(isect_p, n);
+                    V3 s_L;
                     if (light.type == 0) {
                         s_L = divf(mul(mul(multiplier, f), Li), lpdf);  // :199
                     } else {
                         float weight = power_heuristic(lpdf, spdf);  // :201 (int-truncating)
                         s_L = divf(scale(mul(mul(multiplier, f), Li), weight), lpdf);  // :202
                     }
+                    p.sox[i] = s_o.x;
+                    p.soy[i] = s_o.y;
+                    p.soz[i] = s_o.z;
+                    p.sdx[i] = wi.x;
+                    p.sdy[i] = wi.y;
+                    p.sdz[i] = wi.z;
+                    p.slr[i] = s_L.x;
+                    p.slg[i] = s_L.y;
+                    p.slb[i] = s_L.z;
+                    p.starget[i] = light.type == 1 ? light.tri : -1;
+                    p.stmax[i] = lt;
                     has_shadow = true;
                 }
                 // "sample BSDF with MIS" block :213-245: its ray cannot contribute; keep its draws
@@ -424,41 +457,10 @@ k_advance(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__
         p.r3[i] = rs.v3;
         p.r4[i] = rs.v4;
     }
+    if (in_range && !has_shadow) p.stmax[i] = -1.f;  // no shadow ray from this slot this round
 
-    // ---- shadow queue append: ballot + mbcnt inside the wave, one atomic per WORKGROUP
-    unsigned long long m = __ballot(has_shadow);
+    // ---- event counters: this wave's own row
     unsigned long long traced = __ballot(did_gen || did_shade);
-    unsigned wave_in_block = threadIdx.x >> 6;
-    if (lane_id() == 0) {
-        s_wave_cnt[wave_in_block] = (unsigned)__popcll(m);
-        if (traced != 0) s_live = 1;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned tot = 0;
-#pragma unroll
-        for (int k = 0; k < kBlock / 64; k++) tot += s_wave_cnt[k];
-        s_base = tot ? atomicAdd(&ctr->shadow_count[ap.round & 1], tot) : 0u;
-        if (s_live) ctr->last_live_round = ap.round;  // same value from every writer
-    }
-    __syncthreads();
-    if (has_shadow) {
-        unsigned q = s_base + prefix_popc(m);
-        for (unsigned k = 0; k < wave_in_block; k++) q += s_wave_cnt[k];
-        p.sox[q] = s_o.x;
-        p.soy[q] = s_o.y;
-        p.soz[q] = s_o.z;
-        p.sdx[q] = s_d.x;
-        p.sdy[q] = s_d.y;
-        p.sdz[q] = s_d.z;
-        p.stmax[q] = s_tmax;
-        p.slr[q] = s_L.x;
-        p.slg[q] = s_L.y;
-        p.slb[q] = s_L.z;
-        p.spixel[q] = pixel;
-        p.starget[q] = s_target;
-    }
-    // ---- event counters: this wave's own row, no atomics
     int rr_tot = rr_draws;
     if (__ballot(rr_draws != 0)) {
         for (int off = 32; off > 0; off >>= 1) rr_tot += __shfl_xor(rr_tot, off);
@@ -468,12 +470,15 @@ k_advance(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__
     unsigned long long v[C_COUNT] = {(unsigned long long)__popcll(__ballot(did_gen)),
                                      (unsigned long long)__popcll(__ballot(did_shade)),
                                      (unsigned long long)__popcll(traced),
-                                     (unsigned long long)__popcll(m),
+                                     (unsigned long long)__popcll(__ballot(has_shadow)),
                                      (unsigned long long)__popcll(__ballot(did_emit)),
                                      0ull,
                                      (unsigned long long)rr_tot,
                                      0ull};
     row_add(rows, v);
+    // liveness is monotone (a finished slot never restarts), so the host only needs it for the
+    // round that closes a batch: one plain store per live wave in 1 round out of 8
+    if ((ap.round & ap.batch_mask) == ap.batch_mask && traced != 0 && lane_id() == 0) ctr->last_live_round = ap.round;
 }
 
 // ============================================================================ traversal
@@ -517,20 +522,16 @@ __device__ __forceinline__ bool box_hit(V3 o, V3 inv, float lox, float loy, floa
 }
 
 constexpr int kEntryDone = (int)0x80000000;  // "nothing left to visit" marker for a lane
-constexpr int kChunk = 64;                   // ray indices a wave takes per refill atomic
 constexpr int kRefillAt = 40;                // finalise + refill once <= this many lanes still traverse
 __device__ __forceinline__ int leaf_ref(int first, int count) { return ~((first << 3) | count); }
 
-enum { MODE_POOL_CLOSEST = 0, MODE_QUEUE_ANY = 1, MODE_TEST_CLOSEST = 2, MODE_TEST_ANY = 3 };
+enum { MODE_POOL_CLOSEST = 0, MODE_POOL_ANY = 1, MODE_TEST_CLOSEST = 2, MODE_TEST_ANY = 3 };
 
 struct TraceParams {
-    int total;               // number of ray indices (MODE_QUEUE_ANY reads it from ctr instead)
-    int round;               // MODE_QUEUE_ANY: queue parity
-    int debug_no_deposit;    // perf experiments only: skip the framebuffer atomics
-    unsigned *head;          // work head counter (zeroed before launch)
-    float *fb;               // MODE_QUEUE_ANY
-    DCounters *ctr;          // MODE_QUEUE_ANY
-    DWaveRow *rows;          // MODE_QUEUE_ANY
+    int total;             // number of candidate ray indices (slots, or test rays)
+    int debug_no_deposit;  // perf experiments only: skip the framebuffer atomics
+    float *fb;             // MODE_POOL_ANY
+    DWaveRow *rows;        // MODE_POOL_ANY
     // test modes
     const float *o3, *d3, *tmax;
     const int *order, *excluded;
@@ -538,19 +539,27 @@ struct TraceParams {
     float *out_t, *out_u, *out_v;
 };
 
+// LDS layout of the trace kernels (dynamic): [stack: depth x kBlock ints][pending: kBlock ints]
 template <int MODE>
-__global__ void __launch_bounds__(kBlock) k_trace(DScene sc, DPools p, TraceParams tp) {
-    extern __shared__ int s_stack[];
-    constexpr bool ANY = (MODE == MODE_QUEUE_ANY || MODE == MODE_TEST_ANY);
-    int *stack = s_stack + threadIdx.x;
-    int total = tp.total;
-    if (MODE == MODE_QUEUE_ANY) total = (int)tp.ctr->shadow_count[tp.round & 1];
+__global__ void __launch_bounds__(kBlock, 8) k_trace(DScene sc, DPools p, TraceParams tp, int stack_depth) {
+    extern __shared__ int s_lds[];
+    constexpr bool ANY = (MODE == MODE_POOL_ANY || MODE == MODE_TEST_ANY);
+    int *stack = s_lds + threadIdx.x;
+    volatile int *pend = s_lds + stack_depth * kBlock + (threadIdx.x & ~63);  // this wave's 64 entries
+    const int total = tp.total;
+    const int n_chunks = (total + 63) >> 6;
+    const unsigned lane = lane_id();
 
-    // wave-uniform work bookkeeping: the first chunk of every wave is static (wave w owns ray
-    // indices [64 w, 64 w + 64)), so the head counter starts at 64 x (waves in the grid) and only
-    // REfills cost an atomic
-    int chunk_next = (int)min((unsigned)total, wave_index() * 64u);
-    int chunk_end = min(total, chunk_next + 64);
+    // wave-uniform work bookkeeping.  Candidates come in chunks of 64 consecutive indices, dealt
+    // round-robin over the waves of the grid (chunk = wave id + k * waves): no shared head counter
+    // -- a same-address atomic costs ~5 ns on this chip and 16k of them per launch formed a convoy.
+    // The valid candidates of a chunk (live slots / slots that spawned a shadow ray this round) are
+    // compacted into `pend` with ballot + mbcnt and handed to idle lanes from there, so the ray
+    // queue of the reference (flag arrays + cub::DeviceSelect, render.cuh:431-443) exists only as
+    // 64 ints of LDS per wave.
+    int pend_lo = 0, pend_hi = 0;
+    int next_chunk = (int)wave_index();
+    const int grid_waves = (int)(gridDim.x * (kBlock / 64));
     bool exhausted = false;
     // per-lane ray state
     int idx = -1, cur = kEntryDone, sp = 0, best = -1, excluded = -1;
@@ -563,8 +572,7 @@ __global__ void __launch_bounds__(kBlock) k_trace(DScene sc, DPools p, TracePara
         unsigned long long act = __ballot(idx >= 0 && cur != kEntryDone);
         if (__popcll(act) <= kRefillAt) {
             // ---- finalise finished lanes
-            if (MODE == MODE_QUEUE_ANY)
-                deposits += __popcll(__ballot(idx >= 0 && cur == kEntryDone && !occluded));
+            if (MODE == MODE_POOL_ANY) deposits += __popcll(__ballot(idx >= 0 && cur == kEntryDone && !occluded));
             if (idx >= 0 && cur == kEntryDone) {
                 if (MODE == MODE_POOL_CLOSEST) {
                     // hit record in the form mat() consumes (render.cuh:152-153)
@@ -583,9 +591,9 @@ __global__ void __launch_bounds__(kBlock) k_trace(DScene sc, DPools p, TracePara
                         info = (ml.x & 0xffff) | ((ml.y + 1) << 16);
                     }
                     p.hit_info[idx] = info;
-                } else if (MODE == MODE_QUEUE_ANY) {
+                } else if (MODE == MODE_POOL_ANY) {
                     if (!occluded && !tp.debug_no_deposit) {  // render.cuh:291-293
-                        int pixel = p.spixel[idx];
+                        int pixel = p.pixel[idx];
                         atomicAdd(&tp.fb[3 * (size_t)pixel + 0], p.slr[idx]);
                         atomicAdd(&tp.fb[3 * (size_t)pixel + 1], p.slg[idx]);
                         atomicAdd(&tp.fb[3 * (size_t)pixel + 2], p.slb[idx]);
@@ -600,32 +608,37 @@ __global__ void __launch_bounds__(kBlock) k_trace(DScene sc, DPools p, TracePara
                 }
                 idx = -1;
             }
-            // ---- refill idle lanes
-            if (!exhausted) {
-                if (chunk_next >= chunk_end) {
-                    unsigned base = 0;
-                    if (lane_id() == 0) base = atomicAdd(tp.head, (unsigned)kChunk);
-                    base = __builtin_amdgcn_readfirstlane(base);
-                    if ((int)base >= total || base > 0x7fffff00u) {
+            // ---- refill idle lanes (up to three chunks per refill: shadow rays are sparse)
+            for (int tries = 0; tries < 3; tries++) {
+                unsigned long long idle = __ballot(idx < 0);
+                int n_idle = __popcll(idle);
+                if (n_idle == 0) break;
+                if (pend_lo == pend_hi && !exhausted) {
+                    int chunk = next_chunk;
+                    next_chunk += grid_waves;
+                    if (chunk >= n_chunks) {
                         exhausted = true;
                     } else {
-                        chunk_next = (int)base;
-                        chunk_end = min((int)base + kChunk, total);
+                        int cand = chunk * 64 + (int)lane;
+                        bool valid = cand < total;
+                        if (valid && MODE == MODE_POOL_CLOSEST) valid = p.bounces[cand] != kDone;
+                        if (valid && MODE == MODE_POOL_ANY) valid = p.stmax[cand] >= 0.f;
+                        unsigned long long vm = __ballot(valid);
+                        if (valid) pend[prefix_popc(vm)] = cand;
+                        pend_lo = 0;
+                        pend_hi = __popcll(vm);
                     }
                 }
-                if (!exhausted) {
-                    unsigned long long idle = __ballot(idx < 0);
-                    int my = chunk_next + (int)prefix_popc(idle);
-                    if (idx < 0 && my < chunk_end) {
-                        bool live = true;
+                int avail = pend_hi - pend_lo;
+                if (avail > 0) {
+                    int r = (int)prefix_popc(idle);
+                    if (idx < 0 && r < avail) {
+                        int my = pend[pend_lo + r];
                         if (MODE == MODE_POOL_CLOSEST) {
-                            live = p.bounces[my] != kDone;
-                            if (live) {
-                                o = mk(p.ox[my], p.oy[my], p.oz[my]);
-                                d = mk(p.dx[my], p.dy[my], p.dz[my]);
-                                tmax = kFltMax;
-                            }
-                        } else if (MODE == MODE_QUEUE_ANY) {
+                            o = mk(p.ox[my], p.oy[my], p.oz[my]);
+                            d = mk(p.dx[my], p.dy[my], p.dz[my]);
+                            tmax = kFltMax;
+                        } else if (MODE == MODE_POOL_ANY) {
                             o = mk(p.sox[my], p.soy[my], p.soz[my]);
                             d = mk(p.sdx[my], p.sdy[my], p.sdz[my]);
                             tmax = p.stmax[my];
@@ -636,21 +649,21 @@ __global__ void __launch_bounds__(kBlock) k_trace(DScene sc, DPools p, TracePara
                             tmax = tp.tmax[my];
                             if (MODE == MODE_TEST_ANY) excluded = tp.excluded[my];
                         }
-                        if (live) {
-                            idx = my;
-                            inv = inv_dir(d);
-                            cur = 0;  // root pair
-                            sp = 0;
-                            best = -1;
-                            occluded = false;
-                        }
+                        idx = my;
+                        inv = inv_dir(d);
+                        cur = 0;  // root pair
+                        sp = 0;
+                        best = -1;
+                        occluded = false;
                     }
-                    chunk_next = min(chunk_end, chunk_next + (int)__popcll(idle));
+                    pend_lo += min(avail, n_idle);
+                } else if (exhausted) {
+                    break;
                 }
             }
             act = __ballot(idx >= 0 && cur != kEntryDone);
             if (act == 0) {
-                if (exhausted && __ballot(idx >= 0) == 0) break;
+                if (exhausted && pend_lo == pend_hi) break;  // nothing in flight, nothing pending, no chunks left
                 continue;
             }
         }
@@ -717,10 +730,8 @@ __global__ void __launch_bounds__(kBlock) k_trace(DScene sc, DPools p, TracePara
             }
         }
     }
-    if (MODE == MODE_QUEUE_ANY) {
-        if (deposits != 0 && lane_id() == 0) tp.rows[wave_index()].c[C_SHADOW_ADD] += deposits;
-        // the other parity's queue counter is idle during this kernel: clear it for the next round
-        if (blockIdx.x == 0 && threadIdx.x == 0) tp.ctr->shadow_count[(tp.round + 1) & 1] = 0;
+    if (MODE == MODE_POOL_ANY) {
+        if (deposits != 0 && lane == 0) atomicAdd(&tp.rows[wave_index()].c[C_SHADOW_ADD], deposits);
     }
 }
 
@@ -758,6 +769,8 @@ struct rt_scene {
     int2 *d_tri_info = nullptr;
     Material *d_mats = nullptr;
     Light *d_lights = nullptr;
+    float *d_tables = nullptr;    // shading tables (see DScene)
+    int tab_dwords = 0;
     int *d_order = nullptr;       // leaf order -> original
     std::vector<int> h_order;     // leaf order -> original
     std::vector<int> h_inverse;   // original -> leaf order
@@ -770,6 +783,8 @@ struct rt_scene {
         s.lights = d_lights;
         s.num_lights = n_lights;
         s.num_mats = n_mats;
+        s.tables = d_tables;
+        s.tab_dwords = tab_dwords;
         return s;
     }
 };
@@ -882,7 +897,7 @@ int get_context(int n, Context **out) {
                        &p.sox, &p.soy, &p.soz, &p.sdx, &p.sdy, &p.sdz, &p.stmax, &p.slr, &p.slg, &p.slb};
     for (float **f : fptrs)
         if (dev_alloc(*c, *f, (size_t)n)) return 1;
-    int **iptrs[] = {&p.hit_info, &p.bounces, &p.pixel, &p.gen, &p.spixel, &p.starget};
+    int **iptrs[] = {&p.hit_info, &p.bounces, &p.pixel, &p.gen, &p.starget};
     for (int **f : iptrs)
         if (dev_alloc(*c, *f, (size_t)n)) return 1;
     uint32_t **uptrs[] = {&p.rd, &p.r0, &p.r1, &p.r2, &p.r3, &p.r4};
@@ -959,17 +974,16 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
     memcpy(&cam, camera, sizeof(Camera));
     {
         DCounters zero;
-        zero.shadow_count[0] = zero.shadow_count[1] = 0;
         zero.last_live_round = -1;
         zero.pad = 0;
-        zero.trace_head[0] = zero.trace_head[1] = 0;
         zero.pad2[0] = zero.pad2[1] = 0;
         c.h_ctr[0] = zero;  // pinned staging
         HIP_TRY(hipMemcpyAsync(c.d_ctr, &c.h_ctr[0], sizeof(DCounters), hipMemcpyHostToDevice, st));
         HIP_TRY(hipMemsetAsync(c.d_rows, 0, sizeof(DWaveRow) * (size_t)c.n_rows, st));
         HIP_TRY(hipStreamSynchronize(st));  // h_ctr[0] is reused as a snapshot slot below
     }
-    const size_t lds_bytes = sizeof(int) * (size_t)kBlock * (size_t)std::max(1, scene->max_depth);
+    const int stack_depth = std::max(1, scene->max_depth);
+    const size_t lds_bytes = sizeof(int) * (size_t)kBlock * (size_t)(stack_depth + 1);  // stack + pending
     hipLaunchKernelGGL(k_pool_init, dim3(grid_for(n)), dim3(kBlock), 0, st, c.pools, n, max_bounces);
     HIP_TRY(hipGetLastError());
 
@@ -982,7 +996,8 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
     ap.max_bounces = max_bounces;
     ap.cam_end = cam_end;
     ap.round = 0;
-    ap.tables_in_lds = (scene->n_mats <= kLdsTable && scene->n_lights <= kLdsTable) ? 1 : 0;
+    ap.batch_mask = 7;
+    const bool lds_tables = scene->n_mats <= kLdsTable && scene->n_lights <= kLdsTable;
 
     hipEvent_t ev_start, ev_stop;
     HIP_TRY(hipEventCreate(&ev_start));
@@ -992,7 +1007,7 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
     // Rounds are enqueued in batches; after each batch the counters are snapshotted into pinned
     // host memory.  The host looks at the snapshot of batch b-2 before enqueuing batch b, so the
     // GPU always has work queued, and stops when a whole batch traced no ray.
-    const int kBatch = 8;
+    const int kBatch = 8;  // == ap.batch_mask + 1
     const long long generations = (cam_end + kW - 1) / kW;
     const long long max_rounds = (generations + 1) * (long long)(max_bounces + 2) + 64;
     long long rounds = 0;
@@ -1004,19 +1019,18 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
     int dev_cus = 0, occ_c = 0, occ_a = 0;
     HIP_TRY(hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, dev));
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_c, k_trace<MODE_POOL_CLOSEST>, kBlock, lds_bytes));
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_a, k_trace<MODE_QUEUE_ANY>, kBlock, lds_bytes));
-    const int resident = std::max(1, dev_cus * std::max(1, std::min(occ_c, occ_a)));
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_a, k_trace<MODE_POOL_ANY>, kBlock, lds_bytes));
+    int per_cu = std::max(1, std::min(occ_c, occ_a));
+    if (const char *e = getenv("RT_TRACE_BLOCKS_PER_CU")) per_cu = std::max(1, std::min(per_cu, atoi(e)));
+    const int resident = std::max(1, dev_cus * per_cu);
     const dim3 grid_trace(std::min(grid_for(n), resident));
     TraceParams tpc{};
     tpc.total = n;
-    tpc.head = &c.d_ctr->trace_head[0];
     TraceParams tpa{};
-    tpa.head = &c.d_ctr->trace_head[1];
+    tpa.total = n;
     tpa.fb = d_sum;
-    tpa.ctr = c.d_ctr;
     tpa.rows = c.d_rows;
     tpa.debug_no_deposit = (flags & 0x100u) ? 1 : 0;
-    ap.head_init = grid_trace.x * (unsigned)(kBlock / 64) * 64u;
     // RT_FLAG_TIME_KERNELS: every kTimeStride-th round is bracketed with HIP events on the launch
     // stream (no host synchronisation); the events are resolved after the loop.
     const int kTimeStride = 4;
@@ -1038,18 +1052,22 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
                 hipEvent_t e0, e1, e2, e3;
                 if (next_event(&e0) || next_event(&e1) || next_event(&e2) || next_event(&e3)) return 1;
                 HIP_TRY(hipEventRecord(e0, st));
-                hipLaunchKernelGGL(k_advance, grid, block, 0, st, sc, c.pools, cam, ap, d_sum, c.d_ctr, c.d_rows);
+                if (lds_tables)
+                    hipLaunchKernelGGL(k_advance<true>, grid, block, 0, st, sc, c.pools, cam, ap, d_sum, c.d_ctr, c.d_rows);
+                else
+                    hipLaunchKernelGGL(k_advance<false>, grid, block, 0, st, sc, c.pools, cam, ap, d_sum, c.d_ctr, c.d_rows);
                 HIP_TRY(hipEventRecord(e1, st));
-                hipLaunchKernelGGL(k_trace<MODE_POOL_CLOSEST>, grid_trace, block, lds_bytes, st, sc, c.pools, tpc);
+                hipLaunchKernelGGL(k_trace<MODE_POOL_CLOSEST>, grid_trace, block, lds_bytes, st, sc, c.pools, tpc, stack_depth);
                 HIP_TRY(hipEventRecord(e2, st));
-                tpa.round = ap.round;
-                hipLaunchKernelGGL(k_trace<MODE_QUEUE_ANY>, grid_trace, block, lds_bytes, st, sc, c.pools, tpa);
+                hipLaunchKernelGGL(k_trace<MODE_POOL_ANY>, grid_trace, block, lds_bytes, st, sc, c.pools, tpa, stack_depth);
                 HIP_TRY(hipEventRecord(e3, st));
             } else {
-                hipLaunchKernelGGL(k_advance, grid, block, 0, st, sc, c.pools, cam, ap, d_sum, c.d_ctr, c.d_rows);
-                hipLaunchKernelGGL(k_trace<MODE_POOL_CLOSEST>, grid_trace, block, lds_bytes, st, sc, c.pools, tpc);
-                tpa.round = ap.round;
-                hipLaunchKernelGGL(k_trace<MODE_QUEUE_ANY>, grid_trace, block, lds_bytes, st, sc, c.pools, tpa);
+                if (lds_tables)
+                    hipLaunchKernelGGL(k_advance<true>, grid, block, 0, st, sc, c.pools, cam, ap, d_sum, c.d_ctr, c.d_rows);
+                else
+                    hipLaunchKernelGGL(k_advance<false>, grid, block, 0, st, sc, c.pools, cam, ap, d_sum, c.d_ctr, c.d_rows);
+                hipLaunchKernelGGL(k_trace<MODE_POOL_CLOSEST>, grid_trace, block, lds_bytes, st, sc, c.pools, tpc, stack_depth);
+                hipLaunchKernelGGL(k_trace<MODE_POOL_ANY>, grid_trace, block, lds_bytes, st, sc, c.pools, tpa, stack_depth);
             }
             rounds++;
         }
@@ -1059,8 +1077,9 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
         if (batch >= 1) {
             int prev = (batch - 1) & 3;
             HIP_TRY(hipEventSynchronize(c.ev_ring[prev]));
-            // batch b covers rounds [b*kBatch, (b+1)*kBatch): nothing alive in any of them -> done
-            if ((long long)c.h_ctr[prev].last_live_round < (long long)(batch - 1) * kBatch) finished = true;
+            // k_advance records liveness only in the round that closes a batch (liveness is monotone):
+            // if the closing round of batch b-1 traced nothing, every slot is finished
+            if ((long long)c.h_ctr[prev].last_live_round < (long long)batch * kBatch - 1) finished = true;
         }
         batch++;
     }
@@ -1198,6 +1217,15 @@ int rt_scene_create(const float *tri_p0p1p2, int n_tris, const int32_t *tri_mate
     HIP_TRY(hipMemcpy(sc->d_lights, dl.data(), sizeof(Light) * dl.size(), hipMemcpyHostToDevice));
     HIP_TRY(hipMalloc((void **)&sc->d_order, sizeof(int) * std::max(n_tris, 1)));
     if (n_tris) HIP_TRY(hipMemcpy(sc->d_order, sc->h_order.data(), sizeof(int) * n_tris, hipMemcpyHostToDevice));
+    sc->tab_dwords = 5 * n_materials + 24 * n_lights;
+    HIP_TRY(hipMalloc((void **)&sc->d_tables, sizeof(float) * (size_t)std::max(sc->tab_dwords, 1)));
+    {
+        int nt = std::max(std::max(n_materials, n_lights), 1);
+        hipLaunchKernelGGL(k_build_tables, dim3((nt + 63) / 64), dim3(64), 0, nullptr, sc->d_mats, n_materials,
+                           sc->d_lights, n_lights, sc->d_tris, sc->d_tables);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipDeviceSynchronize());
+    }
     *out_scene = sc.release();
     return 0;
 }
@@ -1210,6 +1238,7 @@ void rt_scene_destroy(rt_scene *scene) {
     (void)hipFree(scene->d_mats);
     (void)hipFree(scene->d_lights);
     (void)hipFree(scene->d_order);
+    (void)hipFree(scene->d_tables);
     delete scene;
 }
 
@@ -1311,17 +1340,11 @@ int rt_trace_closest(const rt_scene *scene, int n, const float *origin_xyz, cons
     HIP_TRY(hipMemcpy(d_o, origin_xyz, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d_d, dir_xyz, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d_tm, tmax, sizeof(float) * (size_t)n, hipMemcpyHostToDevice));
-    unsigned *d_head = nullptr;
-    HIP_TRY(hipMalloc((void **)&d_head, sizeof(unsigned)));
     const int test_grid = std::min(grid_for(n), 2048);
-    {
-        unsigned h0 = (unsigned)test_grid * kBlock;
-        HIP_TRY(hipMemcpy(d_head, &h0, sizeof(unsigned), hipMemcpyHostToDevice));
-    }
+    const int stack_depth = std::max(1, scene->max_depth);
     {
         TraceParams tp{};
         tp.total = n;
-        tp.head = d_head;
         tp.o3 = d_o;
         tp.d3 = d_d;
         tp.tmax = d_tm;
@@ -1332,7 +1355,7 @@ int rt_trace_closest(const rt_scene *scene, int n, const float *origin_xyz, cons
         tp.out_v = d_v;
         DPools none{};
         hipLaunchKernelGGL(k_trace<MODE_TEST_CLOSEST>, dim3(test_grid), dim3(kBlock),
-                           sizeof(int) * kBlock * (size_t)std::max(1, scene->max_depth), nullptr, scene->dev(), none, tp);
+                           sizeof(int) * kBlock * (size_t)(stack_depth + 1), nullptr, scene->dev(), none, tp, stack_depth);
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(hit_tri, d_h, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost));
@@ -1340,7 +1363,7 @@ int rt_trace_closest(const rt_scene *scene, int n, const float *origin_xyz, cons
     HIP_TRY(hipMemcpy(u, d_u, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(v, d_v, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost));
     (void)hipFree(d_o); (void)hipFree(d_d); (void)hipFree(d_tm); (void)hipFree(d_t);
-    (void)hipFree(d_u); (void)hipFree(d_v); (void)hipFree(d_h); (void)hipFree(d_head);
+    (void)hipFree(d_u); (void)hipFree(d_v); (void)hipFree(d_h);
     return 0;
 }
 
@@ -1365,17 +1388,11 @@ int rt_trace_any(const rt_scene *scene, int n, const float *origin_xyz, const fl
     HIP_TRY(hipMemcpy(d_d, dir_xyz, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d_tm, tmax, sizeof(float) * (size_t)n, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d_e, excl.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice));
-    unsigned *d_head = nullptr;
-    HIP_TRY(hipMalloc((void **)&d_head, sizeof(unsigned)));
     const int test_grid = std::min(grid_for(n), 2048);
-    {
-        unsigned h0 = (unsigned)test_grid * kBlock;
-        HIP_TRY(hipMemcpy(d_head, &h0, sizeof(unsigned), hipMemcpyHostToDevice));
-    }
+    const int stack_depth = std::max(1, scene->max_depth);
     {
         TraceParams tp{};
         tp.total = n;
-        tp.head = d_head;
         tp.o3 = d_o;
         tp.d3 = d_d;
         tp.tmax = d_tm;
@@ -1383,12 +1400,12 @@ int rt_trace_any(const rt_scene *scene, int n, const float *origin_xyz, const fl
         tp.out_i = d_occ;
         DPools none{};
         hipLaunchKernelGGL(k_trace<MODE_TEST_ANY>, dim3(test_grid), dim3(kBlock),
-                           sizeof(int) * kBlock * (size_t)std::max(1, scene->max_depth), nullptr, scene->dev(), none, tp);
+                           sizeof(int) * kBlock * (size_t)(stack_depth + 1), nullptr, scene->dev(), none, tp, stack_depth);
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(occluded, d_occ, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost));
     (void)hipFree(d_o); (void)hipFree(d_d); (void)hipFree(d_tm); (void)hipFree(d_e); (void)hipFree(d_occ);
-    (void)hipFree(d_head);
+   
     return 0;
 }
 
