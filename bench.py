@@ -25,18 +25,24 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# algorithmic bytes of one closest-hit ray with the reference's record sizes:
-# 32 B ray in + 21 B hit out + 64 B per node PAIR visited + 72 B per triangle test
-# (24-B Primitive + 48-B Triangle).  NP / TT are the reference traversal's per-ray averages for the
-# workload; they are re-measured by the cpu_baseline leg (oracle statistics) when it runs and fall
-# back to SURVEY.md Appendix C's values for the named config otherwise.
-APPX_C = {"full_bsdf": (12.15, 4.09), "matte": (8.17, 3.32), "four_bunnies": (17.77, 4.84),
-          "sixteen_lights": (8.31, 3.34)}
+# algorithmic bytes of the trace stage with the reference's record sizes:
+#   closest-hit ray: 32 B ray in + 21 B hit out + 64 B per node PAIR visited + 72 B per triangle test
+#   any-hit ray:     40 B ray in + 28 B accumulate + 64 B per node pair + 72 B per triangle test
+# (72 B = 24-B Primitive + 48-B Triangle).  NP / TT are the REFERENCE traversal's per-ray averages
+# for the workload; they are re-measured by the cpu_baseline leg (oracle statistics) when it runs
+# and fall back to SURVEY.md Appendix C's values for the named config otherwise.
+APPX_C = {  # scene: (NPc, TTc, NPa, TTa)
+    "full_bsdf": (12.15, 4.09, 6.71, 5.83), "matte": (8.17, 3.32, 7.78, 6.10),
+    "four_bunnies": (17.77, 4.84, 12.69, 6.78), "sixteen_lights": (8.31, 3.34, 10.87, 6.14)}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
 def closest_ray_bytes(np_c: float, tt_c: float) -> float:
     return 53.0 + 64.0 * np_c + 72.0 * tt_c
+
+
+def any_ray_bytes(np_a: float, tt_a: float) -> float:
+    return 68.0 + 64.0 * np_a + 72.0 * tt_a
 
 
 def main():
@@ -102,7 +108,7 @@ def main():
         step()
     fence()
     t0 = time.perf_counter()
-    agg = {"seconds_closest": 0.0, "closest_rays": 0, "launches_closest": 0, "seconds_any": 0.0,
+    agg = {"seconds_trace": 0.0, "closest_rays": 0, "launches_trace": 0,
            "seconds_advance": 0.0, "seconds_render": 0.0, "any_rays": 0, "shade_events": 0}
     for _ in range(args.steps):
         step()
@@ -131,7 +137,7 @@ def main():
             "ms_per_frame": round(1e3 * elapsed / max(args.steps, 1), 3),
         }
         # ---- CPU baseline (rank 0, N = 1 only): the oracle on a bounded sample of the same workload
-        np_c, tt_c = APPX_C[args.scene]
+        np_c, tt_c, np_a, tt_a = APPX_C[args.scene]
         np_src = "SURVEY.md Appendix C"
         if world == 1 and not args.no_cpu_baseline:
             from oracle.oracle import Oracle
@@ -146,35 +152,39 @@ def main():
                 "sample": f"same scene and camera at {w}x{h}, {args.cpu_spp} spp ({w * h * args.cpu_spp} samples), "
                           f"render loop only ({ost['seconds_loop']:.1f} s; RNG init {ost['seconds_rng_init']:.2f} s "
                           f"reported apart), literal wavefront schedule, OpenMP over queue entries"}
-            if ost["ch_rays"] > 0:
+            if ost["ch_rays"] > 0 and ost["ah_rays"] > 0:
                 np_c = ost["ch_node_pairs"] / ost["ch_rays"]
                 tt_c = ost["ch_tri_tests"] / ost["ch_rays"]
+                np_a = ost["ah_node_pairs"] / ost["ah_rays"]
+                tt_a = ost["ah_tri_tests"] / ost["ah_rays"]
                 np_src = f"oracle statistics of the cpu_baseline sample ({args.cpu_spp} spp)"
         else:
             out["cpu_baseline"] = None
-        # ---- roofline of the dominant kernel
-        if agg["launches_closest"] > 0 and agg["seconds_closest"] > 0:
-            rays_per_launch = agg["closest_rays"] / agg["launches_closest"]
-            avg_s = agg["seconds_closest"] / agg["launches_closest"]
-            bytes_per_launch = closest_ray_bytes(np_c, tt_c) * rays_per_launch
+        # ---- roofline of the dominant kernel: k_trace<MODE_POOL> (closest-hit + any-hit rays, one launch/round)
+        if agg["launches_trace"] > 0 and agg["seconds_trace"] > 0:
+            launches = agg["launches_trace"]
+            c_per = agg["closest_rays"] / launches
+            a_per = agg["any_rays"] / launches
+            avg_s = agg["seconds_trace"] / launches
+            bytes_per_launch = closest_ray_bytes(np_c, tt_c) * c_per + any_ray_bytes(np_a, tt_a) * a_per
             achieved = bytes_per_launch / avg_s / 1e9
             out["roofline"] = {
-                "kernel": "k_trace_closest", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                "kernel": "k_trace<MODE_POOL>", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                "bytes_per_ray": round(closest_ray_bytes(np_c, tt_c), 1), "np_tt_source": np_src,
-                "rays_per_launch": round(rays_per_launch, 1), "avg_launch_us": round(avg_s * 1e6, 2),
-                "launches": agg["launches_closest"],
+                "bytes_per_closest_ray": round(closest_ray_bytes(np_c, tt_c), 1),
+                "bytes_per_any_ray": round(any_ray_bytes(np_a, tt_a), 1), "np_tt_source": np_src,
+                "closest_rays_per_launch": round(c_per, 1), "any_rays_per_launch": round(a_per, 1),
+                "avg_launch_us": round(avg_s * 1e6, 2), "launches": launches,
                 "stage_share_of_render": {
-                    "closest": round(agg["seconds_closest"] / max(agg["seconds_render"], 1e-12), 4),
-                    "any": round(agg["seconds_any"] / max(agg["seconds_render"], 1e-12), 4),
+                    "trace": round(agg["seconds_trace"] / max(agg["seconds_render"], 1e-12), 4),
                     "advance": round(agg["seconds_advance"] / max(agg["seconds_render"], 1e-12), 4)},
-                "grays_per_s_closest": round(agg["closest_rays"] / max(agg["seconds_closest"], 1e-12) / 1e9, 3)}
+                "grays_per_s": round((agg["closest_rays"] + agg["any_rays"]) / max(agg["seconds_trace"], 1e-12) / 1e9, 3)}
         else:
             out["roofline"] = None
         out["per_frame"] = {"closest_rays": agg["closest_rays"] // max(args.steps, 1),
                             "any_rays": agg["any_rays"] // max(args.steps, 1),
                             "shade_events": agg["shade_events"] // max(args.steps, 1),
-                            "rounds": agg["launches_closest"] // max(args.steps, 1),
+                            "rounds": agg["launches_trace"] // max(args.steps, 1),
                             "shard_note": "per-frame counts are rank 0's shard" if world > 1 else "whole frame"}
         if args.save_image:
             img = fb.view(h, w, 3).cpu().numpy()

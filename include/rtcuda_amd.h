@@ -69,11 +69,12 @@ typedef struct rt_stats {
     int64_t bvh_depth;
     double seconds_render;   /* device time of the render loop (HIP events), excl. RNG init */
     double seconds_rng_init; /* device time of the one-off XORWOW state initialisation */
-    double seconds_closest;  /* closest-hit kernel: average launch duration (HIP events on the launch
-                                stream, every 4th round sampled) x launches; 0 unless RT_FLAG_TIME_KERNELS */
-    double seconds_any;      /* same for the any-hit kernel */
+    double seconds_trace;    /* trace kernel (closest-hit + any-hit rays of a round in one launch): average
+                                launch duration (HIP events on the launch stream, every 4th round sampled)
+                                x launches; 0 unless RT_FLAG_TIME_KERNELS */
+    double seconds_unused;
     double seconds_advance;  /* same for the advance kernel */
-    int64_t launches_closest; /* launches of each stage kernel (= iterations) */
+    int64_t launches_trace;  /* launches of each stage kernel (= iterations) */
     int64_t reserved[7];     /* reserved[0] = rounds actually sampled by the event timer */
 } rt_stats;
 

@@ -525,13 +525,13 @@ constexpr int kEntryDone = (int)0x80000000;  // "nothing left to visit" marker f
 constexpr int kRefillAt = 40;                // finalise + refill once <= this many lanes still traverse
 __device__ __forceinline__ int leaf_ref(int first, int count) { return ~((first << 3) | count); }
 
-enum { MODE_POOL_CLOSEST = 0, MODE_POOL_ANY = 1, MODE_TEST_CLOSEST = 2, MODE_TEST_ANY = 3 };
+enum { MODE_POOL = 0, MODE_TEST_CLOSEST = 2, MODE_TEST_ANY = 3 };
 
 struct TraceParams {
-    int total;             // number of candidate ray indices (slots, or test rays)
+    int total;             // number of slots (MODE_POOL) or test rays
     int debug_no_deposit;  // perf experiments only: skip the framebuffer atomics
-    float *fb;             // MODE_POOL_ANY
-    DWaveRow *rows;        // MODE_POOL_ANY
+    float *fb;             // MODE_POOL: raw-sum framebuffer
+    DWaveRow *rows;        // MODE_POOL: counter rows
     // test modes
     const float *o3, *d3, *tmax;
     const int *order, *excluded;
@@ -539,92 +539,101 @@ struct TraceParams {
     float *out_t, *out_u, *out_v;
 };
 
-// LDS layout of the trace kernels (dynamic): [stack: depth x kBlock ints][pending: kBlock ints]
+// MODE_POOL traces BOTH ray kinds of a round in one launch: the path ray of every live slot
+// (closest hit, ch()) and the shadow ray of every slot that spawned one (any hit, ah()).  A lane
+// carries its kind with its ray, so closest-hit and any-hit rays share waves; the two kinds differ
+// only in what a triangle hit does and in how the finished ray is finalised.
+// LDS layout (dynamic): [stack: depth x kBlock ints][pending: kBlock ints]
 template <int MODE>
 __global__ void __launch_bounds__(kBlock, 8) k_trace(DScene sc, DPools p, TraceParams tp, int stack_depth) {
     extern __shared__ int s_lds[];
-    constexpr bool ANY = (MODE == MODE_POOL_ANY || MODE == MODE_TEST_ANY);
     int *stack = s_lds + threadIdx.x;
     volatile int *pend = s_lds + stack_depth * kBlock + (threadIdx.x & ~63);  // this wave's 64 entries
     const int total = tp.total;
-    const int n_chunks = (total + 63) >> 6;
+    const int n_chunks = (total + 63) >> 6;                            // chunks per ray kind
+    const int all_chunks = MODE == MODE_POOL ? 2 * n_chunks : n_chunks;  // [closest chunks][any chunks]
     const unsigned lane = lane_id();
+    constexpr int kAnyBit = 1 << 30;  // ray id = slot | kAnyBit for shadow rays
 
-    // wave-uniform work bookkeeping.  Candidates come in chunks of 64 consecutive indices, dealt
+    // wave-uniform work bookkeeping.  Candidates come in chunks of 64 consecutive slots, dealt
     // round-robin over the waves of the grid (chunk = wave id + k * waves): no shared head counter
     // -- a same-address atomic costs ~5 ns on this chip and 16k of them per launch formed a convoy.
     // The valid candidates of a chunk (live slots / slots that spawned a shadow ray this round) are
     // compacted into `pend` with ballot + mbcnt and handed to idle lanes from there, so the ray
-    // queue of the reference (flag arrays + cub::DeviceSelect, render.cuh:431-443) exists only as
+    // queues of the reference (flag arrays + cub::DeviceSelect, render.cuh:431-443) exist only as
     // 64 ints of LDS per wave.
     int pend_lo = 0, pend_hi = 0;
     int next_chunk = (int)wave_index();
     const int grid_waves = (int)(gridDim.x * (kBlock / 64));
     bool exhausted = false;
-    // per-lane ray state
-    int idx = -1, cur = kEntryDone, sp = 0, best = -1, excluded = -1;
+    // per-lane ray state.  `tri` is the best hit so far (closest) or the excluded triangle (any);
+    // `hu` doubles as the occluded flag of an any-hit ray.
+    int id = -1, cur = kEntryDone, sp = 0, tri = -1;
     V3 o = mk(0, 0, 0), d = mk(0, 0, 0), inv = mk(0, 0, 0);
     float tmax = 0.f, hu = 0.f, hv = 0.f;
-    bool occluded = false;
     unsigned long long deposits = 0;
 
     while (true) {
-        unsigned long long act = __ballot(idx >= 0 && cur != kEntryDone);
+        unsigned long long act = __ballot(id >= 0 && cur != kEntryDone);
         if (__popcll(act) <= kRefillAt) {
             // ---- finalise finished lanes
-            if (MODE == MODE_POOL_ANY) deposits += __popcll(__ballot(idx >= 0 && cur == kEntryDone && !occluded));
-            if (idx >= 0 && cur == kEntryDone) {
-                if (MODE == MODE_POOL_CLOSEST) {
-                    // hit record in the form mat() consumes (render.cuh:152-153)
-                    int info = -1;
-                    if (best >= 0) {
-                        Tri tr = load_tri(sc.tris, best);
-                        int2 ml = sc.tri_info[best];
-                        V3 hp = tri_point(tr, hu, hv);
-                        V3 hn = neg(unit(tr.n));
-                        p.hpx[idx] = hp.x;
-                        p.hpy[idx] = hp.y;
-                        p.hpz[idx] = hp.z;
-                        p.hnx[idx] = hn.x;
-                        p.hny[idx] = hn.y;
-                        p.hnz[idx] = hn.z;
-                        info = (ml.x & 0xffff) | ((ml.y + 1) << 16);
-                    }
-                    p.hit_info[idx] = info;
-                } else if (MODE == MODE_POOL_ANY) {
-                    if (!occluded && !tp.debug_no_deposit) {  // render.cuh:291-293
-                        int pixel = p.pixel[idx];
-                        atomicAdd(&tp.fb[3 * (size_t)pixel + 0], p.slr[idx]);
-                        atomicAdd(&tp.fb[3 * (size_t)pixel + 1], p.slg[idx]);
-                        atomicAdd(&tp.fb[3 * (size_t)pixel + 2], p.slb[idx]);
+            const bool fin = id >= 0 && cur == kEntryDone;
+            const bool is_any = MODE == MODE_POOL ? (id & kAnyBit) != 0 : MODE == MODE_TEST_ANY;
+            if (MODE == MODE_POOL) deposits += __popcll(__ballot(fin && is_any && hu == 0.f));
+            if (fin) {
+                const int slot = id & (kAnyBit - 1);
+                if (MODE == MODE_POOL) {
+                    if (!is_any) {
+                        // hit record in the form mat() consumes (render.cuh:152-153, 311-316)
+                        int info = -1;
+                        if (tri >= 0) {
+                            Tri tr = load_tri(sc.tris, tri);
+                            int2 ml = sc.tri_info[tri];
+                            V3 hp = tri_point(tr, hu, hv);
+                            V3 hn = neg(unit(tr.n));
+                            p.hpx[slot] = hp.x;
+                            p.hpy[slot] = hp.y;
+                            p.hpz[slot] = hp.z;
+                            p.hnx[slot] = hn.x;
+                            p.hny[slot] = hn.y;
+                            p.hnz[slot] = hn.z;
+                            info = (ml.x & 0xffff) | ((ml.y + 1) << 16);
+                        }
+                        p.hit_info[slot] = info;
+                    } else if (hu == 0.f && !tp.debug_no_deposit) {  // unoccluded: render.cuh:291-293
+                        int pixel = p.pixel[slot];
+                        atomicAdd(&tp.fb[3 * (size_t)pixel + 0], p.slr[slot]);
+                        atomicAdd(&tp.fb[3 * (size_t)pixel + 1], p.slg[slot]);
+                        atomicAdd(&tp.fb[3 * (size_t)pixel + 2], p.slb[slot]);
                     }
                 } else if (MODE == MODE_TEST_CLOSEST) {
-                    tp.out_i[idx] = best >= 0 ? tp.order[best] : -1;
-                    tp.out_t[idx] = best >= 0 ? tmax : 0.f;
-                    tp.out_u[idx] = hu;
-                    tp.out_v[idx] = hv;
+                    tp.out_i[slot] = tri >= 0 ? tp.order[tri] : -1;
+                    tp.out_t[slot] = tri >= 0 ? tmax : 0.f;
+                    tp.out_u[slot] = hu;
+                    tp.out_v[slot] = hv;
                 } else {
-                    tp.out_i[idx] = occluded ? 1 : 0;
+                    tp.out_i[slot] = hu != 0.f ? 1 : 0;
                 }
-                idx = -1;
+                id = -1;
             }
             // ---- refill idle lanes (up to three chunks per refill: shadow rays are sparse)
             for (int tries = 0; tries < 3; tries++) {
-                unsigned long long idle = __ballot(idx < 0);
+                unsigned long long idle = __ballot(id < 0);
                 int n_idle = __popcll(idle);
                 if (n_idle == 0) break;
                 if (pend_lo == pend_hi && !exhausted) {
                     int chunk = next_chunk;
                     next_chunk += grid_waves;
-                    if (chunk >= n_chunks) {
+                    if (chunk >= all_chunks) {
                         exhausted = true;
                     } else {
-                        int cand = chunk * 64 + (int)lane;
+                        const bool any_chunk = MODE == MODE_POOL && chunk >= n_chunks;
+                        int cand = (any_chunk ? chunk - n_chunks : chunk) * 64 + (int)lane;
                         bool valid = cand < total;
-                        if (valid && MODE == MODE_POOL_CLOSEST) valid = p.bounces[cand] != kDone;
-                        if (valid && MODE == MODE_POOL_ANY) valid = p.stmax[cand] >= 0.f;
+                        if (MODE == MODE_POOL && valid)
+                            valid = any_chunk ? p.stmax[cand] >= 0.f : p.bounces[cand] != kDone;
                         unsigned long long vm = __ballot(valid);
-                        if (valid) pend[prefix_popc(vm)] = cand;
+                        if (valid) pend[prefix_popc(vm)] = any_chunk ? (cand | kAnyBit) : cand;
                         pend_lo = 0;
                         pend_hi = __popcll(vm);
                     }
@@ -632,36 +641,39 @@ __global__ void __launch_bounds__(kBlock, 8) k_trace(DScene sc, DPools p, TraceP
                 int avail = pend_hi - pend_lo;
                 if (avail > 0) {
                     int r = (int)prefix_popc(idle);
-                    if (idx < 0 && r < avail) {
+                    if (id < 0 && r < avail) {
                         int my = pend[pend_lo + r];
-                        if (MODE == MODE_POOL_CLOSEST) {
-                            o = mk(p.ox[my], p.oy[my], p.oz[my]);
-                            d = mk(p.dx[my], p.dy[my], p.dz[my]);
-                            tmax = kFltMax;
-                        } else if (MODE == MODE_POOL_ANY) {
-                            o = mk(p.sox[my], p.soy[my], p.soz[my]);
-                            d = mk(p.sdx[my], p.sdy[my], p.sdz[my]);
-                            tmax = p.stmax[my];
-                            excluded = p.starget[my];
+                        int slot = my & (kAnyBit - 1);
+                        if (MODE == MODE_POOL) {
+                            if (my & kAnyBit) {
+                                o = mk(p.sox[slot], p.soy[slot], p.soz[slot]);
+                                d = mk(p.sdx[slot], p.sdy[slot], p.sdz[slot]);
+                                tmax = p.stmax[slot];
+                                tri = p.starget[slot];
+                            } else {
+                                o = mk(p.ox[slot], p.oy[slot], p.oz[slot]);
+                                d = mk(p.dx[slot], p.dy[slot], p.dz[slot]);
+                                tmax = kFltMax;
+                                tri = -1;
+                            }
                         } else {
-                            o = mk(tp.o3[3 * my], tp.o3[3 * my + 1], tp.o3[3 * my + 2]);
-                            d = mk(tp.d3[3 * my], tp.d3[3 * my + 1], tp.d3[3 * my + 2]);
-                            tmax = tp.tmax[my];
-                            if (MODE == MODE_TEST_ANY) excluded = tp.excluded[my];
+                            o = mk(tp.o3[3 * slot], tp.o3[3 * slot + 1], tp.o3[3 * slot + 2]);
+                            d = mk(tp.d3[3 * slot], tp.d3[3 * slot + 1], tp.d3[3 * slot + 2]);
+                            tmax = tp.tmax[slot];
+                            tri = MODE == MODE_TEST_ANY ? tp.excluded[slot] : -1;
                         }
-                        idx = my;
+                        id = my;
                         inv = inv_dir(d);
                         cur = 0;  // root pair
                         sp = 0;
-                        best = -1;
-                        occluded = false;
+                        hu = 0.f;
                     }
                     pend_lo += min(avail, n_idle);
                 } else if (exhausted) {
                     break;
                 }
             }
-            act = __ballot(idx >= 0 && cur != kEntryDone);
+            act = __ballot(id >= 0 && cur != kEntryDone);
             if (act == 0) {
                 if (exhausted && pend_lo == pend_hi) break;  // nothing in flight, nothing pending, no chunks left
                 continue;
@@ -701,26 +713,29 @@ __global__ void __launch_bounds__(kBlock, 8) k_trace(DScene sc, DPools p, TraceP
         }
         // ---- leaf phase: every lane that holds a leaf tests its triangles (triangle.cuh:39-58)
         if (cur != kEntryDone && cur < 0) {
+            const bool is_any = MODE == MODE_POOL ? (id & kAnyBit) != 0 : MODE == MODE_TEST_ANY;
             int ref = ~cur;
             int first = ref >> 3, count = ref & 7;
+            bool stop = false;
             for (int k = first; k < first + count; k++) {
                 Tri tr = load_tri(sc.tris, k);
                 float t, u, v;
                 if (tri_intersect(tr, o, d, tmax, t, u, v)) {
-                    if (ANY) {
-                        if (k != excluded) {  // bvh.cuh:243: first accepted hit that is not the excluded triangle
-                            occluded = true;
+                    if (is_any) {
+                        if (k != tri) {  // bvh.cuh:243: first accepted hit that is not the excluded triangle
+                            hu = 1.f;    // occluded
+                            stop = true;
                             break;
                         }
                     } else {  // bvh.cuh:227-231: later equal-t hit wins (t <= tmax)
                         tmax = t;
                         hu = u;
                         hv = v;
-                        best = k;
+                        tri = k;
                     }
                 }
             }
-            if (ANY && occluded) {
+            if (stop) {
                 cur = kEntryDone;
             } else if (sp > 0) {
                 sp--;
@@ -730,7 +745,7 @@ __global__ void __launch_bounds__(kBlock, 8) k_trace(DScene sc, DPools p, TraceP
             }
         }
     }
-    if (MODE == MODE_POOL_ANY) {
+    if (MODE == MODE_POOL) {
         if (deposits != 0 && lane == 0) atomicAdd(&tp.rows[wave_index()].c[C_SHADOW_ADD], deposits);
     }
 }
@@ -1016,21 +1031,18 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
     const dim3 grid(grid_for(n)), block(kBlock);
     // persistent trace kernels: as many workgroups as the chip keeps resident (never more than the
     // advance grid, whose wave count sizes the counter rows)
-    int dev_cus = 0, occ_c = 0, occ_a = 0;
+    int dev_cus = 0, occ_c = 0;
     HIP_TRY(hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, dev));
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_c, k_trace<MODE_POOL_CLOSEST>, kBlock, lds_bytes));
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_a, k_trace<MODE_POOL_ANY>, kBlock, lds_bytes));
-    int per_cu = std::max(1, std::min(occ_c, occ_a));
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_c, k_trace<MODE_POOL>, kBlock, lds_bytes));
+    int per_cu = std::max(1, occ_c);
     if (const char *e = getenv("RT_TRACE_BLOCKS_PER_CU")) per_cu = std::max(1, std::min(per_cu, atoi(e)));
     const int resident = std::max(1, dev_cus * per_cu);
     const dim3 grid_trace(std::min(grid_for(n), resident));
-    TraceParams tpc{};
-    tpc.total = n;
-    TraceParams tpa{};
-    tpa.total = n;
-    tpa.fb = d_sum;
-    tpa.rows = c.d_rows;
-    tpa.debug_no_deposit = (flags & 0x100u) ? 1 : 0;
+    TraceParams tpp{};
+    tpp.total = n;
+    tpp.fb = d_sum;
+    tpp.rows = c.d_rows;
+    tpp.debug_no_deposit = (flags & 0x100u) ? 1 : 0;
     // RT_FLAG_TIME_KERNELS: every kTimeStride-th round is bracketed with HIP events on the launch
     // stream (no host synchronisation); the events are resolved after the loop.
     const int kTimeStride = 4;
@@ -1057,17 +1069,15 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
                 else
                     hipLaunchKernelGGL(k_advance<false>, grid, block, 0, st, sc, c.pools, cam, ap, d_sum, c.d_ctr, c.d_rows);
                 HIP_TRY(hipEventRecord(e1, st));
-                hipLaunchKernelGGL(k_trace<MODE_POOL_CLOSEST>, grid_trace, block, lds_bytes, st, sc, c.pools, tpc, stack_depth);
+                hipLaunchKernelGGL(k_trace<MODE_POOL>, grid_trace, block, lds_bytes, st, sc, c.pools, tpp, stack_depth);
                 HIP_TRY(hipEventRecord(e2, st));
-                hipLaunchKernelGGL(k_trace<MODE_POOL_ANY>, grid_trace, block, lds_bytes, st, sc, c.pools, tpa, stack_depth);
                 HIP_TRY(hipEventRecord(e3, st));
             } else {
                 if (lds_tables)
                     hipLaunchKernelGGL(k_advance<true>, grid, block, 0, st, sc, c.pools, cam, ap, d_sum, c.d_ctr, c.d_rows);
                 else
                     hipLaunchKernelGGL(k_advance<false>, grid, block, 0, st, sc, c.pools, cam, ap, d_sum, c.d_ctr, c.d_rows);
-                hipLaunchKernelGGL(k_trace<MODE_POOL_CLOSEST>, grid_trace, block, lds_bytes, st, sc, c.pools, tpc, stack_depth);
-                hipLaunchKernelGGL(k_trace<MODE_POOL_ANY>, grid_trace, block, lds_bytes, st, sc, c.pools, tpa, stack_depth);
+                hipLaunchKernelGGL(k_trace<MODE_POOL>, grid_trace, block, lds_bytes, st, sc, c.pools, tpp, stack_depth);
             }
             rounds++;
         }
@@ -1122,10 +1132,11 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
         stats->seconds_rng_init = rng_seconds;
         // sampled every kTimeStride-th round; scaled to all rounds (average launch duration x launches)
         double scale_up = n_sampled > 0 ? (double)rounds / (double)n_sampled : 0.0;
-        stats->seconds_closest = t_ch * 1e-3 * scale_up;
-        stats->seconds_any = t_ah * 1e-3 * scale_up;
+        stats->seconds_trace = t_ch * 1e-3 * scale_up;
+        stats->seconds_unused = 0.0;
+        (void)t_ah;
         stats->seconds_advance = t_adv * 1e-3 * scale_up;
-        stats->launches_closest = rounds;
+        stats->launches_trace = rounds;
         stats->reserved[0] = n_sampled;
     }
     return 0;
