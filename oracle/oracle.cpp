@@ -670,14 +670,14 @@ float power_heuristic(float f_pdf, float g_pdf_float) {
 }
 inline bool same_hemisphere(V3 wo, V3 wi, V3 n) { return dot(wo, n) * dot(wi, n) < 0.f; }  // :58-60
 
-inline void orc_sincosf(float x, float *s, float *c) {
+inline void sincos_impl(float x, float *s, float *c) {
 #ifdef ORC_LIBM
     sincosf(x, s, c);
 #else
     rt_sincosf(x, s, c);
 #endif
 }
-inline float orc_pow5(float x) {
+inline float pow5_impl(float x) {
 #ifdef ORC_LIBM
     return powf(x, 5);
 #else
@@ -691,7 +691,7 @@ V3 uniform_sample_sphere(Xorwow &rs) {
     float r = sqrtf(1 - z * z);
     float phi = kTwoPi * rnd(rs);
     float x, y;
-    orc_sincosf(phi, &y, &x);
+    sincos_impl(phi, &y, &x);
     return mk(r * x, r * y, z);
 }
 
@@ -736,7 +736,7 @@ V3 mat_sample_f(const Material &m, V3 wo, Xorwow &rs, V3 &n, V3 &wi, float &pdf)
         }
         float r0 = (1 - m.ior) / (1 + m.ior);
         r0 = r0 * r0;
-        float reflectance = r0 + (1 - r0) * orc_pow5(1 - cos_theta);
+        float reflectance = r0 + (1 - r0) * pow5_impl(1 - cos_theta);
         if (rnd(rs) < reflectance) {
             if (!front) n = neg(n);
             wi = reflect(wo, n);
@@ -1272,8 +1272,8 @@ int orc_triangle_intersect(const float *p9, const float *o, const float *d, floa
     tuv[2] = is.v;
     return h ? 1 : 0;
 }
-void orc_sincos(float x, float *s, float *c) { orc_sincosf(x, s, c); }
-float orc_pow5(float x) { return ::orc_pow5(x); }
+void orc_sincos(float x, float *s, float *c) { sincos_impl(x, s, c); }
+float orc_pow5(float x) { return pow5_impl(x); }
 // sample_f on a batch: returns f(3) wi(3) n(3) pdf, advances the rng state
 void orc_sample_f(const orc_material *m, const float *wo, const float *n_in, uint32_t *state6, float *out10) {
     Material mm{mk(m->albedo[0], m->albedo[1], m->albedo[2]), m->ior, m->type};

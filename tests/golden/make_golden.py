@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Regenerates tests/golden/render_goldens.npz from the CPU oracle (pinned-math flavour).
+
+The reference cannot be run here (it needs nvcc + cuRAND + CUB), so these vectors are outputs of the
+oracle -- whose own pins are the SURVEY.md Appendix C values in appendix_c.json.  Each entry: the
+post-processed image, the raw per-pixel sums and the integer event totals of one small render
+(scene recipe from rtcuda_amd/scenes.py, camera of main.cu:162-166, max_bounces 10, seed 1).
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle.oracle import Oracle, build  # noqa: E402
+from rtcuda_amd import scenes  # noqa: E402
+
+CASES = [("matte", 32, 32, 16), ("full_bsdf", 48, 27, 8), ("sixteen_lights", 40, 30, 4), ("matte", 1, 1, 3),
+         ("full_bsdf", 7, 5, 1)]
+
+
+def main():
+    build()
+    orc = Oracle("pinned")
+    out = {}
+    for variant, w, h, spp in CASES:
+        arrays = scenes.cornell_bunny(variant)
+        cam = orc.camera((0.5, 0.5, 1.5), (0.5, 0.5, 0.0), (0.0, 1.0, 0.0), 37.8, w / h)
+        img, raw, st = orc.scene(arrays).render(cam, w, h, spp, threads=8)
+        key = f"{variant}_{w}x{h}x{spp}"
+        out[key + "_img"] = img
+        out[key + "_sum"] = raw
+        out[key + "_counts"] = np.array([st["sum_mat"], st["sum_ah"], st["emission_adds"], st["ah_adds"],
+                                         st["rr_draws"], w * h * spp], np.int64)
+        print(key, out[key + "_counts"].tolist(), img.reshape(-1, 3).mean(0))
+    np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "render_goldens.npz"), **out)
+
+
+if __name__ == "__main__":
+    main()

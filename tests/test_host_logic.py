@@ -1,0 +1,203 @@
+"""CPU tests of the host side: C-ABI surface, scene recipes, PLY ingest, BVH builder, sharding."""
+import ctypes
+import os
+import re
+import struct
+
+import numpy as np
+import pytest
+
+import raygen
+from conftest import ROOT, default_camera
+from rtcuda_amd import dist as rtdist
+from rtcuda_amd import scenes
+
+with open(os.path.join(ROOT, "tests", "golden", "appendix_c.json")) as _fh:
+    import json
+    APPX = json.load(_fh)
+
+
+# ----------------------------------------------------------------------------- C-ABI surface
+def _declared_functions():
+    text = open(os.path.join(ROOT, "include", "rtcuda_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rt_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    """The C-ABI library loads on a machine without a GPU and exports exactly what the header declares."""
+    from rtcuda_amd import api
+    api.build()
+    declared = _declared_functions()
+    assert set(declared) == set(api.EXPORTS), (declared, api.EXPORTS)
+    L = api.lib()
+    for name in declared:
+        assert hasattr(L, name), name
+    assert b"gfx950" in L.rt_version()
+
+
+def test_struct_layouts_match_the_header():
+    from rtcuda_amd import api
+    assert scenes.MATERIAL_DTYPE.itemsize == 20   # rt_material / material.cuh:20-22
+    assert scenes.LIGHT_DTYPE.itemsize == 32      # rt_light
+    assert ctypes.sizeof(api.RtStats) == 8 * 10 + 8 * 5 + 8 + 8 * 7
+
+
+def test_camera_make_needs_no_gpu(oracle):
+    from rtcuda_amd import api
+    for aspect in (1.0, 16 / 9, 0.75):
+        assert np.array_equal(api.make_camera(aspect=aspect).view(np.uint32),
+                              default_camera(oracle, aspect).view(np.uint32))
+
+
+def test_compute_calls_fail_loudly_without_a_gpu(bunny_matte):
+    """No CPU fallback: without a device the product raises instead of computing somewhere else."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from rtcuda_amd import api
+    with pytest.raises(api.RtError):
+        api.Scene(bunny_matte)
+
+
+# ----------------------------------------------------------------------------- scene recipes
+def test_bunny_transform_matches_known_rows():
+    m = scenes.bunny_transform()
+    for got, ref in zip(m[:3], APPX["bunny_transform_rows"]):
+        assert np.allclose(got, ref, rtol=0, atol=5e-9)
+    assert np.array_equal(m[3], np.array([0, 0, 0, 1], np.float32))
+
+
+def test_cornell_bunny_arrays(bunny_matte):
+    a = bunny_matte
+    assert a.n_tris == 69463 and a.tris.dtype == np.float32 and a.tris.shape == (69463, 9)
+    assert (a.tri_material[:69451] == 3).all()                      # brown bunny (main.cu:83)
+    assert a.tri_material[69451:69461].tolist() == [0, 0, 1, 1, 2, 2, 2, 2, 2, 2]
+    # light order of the reference's unordered_map iteration: [69462, 69461]
+    assert a.lights["tri"].tolist() == [69462, 69461]
+    assert a.tri_light[69462] == 0 and a.tri_light[69461] == 1 and (a.tri_light[:69461] == -1).all()
+    assert np.allclose(a.lights["L"], 15.0)
+    lo, hi = a.tris.reshape(-1, 3).min(0), a.tris.reshape(-1, 3).max(0)
+    assert np.array_equal(lo, [0, 0, -1]) and np.array_equal(hi, [1, 1, 0])  # "Global bounding box"
+    bun = a.tris[:69451].reshape(-1, 3)
+    assert np.allclose(bun.min(0), [0.300, 0.0, -0.741], atol=2e-3) and np.allclose(bun.max(0), [0.611, 0.309, -0.500], atol=2e-3)
+
+
+def test_scene_variants():
+    full = scenes.cornell_bunny("full_bsdf")
+    assert (full.tri_material[:69451] == 4).all() and full.materials[4]["type"] == scenes.GLASS
+    assert full.tri_material[69459:69461].tolist() == [5, 5] and full.materials[5]["type"] == scenes.MIRROR
+    four = scenes.cornell_bunny("four_bunnies")
+    assert four.n_tris == 4 * 69451 + 12 == 277816
+    sixteen = scenes.cornell_bunny("sixteen_lights")
+    assert sixteen.n_tris == 69477 and len(sixteen.lights) == 16
+    assert sixteen.lights["tri"].tolist() == list(range(69461, 69477))  # ascending triangle index
+    box = scenes.cornell_bunny("matte", bunny=False)
+    assert box.n_tris == 12 and box.lights["tri"].tolist() == [11, 10]
+    with pytest.raises(ValueError):
+        scenes.cornell_bunny("nope")
+
+
+def test_ply_reader_ascii_and_binary(tmp_path):
+    pos, faces = scenes.load_ply()
+    assert pos.shape == (35947, 3) and faces.shape == (69451, 3) and faces.max() == 35946
+    assert np.array_equal(pos[0], np.array([-0.0378297, 0.12794, 0.00447467], np.float32))
+    # the same mesh as binary_little_endian with a different property order and an extra element
+    path = tmp_path / "tiny.ply"
+    v = pos[:5]
+    f = np.array([[0, 1, 2], [2, 3, 4]], np.int32)
+    with open(path, "wb") as fh:
+        fh.write(b"ply\nformat binary_little_endian 1.0\nelement vertex 5\nproperty float z\nproperty float x\n"
+                 b"property float y\nproperty uchar flag\nelement face 2\nproperty list uchar int vertex_indices\nend_header\n")
+        for p in v:
+            fh.write(struct.pack("<fffB", p[2], p[0], p[1], 7))
+        for t in f:
+            fh.write(struct.pack("<Biii", 3, *t))
+    p2, f2 = scenes.load_ply(str(path))
+    assert np.array_equal(p2, v) and np.array_equal(f2, f)
+    bad = tmp_path / "quad.ply"
+    bad.write_text("ply\nformat ascii 1.0\nelement vertex 4\nproperty float x\nproperty float y\nproperty float z\n"
+                   "element face 1\nproperty list uchar int vertex_indices\nend_header\n0 0 0\n1 0 0\n1 1 0\n0 1 0\n4 0 1 2 3\n")
+    with pytest.raises(ValueError):
+        scenes.load_ply(str(bad))
+
+
+def test_ppm_quantisation(tmp_path):
+    img = np.array([[[0.0, 0.5, 1.0], [2.0, -1.0, 0.999]]], np.float32)
+    path = tmp_path / "o.ppm"
+    scenes.write_ppm(str(path), img)
+    lines = path.read_text().split("\n")
+    assert lines[:3] == ["P3", "2 1", "255"]
+    assert lines[3] == "0 128 255" and lines[4] == "255 0 255"   # clamp(int(256 c), 0, 255), main.cu:186-188
+
+
+# ----------------------------------------------------------------------------- BVH builder (host, no GPU)
+def _hostcheck():
+    from rtcuda_amd import api
+    api.build()
+    L = ctypes.CDLL(os.path.join(os.path.dirname(api.LIB_PATH), "librt_hostcheck.so"))
+    L.rt_bvh_selfcheck.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                   ctypes.c_void_p]
+    return L
+
+
+def _selfcheck(L, tris, ro, rd):
+    out = np.zeros(8, np.int64)
+    tris = np.ascontiguousarray(tris, np.float32)
+    ro = np.ascontiguousarray(ro, np.float32)
+    rd = np.ascontiguousarray(rd, np.float32)
+    L.rt_bvh_selfcheck(tris.ctypes.data, tris.shape[0], ro.shape[0], ro.ctypes.data if len(ro) else None,
+                       rd.ctypes.data if len(rd) else None, out.ctypes.data)
+    return dict(zip(["pairs", "leaves", "depth", "maxleaf", "errors", "mismatch", "maxstack", "maxsteps"], out.tolist()))
+
+
+def test_product_bvh_structure_and_cpu_walk(oracle, bunny_matte):
+    L = _hostcheck()
+    cam = default_camera(oracle, 16 / 9)
+    ro, rd = raygen.camera_rays(cam, 1920, 1080, 600, seed=3)
+    ao, ad = raygen.axis_aligned_rays(300, seed=4)
+    r = _selfcheck(L, bunny_matte.tris, np.concatenate([ro, ao]), np.concatenate([rd, ad]))
+    assert r["errors"] == 0 and r["mismatch"] == 0
+    assert r["depth"] <= 40 and r["maxleaf"] <= 4 and r["maxstack"] < r["depth"]
+    assert r["pairs"] + 1 == r["leaves"]  # binary tree: internal pairs + 1 leaves
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 5, 64])
+def test_product_bvh_tiny_and_degenerate(n):
+    L = _hostcheck()
+    rng = np.random.default_rng(n)
+    tris = rng.uniform(0, 1, (max(n, 1), 9)).astype(np.float32)[:n]
+    ro = rng.uniform(-1, 2, (200, 3)).astype(np.float32)
+    rd = rng.normal(size=(200, 3))
+    rd = (rd / np.linalg.norm(rd, axis=1, keepdims=True)).astype(np.float32)
+    r = _selfcheck(L, tris.reshape(-1, 9), ro, rd)
+    assert r["errors"] == 0 and r["mismatch"] == 0
+    # coincident triangles (SAH finds no plane): must still terminate with bounded leaves
+    if n >= 5:
+        same = np.repeat(tris[:1], n, axis=0)
+        r = _selfcheck(L, same, ro, rd)
+        assert r["errors"] == 0 and r["mismatch"] == 0 and r["maxleaf"] <= 4
+
+
+# ----------------------------------------------------------------------------- sharding
+def test_shard_ranges_partition_the_slots():
+    W = rtdist.W
+    for world in (1, 2, 4, 8, 64):
+        ranges = [rtdist.shard_range(r, world) for r in range(world)]
+        assert ranges[0][0] == 0 and ranges[-1][1] == W
+        assert all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+    with pytest.raises(ValueError):
+        rtdist.shard_range(0, 3)
+    with pytest.raises(ValueError):
+        rtdist.shard_range(8, 8)
+
+
+def test_camera_ray_ownership_is_a_round_robin_of_pixel_strips():
+    W, spp, world = rtdist.W, 256, 8
+    # all samples of a pixel go to one rank, consecutive 512-pixel strips cycle over the ranks
+    per_rank_pixels = W // world // spp
+    assert per_rank_pixels == 512
+    for pixel in (0, 511, 512, 4095, 4096, 2073599):
+        owners = {rtdist.owner_of_camera_ray(pixel * spp + s, world) for s in (0, 1, spp - 1)}
+        assert len(owners) == 1
+        assert owners.pop() == (pixel // per_rank_pixels) % world
