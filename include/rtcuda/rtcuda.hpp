@@ -1,0 +1,193 @@
+// rtcuda.hpp -- the reference's host API for the render path, on top of the C-ABI (rtcuda_amd.h).
+//
+// Same names, constructor signatures and call sequence as lashhw/rtcuda's headers, so its driver
+// (main.cu:41-173) compiles against this file with the CUDA allocation calls deleted:
+//
+//   Vec3                                  vec3.cuh:4-30        (host subset: what the driver touches)
+//   Triangle(p0, p1, p2)                  triangle.cuh:6-7
+//   Material::make_matte/mirror/glass     material.cuh:25-44
+//   Light::make_point_light/area_light    light.cuh:70-84
+//   Primitive(tri*, mat*, light* = NULL)  primitive.cuh:6-7
+//   Bvh(triangles, primitives)            bvh.cuh:17,30        (asserts equal sizes, :33)
+//   Scene{bvh, num_lights, d_lights}      scene.cuh:4-8
+//   Camera(lookfrom, lookat, up, vfov, aspect)  camera.cuh:6,15
+//   render(w, h, spp, max_bounces, camera, scene, framebuffer)  render.cuh:366-367
+//
+// Difference by design: the pointers handed to Light / Primitive are HOST pointers into the
+// caller's own arrays (the reference hands out device pointers it cudaMalloc'ed and never frees);
+// render() flattens them to indices and the library owns every device allocation.
+// Errors throw std::runtime_error (the reference prints and exit()s, utility.cuh:6-13).
+#ifndef RTCUDA_HPP
+#define RTCUDA_HPP
+
+#include <cassert>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../rtcuda_amd.h"
+
+struct Vec3 {
+    Vec3() {}
+    constexpr Vec3(float x, float y, float z) : x(x), y(y), z(z) {}
+    constexpr Vec3(float xyz) : x(xyz), y(xyz), z(xyz) {}
+    static Vec3 make_zeros() { return Vec3(0.f, 0.f, 0.f); }
+    static Vec3 make_ones() { return Vec3(1.f, 1.f, 1.f); }
+    float x, y, z;
+};
+
+struct Triangle {
+    Triangle() {}
+    Triangle(const Vec3 &p0, const Vec3 &p1, const Vec3 &p2) : p0(p0), p1_(p1), p2_(p2) {}
+    Vec3 p0, p1_, p2_;  // the library derives e1, e2, n itself (triangle.cuh:7) with pinned fp32 arithmetic
+};
+
+enum MaterialType { MATTE, MIRROR, GLASS };
+struct Material {
+    Material() : albedo(0.f), index_of_refraction(0.f), type(MATTE) {}
+    static Material make_matte(const Vec3 &albedo) { Material m; m.albedo = albedo; m.type = MATTE; return m; }
+    static Material make_mirror(const Vec3 &albedo) { Material m; m.albedo = albedo; m.type = MIRROR; return m; }
+    static Material make_glass(float ior) { Material m; m.index_of_refraction = ior; m.type = GLASS; return m; }
+    Vec3 albedo;
+    float index_of_refraction;
+    MaterialType type;
+};
+
+enum LightType { POINT_LIGHT, AREA_LIGHT };
+struct Light {
+    Light() : type(POINT_LIGHT), pos(0.f), d_triangle(nullptr), L(0.f) {}
+    static Light make_point_light(const Vec3 &pos, const Vec3 &I) { Light l; l.type = POINT_LIGHT; l.pos = pos; l.L = I; return l; }
+    static Light make_area_light(Triangle *d_triangle, const Vec3 &L) { Light l; l.type = AREA_LIGHT; l.d_triangle = d_triangle; l.L = L; return l; }
+    LightType type;
+    Vec3 pos;
+    Triangle *d_triangle;
+    Vec3 L;  // I for point lights
+};
+
+struct Primitive {
+    Primitive() : d_triangle(nullptr), d_mat(nullptr), d_area_light(nullptr) {}
+    Primitive(Triangle *d_triangle, Material *d_mat, Light *d_area_light = nullptr)
+        : d_triangle(d_triangle), d_mat(d_mat), d_area_light(d_area_light) {}
+    Triangle *d_triangle;
+    Material *d_mat;
+    Light *d_area_light;
+};
+
+namespace rtcuda_detail {
+struct SceneHandle {
+    rt_scene *h = nullptr;
+    const Light *lights_key = nullptr;
+    int num_lights_key = -1;
+    ~SceneHandle() { if (h) rt_scene_destroy(h); }
+};
+inline void check(int rc, const char *what) {
+    if (rc != 0) throw std::runtime_error(std::string(what) + ": " + rt_last_error());
+}
+}  // namespace rtcuda_detail
+
+// Host-side description only; the device BVH is built by the library when render() first sees the scene.
+struct Bvh {
+    Bvh() : num_primitives(0) {}
+    Bvh(const std::vector<Triangle> &triangles, const std::vector<Primitive> &primitives)
+        : num_primitives((int)triangles.size()), triangles(triangles), primitives(primitives),
+          triangle_base(triangles.empty() ? nullptr : &triangles[0]),
+          handle(std::make_shared<rtcuda_detail::SceneHandle>()) {
+        assert(triangles.size() == primitives.size());  // bvh.cuh:33
+    }
+    int num_primitives;
+    std::vector<Triangle> triangles;
+    std::vector<Primitive> primitives;
+    const Triangle *triangle_base;  // primitives[i].d_triangle and Light::d_triangle point into [base, base + n)
+    std::shared_ptr<rtcuda_detail::SceneHandle> handle;
+};
+
+struct Scene {
+    Bvh bvh;
+    int num_lights;
+    Light *d_lights;
+};
+
+struct Camera {
+    Camera() {}
+    Camera(Vec3 lookfrom, Vec3 lookat, Vec3 up, float vfov, float aspect_ratio) {
+        float a[3] = {lookfrom.x, lookfrom.y, lookfrom.z}, b[3] = {lookat.x, lookat.y, lookat.z}, c[3] = {up.x, up.y, up.z};
+        rtcuda_detail::check(rt_camera_make(a, b, c, vfov, aspect_ratio, &pod), "Camera");
+    }
+    rt_camera pod;
+};
+
+namespace rtcuda_detail {
+inline rt_scene *realise(const Scene &scene) {
+    SceneHandle &sh = *scene.bvh.handle;
+    if (sh.h && sh.lights_key == scene.d_lights && sh.num_lights_key == scene.num_lights) return sh.h;
+    if (sh.h) { rt_scene_destroy(sh.h); sh.h = nullptr; }
+    const Bvh &bvh = scene.bvh;
+    const int n = bvh.num_primitives;
+    std::vector<float> verts((size_t)9 * (n > 0 ? n : 1));
+    std::vector<int32_t> tri_mat(n > 0 ? n : 1), tri_light(n > 0 ? n : 1);
+    std::vector<const Material *> mat_ptrs;
+    std::vector<rt_material> mats;
+    // primitives may come in any order: primitive i describes triangle (d_triangle - base)
+    for (int i = 0; i < n; i++) {
+        const Primitive &pr = bvh.primitives[i];
+        long ti = pr.d_triangle - bvh.triangle_base;
+        if (ti < 0 || ti >= n) throw std::runtime_error("render: Primitive::d_triangle does not point into the Bvh's triangles");
+        const Triangle &t = bvh.triangles[ti];
+        float *q = &verts[9 * (size_t)ti];
+        q[0] = t.p0.x; q[1] = t.p0.y; q[2] = t.p0.z;
+        q[3] = t.p1_.x; q[4] = t.p1_.y; q[5] = t.p1_.z;
+        q[6] = t.p2_.x; q[7] = t.p2_.y; q[8] = t.p2_.z;
+        int mi = -1;
+        for (size_t k = 0; k < mat_ptrs.size(); k++) if (mat_ptrs[k] == pr.d_mat) { mi = (int)k; break; }
+        if (mi < 0) {
+            if (!pr.d_mat) throw std::runtime_error("render: Primitive without material");
+            mi = (int)mat_ptrs.size();
+            mat_ptrs.push_back(pr.d_mat);
+            rt_material m;
+            m.albedo[0] = pr.d_mat->albedo.x; m.albedo[1] = pr.d_mat->albedo.y; m.albedo[2] = pr.d_mat->albedo.z;
+            m.index_of_refraction = pr.d_mat->index_of_refraction;
+            m.type = (int32_t)pr.d_mat->type;
+            mats.push_back(m);
+        }
+        tri_mat[ti] = mi;
+        long li = pr.d_area_light ? pr.d_area_light - scene.d_lights : -1;
+        if (pr.d_area_light && (li < 0 || li >= scene.num_lights)) throw std::runtime_error("render: Primitive::d_area_light does not point into Scene::d_lights");
+        tri_light[ti] = (int32_t)li;
+    }
+    std::vector<rt_light> lights(scene.num_lights > 0 ? scene.num_lights : 1);
+    for (int k = 0; k < scene.num_lights; k++) {
+        const Light &l = scene.d_lights[k];
+        rt_light &o = lights[k];
+        o.type = (int32_t)l.type;
+        o.pos[0] = l.pos.x; o.pos[1] = l.pos.y; o.pos[2] = l.pos.z;
+        o.L[0] = l.L.x; o.L[1] = l.L.y; o.L[2] = l.L.z;
+        o.triangle = -1;
+        if (l.type == AREA_LIGHT) {
+            long ti = l.d_triangle - bvh.triangle_base;
+            if (ti < 0 || ti >= n) throw std::runtime_error("render: Light::d_triangle does not point into the Bvh's triangles");
+            o.triangle = (int32_t)ti;
+        }
+    }
+    check(rt_scene_create(verts.data(), n, tri_mat.data(), tri_light.data(), mats.data(), (int)mats.size(),
+                          lights.data(), scene.num_lights, &sh.h), "rt_scene_create");
+    sh.lights_key = scene.d_lights;
+    sh.num_lights_key = scene.num_lights;
+    return sh.h;
+}
+}  // namespace rtcuda_detail
+
+// render.cuh:366-367.  `seed` is the reference's hard-coded RAND_SEED = 1 (render.cuh:417).
+inline void render(int width, int height, int num_samples, int max_bounces, Camera camera, Scene scene,
+                   std::vector<Vec3> &framebuffer, uint64_t seed = 1, rt_stats *stats = nullptr) {
+    rt_scene *h = rtcuda_detail::realise(scene);
+    framebuffer.resize((size_t)width * height);
+    static_assert(sizeof(Vec3) == 12, "Vec3 must be three packed floats");
+    rtcuda_detail::check(rt_render(h, &camera.pod, width, height, num_samples, max_bounces, seed, 0,
+                                   reinterpret_cast<float *>(framebuffer.data()), stats), "render");
+}
+
+#endif  // RTCUDA_HPP
