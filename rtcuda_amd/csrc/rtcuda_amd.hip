@@ -106,7 +106,7 @@ struct DPools {
 // the first version of k_advance.
 struct DCounters {
     int last_live_round;         // highest batch-closing round in which some slot still traced a ray
-    int pad;
+    unsigned int round_shades;   // lockstep rounds only: mat() events of the round (the reference's n_mat)
     unsigned int pad2[2];
 };
 enum { C_CAMERA = 0, C_SHADE, C_CLOSEST, C_ANY, C_EMIT, C_SHADOW_ADD, C_RR, C_UNUSED, C_COUNT };
@@ -114,7 +114,8 @@ struct DWaveRow {
     unsigned long long c[C_COUNT];  // one 64-byte line per wave
 };
 
-constexpr int kDone = -0x7fffffff;
+constexpr int kDone = -0x7fffffff;    // slot has no camera ray left
+constexpr int kParked = -0x7ffffffe;  // slot waits for the lockstep rounds of the final generation
 
 // ============================================================================ wave helpers
 __device__ __forceinline__ unsigned lane_id() {
@@ -193,6 +194,8 @@ struct AdvanceParams {
     long long cam_end;  // width*height*spp
     int round;
     int batch_mask;      // rounds with (round & batch_mask) == batch_mask close a host-polled batch
+    int last_gen;        // index of the final camera-ray generation
+    int lockstep;        // 1: final generation, one init() per slot per round (literal reference schedule)
 };
 
 constexpr int kLdsTable = 64;                   // materials / lights staged in LDS per workgroup
@@ -294,7 +297,15 @@ k_advance(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__
     const int off_ltri = tab_off_ltri(sc.num_mats, sc.num_lights);
     const int off_lpre = tab_off_lpre(sc.num_mats, sc.num_lights);
 
-    const bool alive = bounces != kDone;
+    // Final generation: the reference stops the whole render at the first iteration in which no slot
+    // shades (render.cuh:436), which can cut off slots that Russian roulette would have revived
+    // later.  That is a global condition, so the last generation runs in lockstep: slots that finish
+    // generation last_gen - 1 park, and once all are parked the host drives one init() per round.
+    if (ap.lockstep && bounces == kParked) {
+        bounces = ap.max_bounces;  // routes the slot to gen() below
+        hit_info = -1;
+    }
+    const bool alive = bounces != kDone && bounces != kParked;
     bool did_gen = false, did_shade = false, has_shadow = false, did_emit = false;
     int rr_draws = 0;
 
@@ -334,6 +345,7 @@ k_advance(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__
                     did_shade = true;
                     break;
                 }
+                if (ap.lockstep) break;              // exactly one init() per round
                 if (!hit) bounces = ap.max_bounces;  // idle iterations consume nothing: skip them
                 continue;
             }
@@ -341,6 +353,10 @@ k_advance(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__
             long long cid = (long long)gen * kW + (ap.slot_lo + i);
             if (cid >= ap.cam_end) {
                 bounces = kDone;
+                break;
+            }
+            if (!ap.lockstep && gen == ap.last_gen) {
+                bounces = kParked;
                 break;
             }
             p.gen[i] = gen + 1;
@@ -479,6 +495,10 @@ k_advance(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__
     // liveness is monotone (a finished slot never restarts), so the host only needs it for the
     // round that closes a batch: one plain store per live wave in 1 round out of 8
     if ((ap.round & ap.batch_mask) == ap.batch_mask && traced != 0 && lane_id() == 0) ctr->last_live_round = ap.round;
+    if (ap.lockstep) {
+        unsigned long long sm = __ballot(did_shade);
+        if (sm != 0 && lane_id() == 0) atomicAdd(&ctr->round_shades, (unsigned)__popcll(sm));
+    }
 }
 
 // ============================================================================ traversal
@@ -631,7 +651,7 @@ __global__ void __launch_bounds__(kBlock, 8) k_trace(DScene sc, DPools p, TraceP
                         int cand = (any_chunk ? chunk - n_chunks : chunk) * 64 + (int)lane;
                         bool valid = cand < total;
                         if (MODE == MODE_POOL && valid)
-                            valid = any_chunk ? p.stmax[cand] >= 0.f : p.bounces[cand] != kDone;
+                            valid = any_chunk ? p.stmax[cand] >= 0.f : (p.bounces[cand] != kDone && p.bounces[cand] != kParked);
                         unsigned long long vm = __ballot(valid);
                         if (valid) pend[prefix_popc(vm)] = any_chunk ? (cand | kAnyBit) : cand;
                         pend_lo = 0;
@@ -990,7 +1010,7 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
     {
         DCounters zero;
         zero.last_live_round = -1;
-        zero.pad = 0;
+        zero.round_shades = 0;
         zero.pad2[0] = zero.pad2[1] = 0;
         c.h_ctr[0] = zero;  // pinned staging
         HIP_TRY(hipMemcpyAsync(c.d_ctr, &c.h_ctr[0], sizeof(DCounters), hipMemcpyHostToDevice, st));
@@ -1010,8 +1030,10 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
     ap.spp = spp;
     ap.max_bounces = max_bounces;
     ap.cam_end = cam_end;
+    ap.last_gen = (int)((cam_end + kW - 1) / kW) - 1;
     ap.round = 0;
     ap.batch_mask = 7;
+    ap.lockstep = 0;
     const bool lds_tables = scene->n_mats <= kLdsTable && scene->n_lights <= kLdsTable;
 
     hipEvent_t ev_start, ev_stop;
@@ -1092,6 +1114,28 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
             if ((long long)c.h_ctr[prev].last_live_round < (long long)batch * kBatch - 1) finished = true;
         }
         batch++;
+    }
+    // ---- final generation in lockstep (see k_advance): round 0 generates, every later round is one
+    // reference iteration; the render ends at the first round in which nothing shades (render.cuh:436)
+    if (finished) {
+        ap.lockstep = 1;
+        for (int j = 0; j <= max_bounces + 1; j++) {
+            ap.round = (int)(rounds & 0x3fffffff);
+            HIP_TRY(hipMemsetAsync(&c.d_ctr->round_shades, 0, sizeof(unsigned), st));
+            if (lds_tables)
+                hipLaunchKernelGGL(k_advance<true>, grid, block, 0, st, sc, c.pools, cam, ap, d_sum, c.d_ctr, c.d_rows);
+            else
+                hipLaunchKernelGGL(k_advance<false>, grid, block, 0, st, sc, c.pools, cam, ap, d_sum, c.d_ctr, c.d_rows);
+            HIP_TRY(hipGetLastError());
+            rounds++;
+            if (j > 0) {
+                HIP_TRY(hipMemcpyAsync(&c.h_ctr[0], c.d_ctr, sizeof(DCounters), hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipStreamSynchronize(st));
+                if (c.h_ctr[0].round_shades == 0) break;
+            }
+            hipLaunchKernelGGL(k_trace<MODE_POOL>, grid_trace, block, lds_bytes, st, sc, c.pools, tpp, stack_depth);
+            HIP_TRY(hipGetLastError());
+        }
     }
     HIP_TRY(hipEventRecord(ev_stop, st));
     HIP_TRY(hipEventSynchronize(ev_stop));
