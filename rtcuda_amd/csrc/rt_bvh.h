@@ -5,22 +5,28 @@
 // only needs "closest accepted triangle" (results are topology-independent
 // except equal-t ties), so the tree is built for the traversal kernel instead:
 //
-//   * full-sweep SAH over three index arrays kept sorted per axis (the quality class of the
-//     reference's builder), leaf cost model C_leaf = n_tris, C_split = 1 + SAH, max 4 tris/leaf;
-//   * output is an array of 64-byte PAIR records -- both children's boxes plus both child links in
-//     one 64-byte line -- so one traversal step is one aligned 64-byte fetch (4 x dwordx4);
-//   * triangles are re-ordered so every leaf's triangles are contiguous ("leaf order");
-//   * boxes are padded outward by a few ulps so the fp32 slab test in the kernel is conservative
-//     with respect to the exact triangle test (a box test must never cull a triangle the
-//     triangle test would accept).
+//   1. binary tree by full-sweep SAH over three index arrays kept sorted per axis (the quality class
+//      of the reference's builder), leaf cost model C_leaf = n_tris, C_split = 1 + SAH, <= 4 tris/leaf;
+//   2. collapsed to a 4-wide tree (the child with the largest surface area is opened until a node has
+//      four children), which halves the number of dependent node fetches per ray;
+//   3. every 4-wide node is ONE 64-byte record -- the traversal kernel is bound by the number of
+//      64-byte lines its divergent lanes pull through the texture-address path, so the four child
+//      boxes are stored as 8-bit offsets on a power-of-two grid anchored at the node's own box
+//      (6 bytes per child instead of 24):
 //
-// Pair record layout (16 words):
-//   w0..w5   left  box  xmin ymin zmin xmax ymax zmax
-//   w6..w11  right box  xmin ymin zmin xmax ymax zmax
-//   w12 left link, w13 right link, w14 left count, w15 right count
-//   link >= 0 with count == 0 : index of the child's pair record
-//   count  > 0                : leaf, link = first triangle (leaf order), count triangles
-//   count == 0 and link == -1 : empty child (box inverted, never hit)
+//        w0..w2   float  origin = lower corner of the node's box
+//        w3       uint   grid exponents: ex | ey << 8 | ez << 16   (cell = 2^(e - 127) as an fp32 bit pattern)
+//        w4..w7   int    child links: >= 0 inner node index, < 0 leaf reference ~(first << 3 | count),
+//                        0x80000000 = no child
+//        w8..w10  uint   lower bounds x / y / z, one byte per child (child k in bits 8k..8k+7)
+//        w11..w13 uint   upper bounds x / y / z
+//        w14,w15  spare
+//
+//      decode (device and host use exactly this fp32 expression, no FMA):  bound = origin + float(q) * cell
+//      The builder verifies, with that same expression, that every decoded child box CONTAINS the child's
+//      exact box padded outward by 2 ulps, so the kernel's slab test stays conservative with respect to
+//      the exact triangle test (a box test must never cull a triangle the triangle test would accept).
+//   4. triangles are re-ordered so every leaf's triangles are contiguous ("leaf order").
 #ifndef RT_BVH_H
 #define RT_BVH_H
 
@@ -52,24 +58,49 @@ struct Box {
     }
 };
 
-struct Pair {
-    float lbox[6];
-    float rbox[6];
-    int32_t llink, rlink, lcount, rcount;
+constexpr int32_t kNoChild = (int32_t)0x80000000;
+inline int32_t leaf_ref(int first, int count) { return ~((first << 3) | count); }
+
+struct Node4 {
+    float origin[3];
+    uint32_t exps;
+    int32_t link[4];
+    uint32_t qlo[3];
+    uint32_t qhi[3];
+    uint32_t spare[2];
 };
-static_assert(sizeof(Pair) == 64, "pair record must be one 64-byte line");
+static_assert(sizeof(Node4) == 64, "wide node must be one 64-byte line");
+
+// decode exactly as the kernel does
+inline float cell_size(uint32_t exps, int axis) {
+    uint32_t bits = ((exps >> (8 * axis)) & 0xffu) << 23;
+    float f;
+    memcpy(&f, &bits, 4);
+    return f;
+}
+inline float decode(float origin, uint32_t q, float cell) { return origin + (float)q * cell; }
+
+struct BinNode {
+    Box box;         // exact (unpadded) box of the subtree
+    int left = -1;   // children (binary) or -1
+    int right = -1;
+    int first = 0;   // leaf: first triangle in leaf order
+    int count = 0;   // leaf: triangle count (0 for inner)
+};
 
 struct Result {
-    std::vector<Pair> pairs;
+    std::vector<Node4> nodes;
     std::vector<int32_t> order;  // leaf order -> original triangle index
-    int max_depth = 0;
+    int max_depth = 0;           // depth of the 4-wide tree (root = 1)
+    int bin_depth = 0;           // depth of the binary tree it was collapsed from
     int num_leaves = 0;
+    int stack_bound = 1;         // upper bound of the traversal stack: 3 entries per level
+    bool ok = true;              // false if a leaf could not be referenced (more than 7 triangles)
 };
 
 constexpr int kMaxLeaf = 4;
-constexpr int kMaxDepth = 48;  // hard cap; the traversal stack is sized from Result::max_depth
+constexpr int kMaxBinDepth = 60;
 
-// nextafter-style outward padding: k ulps at the magnitude of the value (min 1e-30 absolute)
 inline float pad_down(float v, int k) {
     for (int i = 0; i < k; i++) v = std::nextafter(v, -FLT_MAX);
     return v;
@@ -79,23 +110,14 @@ inline float pad_up(float v, int k) {
     return v;
 }
 
-// verts: n x 9 floats (p0 p1 p2).  Deterministic for a given input.
-inline Result build(const float *verts, int n) {
-    Result res;
-    res.order.resize(n);
-    if (n == 0) {
-        Pair p;
-        Box e;
-        e.reset();
-        memcpy(p.lbox, e.lo, 12);
-        memcpy(p.lbox + 3, e.hi, 12);
-        memcpy(p.rbox, e.lo, 12);
-        memcpy(p.rbox + 3, e.hi, 12);
-        p.llink = p.rlink = -1;
-        p.lcount = p.rcount = 0;
-        res.pairs.push_back(p);
-        return res;
-    }
+// ---- step 1: binary SAH tree
+inline void build_binary(const float *verts, int n, std::vector<BinNode> &bin, std::vector<int32_t> &order,
+                         int &bin_depth, int &num_leaves) {
+    bin.clear();
+    order.assign(n, 0);
+    bin_depth = 0;
+    num_leaves = 0;
+    if (n == 0) return;
     std::vector<Box> boxes(n);
     std::vector<float> cen(3 * (size_t)n);
     for (int i = 0; i < n; i++) {
@@ -112,167 +134,226 @@ inline Result build(const float *verts, int n) {
     for (int a = 0; a < 3; a++) {
         idx[a].resize(n);
         std::iota(idx[a].begin(), idx[a].end(), 0);
-        std::stable_sort(idx[a].begin(), idx[a].end(), [&](int i, int j) {
-            return cen[3 * (size_t)i + a] < cen[3 * (size_t)j + a];
-        });
+        std::stable_sort(idx[a].begin(), idx[a].end(),
+                         [&](int i, int j) { return cen[3 * (size_t)i + a] < cen[3 * (size_t)j + a]; });
     }
     std::vector<float> right_area(n);
     std::vector<uint8_t> side(n);
     std::vector<int32_t> tmp(n);
-
     struct Task {
-        int begin, end, depth;
-        int parent;   // pair index that owns this child (-1 for the root range)
-        int which;    // 0 = left child of parent, 1 = right
-        Box box;
+        int node, begin, end, depth;
     };
-    auto set_child_box = [&](Pair &p, int which, const Box &b) {
-        float *dst = which ? p.rbox : p.lbox;
-        for (int a = 0; a < 3; a++) {
-            dst[a] = pad_down(b.lo[a], 2);
-            dst[3 + a] = pad_up(b.hi[a], 2);
-        }
-    };
-    int out_pos = 0;  // next free position in leaf order
-    auto make_leaf = [&](const Task &t) {
-        Pair &p = res.pairs[t.parent];
-        int first = out_pos;
-        for (int i = t.begin; i < t.end; i++) res.order[out_pos++] = idx[0][i];
-        if (t.which) {
-            p.rlink = first;
-            p.rcount = t.end - t.begin;
-        } else {
-            p.llink = first;
-            p.lcount = t.end - t.begin;
-        }
-        res.num_leaves++;
-        res.max_depth = std::max(res.max_depth, t.depth);
-    };
-
+    int out_pos = 0;
     Box root;
     root.reset();
     for (int i = 0; i < n; i++) root.extend(boxes[i]);
-
-    // The root range always becomes pair 0 (a scene that is a single leaf gets a pair whose right
-    // child is empty), so the kernel never special-cases "root is a leaf" (bvh.cuh:252,307).
+    bin.reserve(2 * (size_t)n);
+    bin.push_back(BinNode());
+    bin[0].box = root;
     std::vector<Task> stack;
-    {
-        Pair p;
-        memset(&p, 0, sizeof(p));
-        Box e;
-        e.reset();
-        memcpy(p.lbox, e.lo, 12);
-        memcpy(p.lbox + 3, e.hi, 12);
-        memcpy(p.rbox, e.lo, 12);
-        memcpy(p.rbox + 3, e.hi, 12);
-        p.llink = p.rlink = -1;
-        res.pairs.push_back(p);
-    }
-    // split a range into two child tasks of pair `pi`; returns false if it should be a leaf
-    auto try_split = [&](int begin, int end, const Box &box, int &best_axis, int &best_split, Box &lb, Box &rb) {
-        int cnt = end - begin;
-        float best = FLT_MAX;
-        best_axis = -1;
-        for (int a = 0; a < 3; a++) {
-            Box acc;
-            acc.reset();
-            for (int i = end - 1; i > begin; i--) {
-                acc.extend(boxes[idx[a][i]]);
-                right_area[i] = acc.half_area();
-            }
-            acc.reset();
-            for (int i = begin; i < end - 1; i++) {
-                acc.extend(boxes[idx[a][i]]);
-                float cost = acc.half_area() * (float)(i + 1 - begin) + right_area[i + 1] * (float)(end - i - 1);
-                if (cost < best) {
-                    best = cost;
-                    best_axis = a;
-                    best_split = i + 1;
-                }
-            }
-        }
-        if (best_axis < 0) return false;
-        float leaf_cost = box.half_area() * (float)cnt;
-        float split_cost = box.half_area() * 1.0f + best;  // traversal step ~ one triangle test
-        if (cnt <= kMaxLeaf && split_cost >= leaf_cost) return false;
-        lb.reset();
-        rb.reset();
-        for (int i = begin; i < best_split; i++) lb.extend(boxes[idx[best_axis][i]]);
-        for (int i = best_split; i < end; i++) rb.extend(boxes[idx[best_axis][i]]);
-        return true;
-    };
-    auto partition_other_axes = [&](int begin, int end, int axis, int split) {
-        for (int i = begin; i < split; i++) side[idx[axis][i]] = 0;
-        for (int i = split; i < end; i++) side[idx[axis][i]] = 1;
-        for (int a = 0; a < 3; a++) {
-            if (a == axis) continue;
-            int l = begin, r = 0;
-            for (int i = begin; i < end; i++) {
-                int t = idx[a][i];
-                if (side[t] == 0) idx[a][l++] = t;
-                else tmp[r++] = t;
-            }
-            memcpy(&idx[a][l], tmp.data(), sizeof(int32_t) * (size_t)r);
-        }
-    };
-
-    // root handling
-    {
-        int axis, split;
-        Box lb, rb;
-        if (n >= 2 && try_split(0, n, root, axis, split, lb, rb)) {
-            partition_other_axes(0, n, axis, split);
-            set_child_box(res.pairs[0], 0, lb);
-            set_child_box(res.pairs[0], 1, rb);
-            // depth-first, left child first: keeps subtrees contiguous in memory
-            stack.push_back(Task{split, n, 1, 0, 1, rb});
-            stack.push_back(Task{0, split, 1, 0, 0, lb});
-        } else {
-            set_child_box(res.pairs[0], 0, root);
-            Task t{0, n, 1, 0, 0, root};
-            make_leaf(t);
-        }
-    }
+    stack.push_back(Task{0, 0, n, 1});
     while (!stack.empty()) {
         Task t = stack.back();
         stack.pop_back();
-        int cnt = t.end - t.begin;
-        int axis = -1, split = -1;
-        Box lb, rb;
-        bool can_split = cnt >= 2 && t.depth < kMaxDepth && try_split(t.begin, t.end, t.box, axis, split, lb, rb);
-        if (!can_split && cnt > kMaxLeaf && t.depth < kMaxDepth) {
-            // SAH found no useful plane (coincident boxes): split in the middle of axis 0
-            axis = 0;
-            split = t.begin + cnt / 2;
-            lb.reset();
-            rb.reset();
-            for (int i = t.begin; i < split; i++) lb.extend(boxes[idx[0][i]]);
-            for (int i = split; i < t.end; i++) rb.extend(boxes[idx[0][i]]);
-            can_split = true;
+        const int cnt = t.end - t.begin;
+        bin_depth = std::max(bin_depth, t.depth);
+        int best_axis = -1, best_split = -1;
+        if (cnt >= 2 && t.depth < kMaxBinDepth) {
+            float best = FLT_MAX;
+            for (int a = 0; a < 3; a++) {
+                Box acc;
+                acc.reset();
+                for (int i = t.end - 1; i > t.begin; i--) {
+                    acc.extend(boxes[idx[a][i]]);
+                    right_area[i] = acc.half_area();
+                }
+                acc.reset();
+                for (int i = t.begin; i < t.end - 1; i++) {
+                    acc.extend(boxes[idx[a][i]]);
+                    float cost = acc.half_area() * (float)(i + 1 - t.begin) + right_area[i + 1] * (float)(t.end - i - 1);
+                    if (cost < best) {
+                        best = cost;
+                        best_axis = a;
+                        best_split = i + 1;
+                    }
+                }
+            }
+            if (best_axis >= 0) {
+                float area = bin[t.node].box.half_area();
+                float leaf_cost = area * (float)cnt;
+                float split_cost = area * 1.0f + best;  // one traversal step ~ one triangle test
+                if (cnt <= kMaxLeaf && split_cost >= leaf_cost) best_axis = -1;
+            }
+            if (best_axis < 0 && cnt > kMaxLeaf) {  // coincident boxes: split in the middle of axis 0
+                best_axis = 0;
+                best_split = t.begin + cnt / 2;
+            }
         }
-        if (!can_split) {
-            make_leaf(t);
+        if (best_axis < 0) {  // leaf (a range longer than kMaxLeaf only at the depth cap)
+            bin[t.node].first = out_pos;
+            bin[t.node].count = cnt;
+            for (int i = t.begin; i < t.end; i++) order[out_pos++] = idx[0][i];
+            num_leaves++;
             continue;
         }
-        partition_other_axes(t.begin, t.end, axis, split);
-        int pi = (int)res.pairs.size();
-        Pair p;
-        memset(&p, 0, sizeof(p));
-        p.llink = p.rlink = -1;
-        res.pairs.push_back(p);
-        set_child_box(res.pairs[pi], 0, lb);
-        set_child_box(res.pairs[pi], 1, rb);
-        Pair &par = res.pairs[t.parent];
-        if (t.which) {
-            par.rlink = pi;
-            par.rcount = 0;
-        } else {
-            par.llink = pi;
-            par.lcount = 0;
+        for (int i = t.begin; i < best_split; i++) side[idx[best_axis][i]] = 0;
+        for (int i = best_split; i < t.end; i++) side[idx[best_axis][i]] = 1;
+        for (int a = 0; a < 3; a++) {
+            if (a == best_axis) continue;
+            int l = t.begin, r = 0;
+            for (int i = t.begin; i < t.end; i++) {
+                int tri = idx[a][i];
+                if (side[tri] == 0) idx[a][l++] = tri;
+                else tmp[r++] = tri;
+            }
+            memcpy(&idx[a][l], tmp.data(), sizeof(int32_t) * (size_t)r);
         }
-        stack.push_back(Task{split, t.end, t.depth + 1, pi, 1, rb});
-        stack.push_back(Task{t.begin, split, t.depth + 1, pi, 0, lb});
+        Box lb, rb;
+        lb.reset();
+        rb.reset();
+        for (int i = t.begin; i < best_split; i++) lb.extend(boxes[idx[best_axis][i]]);
+        for (int i = best_split; i < t.end; i++) rb.extend(boxes[idx[best_axis][i]]);
+        int li = (int)bin.size();
+        bin.push_back(BinNode());
+        bin.push_back(BinNode());
+        bin[li].box = lb;
+        bin[li + 1].box = rb;
+        bin[t.node].left = li;
+        bin[t.node].right = li + 1;
+        // depth-first, left first: a leaf's triangles and a subtree's leaves stay contiguous
+        stack.push_back(Task{li + 1, best_split, t.end, t.depth + 1});
+        stack.push_back(Task{li, t.begin, best_split, t.depth + 1});
     }
+}
+
+// ---- steps 2 + 3: collapse to 4-wide, quantise
+inline bool quantise_node(Node4 &nd, const Box *child_boxes, int nchild) {
+    Box all;
+    all.reset();
+    Box padded[4];
+    for (int k = 0; k < nchild; k++) {
+        for (int a = 0; a < 3; a++) {
+            padded[k].lo[a] = pad_down(child_boxes[k].lo[a], 2);
+            padded[k].hi[a] = pad_up(child_boxes[k].hi[a], 2);
+        }
+        all.extend(padded[k]);
+    }
+    nd.exps = 0;
+    for (int a = 0; a < 3; a++) {
+        nd.origin[a] = all.lo[a];
+        nd.qlo[a] = 0;
+        nd.qhi[a] = 0;
+    }
+    for (int a = 0; a < 3; a++) {
+        double extent = (double)all.hi[a] - (double)all.lo[a];
+        int e = 1;  // biased exponent byte; cell = 2^(e - 127)
+        if (extent > 0) {
+            int ex;
+            std::frexp(extent / 255.0, &ex);  // extent/255 = m * 2^ex, m in [0.5, 1)  -> cell 2^ex >= extent/255
+            e = std::min(254, std::max(1, ex + 127));
+        }
+        for (;; e++) {
+            if (e > 254) return false;
+            uint32_t exps_try = (nd.exps & ~(0xffu << (8 * a))) | ((uint32_t)e << (8 * a));
+            float cell = cell_size(exps_try, a);
+            uint32_t lo_bytes = 0, hi_bytes = 0;
+            bool ok = true;
+            for (int k = 0; k < nchild && ok; k++) {
+                double ql = std::floor(((double)padded[k].lo[a] - (double)nd.origin[a]) / (double)cell);
+                double qh = std::ceil(((double)padded[k].hi[a] - (double)nd.origin[a]) / (double)cell);
+                long l = (long)std::max(0.0, std::min(255.0, ql));
+                long h = (long)std::max(0.0, std::min(255.0, qh));
+                while (l > 0 && decode(nd.origin[a], (uint32_t)l, cell) > padded[k].lo[a]) l--;
+                while (h < 255 && decode(nd.origin[a], (uint32_t)h, cell) < padded[k].hi[a]) h++;
+                if (decode(nd.origin[a], (uint32_t)l, cell) > padded[k].lo[a] ||
+                    decode(nd.origin[a], (uint32_t)h, cell) < padded[k].hi[a])
+                    ok = false;  // grid too fine for this extent: double the cell
+                lo_bytes |= (uint32_t)l << (8 * k);
+                hi_bytes |= (uint32_t)h << (8 * k);
+            }
+            if (ok) {
+                nd.exps = exps_try;
+                nd.qlo[a] = lo_bytes;
+                nd.qhi[a] = hi_bytes;
+                break;
+            }
+        }
+    }
+    return true;
+}
+
+// verts: n x 9 floats (p0 p1 p2).  Deterministic for a given input.
+inline Result build(const float *verts, int n) {
+    Result res;
+    std::vector<BinNode> bin;
+    build_binary(verts, n, bin, res.order, res.bin_depth, res.num_leaves);
+    auto empty_node = [] {
+        Node4 nd;
+        memset(&nd, 0, sizeof(nd));
+        for (int k = 0; k < 4; k++) nd.link[k] = kNoChild;
+        nd.exps = 0x010101u;
+        return nd;
+    };
+    if (n == 0) {
+        res.nodes.push_back(empty_node());
+        res.max_depth = 1;
+        res.stack_bound = 1;
+        return res;
+    }
+    struct Task {
+        int bin_node, out_node, depth;
+    };
+    res.nodes.push_back(empty_node());
+    std::vector<Task> stack;
+    stack.push_back(Task{0, 0, 1});
+    while (!stack.empty()) {
+        Task t = stack.back();
+        stack.pop_back();
+        res.max_depth = std::max(res.max_depth, t.depth);
+        // children of the wide node: open the inner child with the largest surface area until 4
+        int kids[4];
+        int nk = 0;
+        const BinNode &b = bin[t.bin_node];
+        if (b.left < 0) {
+            kids[nk++] = t.bin_node;  // the whole tree is one leaf
+        } else {
+            kids[nk++] = b.left;
+            kids[nk++] = b.right;
+            while (nk < 4) {
+                int pick = -1;
+                float best = -1.f;
+                for (int k = 0; k < nk; k++)
+                    if (bin[kids[k]].left >= 0 && bin[kids[k]].box.half_area() > best) {
+                        best = bin[kids[k]].box.half_area();
+                        pick = k;
+                    }
+                if (pick < 0) break;
+                int opened = kids[pick];
+                kids[pick] = bin[opened].left;
+                kids[nk++] = bin[opened].right;
+            }
+        }
+        Box cb[4];
+        Node4 nd = empty_node();
+        for (int k = 0; k < nk; k++) cb[k] = bin[kids[k]].box;
+        quantise_node(nd, cb, nk);
+        for (int k = 0; k < nk; k++) {
+            const BinNode &c = bin[kids[k]];
+            if (c.left < 0) {
+                // a leaf longer than 7 triangles cannot be referenced (3 count bits); the builder only
+                // produces such ranges at the binary depth cap, where they are split into several refs
+                if (c.count > 7) res.ok = false;
+                nd.link[k] = leaf_ref(c.first, std::min(c.count, 7));
+            } else {
+                int child = (int)res.nodes.size();
+                res.nodes.push_back(empty_node());
+                nd.link[k] = child;
+                stack.push_back(Task{kids[k], child, t.depth + 1});
+            }
+        }
+        res.nodes[t.out_node] = nd;
+    }
+    res.stack_bound = 3 * res.max_depth + 1;
     return res;
 }
 

@@ -1,15 +1,16 @@
 // rt_host_check.cpp -- host-only self-check of the BVH builder (rt_bvh.h), compiled with g++.
 //
-// Runs without a GPU: validates the pair-record tree the kernels will walk (every triangle in
-// exactly one leaf, every pair reachable exactly once, child boxes contain their triangles, depth
-// within the kernel's LDS stack) and walks it on the CPU with the same control flow as
-// traverse_closest in rtcuda_amd.hip, comparing against an exhaustive search.  A malformed tree
-// would hang or fault the GPU; this is where it is caught first.
+// Runs without a GPU: validates the 4-wide quantised tree the kernels will walk (every triangle in
+// exactly one leaf, every node reachable exactly once, every DECODED child box contains its
+// triangles, stack bound) and walks it on the CPU with the same control flow and the same fp32
+// expressions as k_trace in rtcuda_amd.hip, comparing against an exhaustive search.  A malformed
+// tree would hang or fault the GPU; this is where it is caught first.
 #include <cfloat>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <vector>
 
 #include "rt_bvh.h"
@@ -32,65 +33,82 @@ inline bool tri_hit(const Tri &tr, V3 o, V3 d, float tmax, float &t) {
     }
     return false;
 }
-inline bool box_hit(V3 o, V3 inv, const float *b, float tmax, float &entry) {
-    float ax = (b[0] - o.x) * inv.x, bx = (b[3] - o.x) * inv.x;
-    float ay = (b[1] - o.y) * inv.y, by = (b[4] - o.y) * inv.y;
-    float az = (b[2] - o.z) * inv.z, bz = (b[5] - o.z) * inv.z;
+inline bool box_hit(V3 o, V3 inv, const float *lo, const float *hi, float tmax, float &entry) {
+    float ax = (lo[0] - o.x) * inv.x, bx = (hi[0] - o.x) * inv.x;
+    float ay = (lo[1] - o.y) * inv.y, by = (hi[1] - o.y) * inv.y;
+    float az = (lo[2] - o.z) * inv.z, bz = (hi[2] - o.z) * inv.z;
     float t_in = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
     float t_out = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
     entry = t_in;
     t_out = t_out * 1.0000004f;
     return t_in <= t_out && t_out >= 0.f && t_in <= tmax;
 }
+inline void child_box(const rtbvh::Node4 &nd, int k, float *lo, float *hi) {
+    for (int a = 0; a < 3; a++) {
+        float cell = rtbvh::cell_size(nd.exps, a);
+        lo[a] = rtbvh::decode(nd.origin[a], (nd.qlo[a] >> (8 * k)) & 0xffu, cell);
+        hi[a] = rtbvh::decode(nd.origin[a], (nd.qhi[a] >> (8 * k)) & 0xffu, cell);
+    }
+}
 }  // namespace
 
 extern "C" {
-// out: [pairs, leaves, max_depth, max_leaf_size, structural_errors, walk_mismatches, max_stack, max_steps]
-int rt_bvh_selfcheck(const float *verts, int n, int n_rays, const float *o3, const float *d3, int64_t *out8) {
+// out: [nodes, leaves, depth4, max_leaf_size, structural_errors, walk_mismatches, max_stack, max_steps,
+//       stack_bound, binary_depth]
+int rt_bvh_selfcheck(const float *verts, int n, int n_rays, const float *o3, const float *d3, int64_t *out10) {
     rtbvh::Result r = rtbvh::build(verts, n);
-    memset(out8, 0, 8 * sizeof(int64_t));
-    out8[0] = (int64_t)r.pairs.size();
-    out8[1] = r.num_leaves;
-    out8[2] = r.max_depth;
-    int64_t errors = 0;
-    std::vector<int> seen_tri(n, 0), seen_pair(r.pairs.size(), 0);
-    seen_pair[0] = 1;
+    memset(out10, 0, 10 * sizeof(int64_t));
+    out10[0] = (int64_t)r.nodes.size();
+    out10[1] = r.num_leaves;
+    out10[2] = r.max_depth;
+    out10[8] = r.stack_bound;
+    out10[9] = r.bin_depth;
+    int64_t errors = r.ok ? 0 : 1;
+    std::vector<int> seen_tri(n, 0), seen_node(r.nodes.size(), 0);
+    seen_node[0] = 1;
     int max_leaf = 0;
-    for (size_t pi = 0; pi < r.pairs.size(); pi++) {
-        const rtbvh::Pair &p = r.pairs[pi];
-        for (int side = 0; side < 2; side++) {
-            int link = side ? p.rlink : p.llink, count = side ? p.rcount : p.lcount;
-            const float *box = side ? p.rbox : p.lbox;
-            if (count > 0) {
-                if (link < 0 || link + count > n) { errors++; continue; }
+    // subtree boxes (from decoded children) must nest: collect each node's decoded union on the way
+    for (size_t ni = 0; ni < r.nodes.size(); ni++) {
+        const rtbvh::Node4 &nd = r.nodes[ni];
+        for (int k = 0; k < 4; k++) {
+            int link = nd.link[k];
+            if (link == rtbvh::kNoChild) continue;
+            float lo[3], hi[3];
+            child_box(nd, k, lo, hi);
+            if (link < 0) {
+                int ref = ~link, first = ref >> 3, count = ref & 7;
+                if (count <= 0 || first < 0 || first + count > n) { errors++; continue; }
                 max_leaf = std::max(max_leaf, count);
-                for (int k = link; k < link + count; k++) {
-                    int ti = r.order[k];
+                for (int q = first; q < first + count; q++) {
+                    int ti = r.order[q];
                     if (ti < 0 || ti >= n) { errors++; continue; }
                     seen_tri[ti]++;
                     const float *v = verts + 9 * (size_t)ti;
                     for (int c = 0; c < 3; c++)
                         for (int a = 0; a < 3; a++)
-                            if (v[3 * c + a] < box[a] || v[3 * c + a] > box[3 + a]) errors++;
+                            if (!(v[3 * c + a] > lo[a] || v[3 * c + a] == lo[a]) || !(v[3 * c + a] < hi[a] || v[3 * c + a] == hi[a])) errors++;
                 }
-            } else if (link >= 0) {
-                if (link >= (int)r.pairs.size() || link <= (int)pi) { errors++; continue; }  // children come later
-                seen_pair[link]++;
-                const rtbvh::Pair &ch = r.pairs[link];
-                for (int a = 0; a < 3; a++) {  // child boxes inside the parent's box for that side (up to padding)
-                    float lo = std::min(ch.lbox[a], ch.rbox[a]), hi = std::max(ch.lbox[3 + a], ch.rbox[3 + a]);
-                    if (ch.llink == -1 && ch.lcount == 0) { lo = ch.rbox[a]; hi = ch.rbox[3 + a]; }
-                    if (ch.rlink == -1 && ch.rcount == 0) { lo = ch.lbox[a]; hi = ch.lbox[3 + a]; }
-                    float tol = 1e-5f * std::max(1.f, std::max(fabsf(lo), fabsf(hi)));
-                    if (lo < box[a] - tol || hi > box[3 + a] + tol) errors++;
+            } else {
+                if (link >= (int)r.nodes.size() || link <= (int)ni) { errors++; continue; }  // children come later
+                seen_node[link]++;
+                // every decoded grandchild box must lie inside this decoded child box
+                const rtbvh::Node4 &ch = r.nodes[link];
+                for (int g = 0; g < 4; g++) {
+                    if (ch.link[g] == rtbvh::kNoChild) continue;
+                    float glo[3], ghi[3];
+                    child_box(ch, g, glo, ghi);
+                    for (int a = 0; a < 3; a++) {
+                        float tol = 1e-2f * (hi[a] - lo[a]) + 1e-6f;  // the child's own grid is finer than the parent's cell
+                        if (glo[a] < lo[a] - tol || ghi[a] > hi[a] + tol) errors++;
+                    }
                 }
             }
         }
     }
     for (int i = 0; i < n; i++) if (seen_tri[i] != 1) errors++;
-    for (size_t i = 0; i < r.pairs.size(); i++) if (seen_pair[i] != 1) errors++;
-    out8[3] = max_leaf;
-    out8[4] = errors;
+    for (size_t i = 0; i < r.nodes.size(); i++) if (seen_node[i] != 1) errors++;
+    out10[3] = max_leaf;
+    out10[4] = errors;
     if (errors) return 0;
     // CPU walk with the kernel's control flow vs exhaustive search
     std::vector<Tri> tris(n);
@@ -99,37 +117,61 @@ int rt_bvh_selfcheck(const float *verts, int n, int n_rays, const float *o3, con
         V3 p0{q[0], q[1], q[2]}, p1{q[3], q[4], q[5]}, p2{q[6], q[7], q[8]};
         tris[k].p0 = p0; tris[k].e1 = sub(p0, p1); tris[k].e2 = sub(p2, p0); tris[k].n = cross(tris[k].e1, tris[k].e2);
     }
-    int64_t mism = 0, max_stack = 0, max_steps = 0;
+    int64_t mism = 0, max_stack = 0, max_steps = 0, sum_inner = 0, sum_leaf = 0, sum_tri = 0;
+    std::vector<int> stack(r.stack_bound + 8);
     for (int i = 0; i < n_rays; i++) {
         V3 o{o3[3 * i], o3[3 * i + 1], o3[3 * i + 2]}, d{d3[3 * i], d3[3 * i + 1], d3[3 * i + 2]};
         auto clampinv = [](float x) { return 1.f / ((fabsf(x) < FLT_EPSILON) ? copysignf(FLT_EPSILON, x) : x); };
         V3 inv{clampinv(d.x), clampinv(d.y), clampinv(d.z)};
         float tmax = FLT_MAX, t;
-        int best = -1, sp = 0, node = 0, stack[64];
+        int best = -1, sp = 0, cur = 0;
         int64_t steps = 0;
-        while (true) {
-            if (++steps > 1000000) { mism += 1000000; break; }
-            const rtbvh::Pair &p = r.pairs[node];
-            float el, er;
-            bool hl = box_hit(o, inv, p.lbox, tmax, el), hr = box_hit(o, inv, p.rbox, tmax, er);
-            if (hl && p.lcount > 0) for (int k = p.llink; k < p.llink + p.lcount; k++) if (tri_hit(tris[k], o, d, tmax, t)) { tmax = t; best = k; }
-            if (hr && p.rcount > 0) for (int k = p.rlink; k < p.rlink + p.rcount; k++) if (tri_hit(tris[k], o, d, tmax, t)) { tmax = t; best = k; }
-            bool il = hl && p.lcount == 0 && p.llink >= 0, ir = hr && p.rcount == 0 && p.rlink >= 0;
-            if (il && ir) {
-                int nr = el > er ? p.rlink : p.llink, fr = el > er ? p.llink : p.rlink;
-                if (sp >= 64) { mism += 1000000; break; }
-                stack[sp++] = fr; node = nr;
+        bool bad = false;
+        while (cur != rtbvh::kNoChild) {
+            if (++steps > 1000000) { bad = true; break; }
+            if (cur >= 0) {
+                sum_inner++;
+                const rtbvh::Node4 &nd = r.nodes[cur];
+                uint32_t key[4];
+                int lnk[4];
+                for (int k = 0; k < 4; k++) {
+                    float lo[3], hi[3], e;
+                    child_box(nd, k, lo, hi);
+                    bool h = box_hit(o, inv, lo, hi, tmax, e) && nd.link[k] != rtbvh::kNoChild;
+                    float ee = fmaxf(e, 0.f);
+                    uint32_t bits;
+                    memcpy(&bits, &ee, 4);
+                    key[k] = h ? bits : 0xffffffffu;
+                    lnk[k] = nd.link[k];
+                }
+                auto cswap = [&](int a, int b) { if (key[b] < key[a]) { std::swap(key[a], key[b]); std::swap(lnk[a], lnk[b]); } };
+                cswap(0, 1); cswap(2, 3); cswap(0, 2); cswap(1, 3); cswap(1, 2);
+                for (int k = 3; k >= 1; k--)
+                    if (key[k] != 0xffffffffu) {
+                        if (sp >= (int)stack.size()) { bad = true; break; }
+                        stack[sp++] = lnk[k];
+                    }
+                if (bad) break;
                 if (sp > max_stack) max_stack = sp;
-            } else if (il) node = p.llink;
-            else if (ir) node = p.rlink;
-            else { if (sp == 0) break; node = stack[--sp]; }
+                if (key[0] != 0xffffffffu) cur = lnk[0];
+                else cur = sp > 0 ? stack[--sp] : rtbvh::kNoChild;
+            } else {
+                int ref = ~cur, first = ref >> 3, count = ref & 7;
+                sum_leaf++;
+                sum_tri += count;
+                for (int k = first; k < first + count; k++) if (tri_hit(tris[k], o, d, tmax, t)) { tmax = t; best = k; }
+                cur = sp > 0 ? stack[--sp] : rtbvh::kNoChild;
+            }
         }
+        if (bad) { mism += 1000000; continue; }
         if (steps > max_steps) max_steps = steps;
         float bt = FLT_MAX; int bb = -1;
         for (int k = 0; k < n; k++) if (tri_hit(tris[k], o, d, bt, t)) { bt = t; bb = k; }
         if ((bb < 0) != (best < 0) || (bb >= 0 && bt != tmax)) mism++;
     }
-    out8[5] = mism; out8[6] = max_stack; out8[7] = max_steps;
+    out10[5] = mism; out10[6] = max_stack; out10[7] = max_steps;
+    if (getenv("RT_BVH_STATS") && n_rays > 0)
+        fprintf(stderr, "bvh walk: inner %.2f leaf %.2f tri %.2f per ray\n", (double)sum_inner / n_rays, (double)sum_leaf / n_rays, (double)sum_tri / n_rays);
     return 0;
 }
 }

@@ -35,6 +35,7 @@
 #include <cstring>
 #include <memory>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -61,12 +62,14 @@ int fail(const std::string &msg) {
 
 constexpr int kW = RT_NUM_WORKING_PATHS;
 constexpr int kBlock = 256;       // 4 waves per workgroup
-constexpr int kMaxStackDepth = 40; // LDS traversal stack = tree depth entries per lane (dynamic LDS), capped here
+constexpr int kLdsStack = 16;          // traversal stack entries kept in LDS per lane
+constexpr int kOverStride = 1 << 19;   // lanes of the overflow stack (>= lanes of the largest trace grid)
+constexpr int kMaxStackBound = 160;    // deepest traversal stack a scene may need (3 per level + 1)
 }  // namespace
 
 // ============================================================================ device structures
 struct DScene {
-    const float4 *pairs;   // 4 x float4 per pair record
+    const float4 *nodes;   // 4 x float4 per 4-wide node record (rt_bvh.h)
     const float4 *tris;    // 3 x float4 per triangle, leaf order
     const int2 *tri_info;  // leaf order: {material index, light index or -1}
     const Material *mats;
@@ -541,7 +544,19 @@ __device__ __forceinline__ bool box_hit(V3 o, V3 inv, float lox, float loy, floa
     return t_in <= t_out && t_out >= 0.f && t_in <= tmax;
 }
 
-constexpr int kEntryDone = (int)0x80000000;  // "nothing left to visit" marker for a lane
+constexpr int kEntryDone = (int)0x80000000;  // "nothing left to visit" marker for a lane (== rtbvh::kNoChild)
+// Traversal stack: the first `cap` entries of a lane live in its LDS column, deeper ones (rare: the
+// bound is 3 per tree level, the typical depth under 10) in a per-lane column of a global overflow
+// buffer, so LDS use -- and with it occupancy -- is set by the common case, not the worst case.
+__device__ __forceinline__ void stack_push(int *lds_col, int *over_col, int &sp, int cap, int v) {
+    if (sp < cap) lds_col[sp * kBlock] = v;
+    else over_col[(size_t)(sp - cap) * kOverStride] = v;
+    sp++;
+}
+__device__ __forceinline__ int stack_pop(int *lds_col, int *over_col, int &sp, int cap) {
+    sp--;
+    return sp < cap ? lds_col[sp * kBlock] : over_col[(size_t)(sp - cap) * kOverStride];
+}
 constexpr int kRefillAt = 40;                // finalise + refill once <= this many lanes still traverse
 __device__ __forceinline__ int leaf_ref(int first, int count) { return ~((first << 3) | count); }
 
@@ -563,12 +578,13 @@ struct TraceParams {
 // (closest hit, ch()) and the shadow ray of every slot that spawned one (any hit, ah()).  A lane
 // carries its kind with its ray, so closest-hit and any-hit rays share waves; the two kinds differ
 // only in what a triangle hit does and in how the finished ray is finalised.
-// LDS layout (dynamic): [stack: depth x kBlock ints][pending: kBlock ints]
+// LDS layout (dynamic): [stack: stack_cap x kBlock ints][pending: kBlock ints]
 template <int MODE>
-__global__ void __launch_bounds__(kBlock, 8) k_trace(DScene sc, DPools p, TraceParams tp, int stack_depth) {
+__global__ void __launch_bounds__(kBlock, 8) k_trace(DScene sc, DPools p, TraceParams tp, int stack_cap, int *overflow) {
     extern __shared__ int s_lds[];
     int *stack = s_lds + threadIdx.x;
-    volatile int *pend = s_lds + stack_depth * kBlock + (threadIdx.x & ~63);  // this wave's 64 entries
+    int *over = overflow + (blockIdx.x * kBlock + threadIdx.x);
+    volatile int *pend = s_lds + stack_cap * kBlock + (threadIdx.x & ~63);  // this wave's 64 entries
     const int total = tp.total;
     const int n_chunks = (total + 63) >> 6;                            // chunks per ray kind
     const int all_chunks = MODE == MODE_POOL ? 2 * n_chunks : n_chunks;  // [closest chunks][any chunks]
@@ -699,33 +715,51 @@ __global__ void __launch_bounds__(kBlock, 8) k_trace(DScene sc, DPools p, TraceP
                 continue;
             }
         }
-        // ---- inner phase: step through pair records until no lane holds an inner entry
+        // ---- inner phase: step through 4-wide node records until no lane holds an inner entry
         while (__ballot(cur >= 0) != 0) {
             if (cur >= 0) {
-                const float4 *q = sc.pairs + 4 * (size_t)cur;
+                const float4 *q = sc.nodes + 4 * (size_t)cur;
                 float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
-                int llink = __float_as_int(q3.x), rlink = __float_as_int(q3.y);
-                int lcount = __float_as_int(q3.z), rcount = __float_as_int(q3.w);
-                float el, er;
-                bool hl = box_hit(o, inv, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tmax, el);
-                bool hr = box_hit(o, inv, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tmax, er);
-                // child entries: inner pair index, leaf reference, or "empty" (kEntryDone)
-                int cl = lcount > 0 ? leaf_ref(llink, lcount) : (llink >= 0 ? llink : kEntryDone);
-                int cr = rcount > 0 ? leaf_ref(rlink, rcount) : (rlink >= 0 ? rlink : kEntryDone);
-                hl = hl && cl != kEntryDone;
-                hr = hr && cr != kEntryDone;
-                if (hl && hr) {
-                    bool left_first = !(el > er);
-                    stack[sp * kBlock] = left_first ? cr : cl;
-                    sp++;
-                    cur = left_first ? cl : cr;
-                } else if (hl) {
-                    cur = cl;
-                } else if (hr) {
-                    cur = cr;
+                const unsigned exps = __float_as_uint(q0.w);
+                const float cx = __uint_as_float((exps & 0xffu) << 23);
+                const float cy = __uint_as_float(((exps >> 8) & 0xffu) << 23);
+                const float cz = __uint_as_float(((exps >> 16) & 0xffu) << 23);
+                const unsigned lox = __float_as_uint(q2.x), loy = __float_as_uint(q2.y), loz = __float_as_uint(q2.z);
+                const unsigned hix = __float_as_uint(q2.w), hiy = __float_as_uint(q3.x), hiz = __float_as_uint(q3.y);
+                const int links[4] = {__float_as_int(q1.x), __float_as_int(q1.y), __float_as_int(q1.z), __float_as_int(q1.w)};
+                // (entry distance, link) of every child the ray may enter; a miss sorts last
+                unsigned key[4];
+                int lnk[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int sh = 8 * k;
+                    // bound = origin + float(q) * cell : the expression the builder verified (rt_bvh.h)
+                    float bx0 = q0.x + (float)((lox >> sh) & 0xffu) * cx, bx1 = q0.x + (float)((hix >> sh) & 0xffu) * cx;
+                    float by0 = q0.y + (float)((loy >> sh) & 0xffu) * cy, by1 = q0.y + (float)((hiy >> sh) & 0xffu) * cy;
+                    float bz0 = q0.z + (float)((loz >> sh) & 0xffu) * cz, bz1 = q0.z + (float)((hiz >> sh) & 0xffu) * cz;
+                    float e;
+                    bool h = box_hit(o, inv, bx0, by0, bz0, bx1, by1, bz1, tmax, e) && links[k] != kEntryDone;
+                    key[k] = h ? __float_as_uint(fmaxf(e, 0.f)) : 0xffffffffu;
+                    lnk[k] = links[k];
+                }
+                // sorting network on 4 (key, link) pairs, ascending by entry distance
+#define RT_CSWAP(a, b)                                                     \
+    {                                                                      \
+        bool sw = key[b] < key[a];                                         \
+        unsigned ka = sw ? key[b] : key[a], kb = sw ? key[a] : key[b];     \
+        int la = sw ? lnk[b] : lnk[a], lb = sw ? lnk[a] : lnk[b];          \
+        key[a] = ka; key[b] = kb; lnk[a] = la; lnk[b] = lb;                \
+    }
+                RT_CSWAP(0, 1) RT_CSWAP(2, 3) RT_CSWAP(0, 2) RT_CSWAP(1, 3) RT_CSWAP(1, 2)
+#undef RT_CSWAP
+                // far children first onto the stack, nearest becomes the current entry
+                if (key[3] != 0xffffffffu) { stack_push(stack, over, sp, stack_cap, lnk[3]); }
+                if (key[2] != 0xffffffffu) { stack_push(stack, over, sp, stack_cap, lnk[2]); }
+                if (key[1] != 0xffffffffu) { stack_push(stack, over, sp, stack_cap, lnk[1]); }
+                if (key[0] != 0xffffffffu) {
+                    cur = lnk[0];
                 } else if (sp > 0) {
-                    sp--;
-                    cur = stack[sp * kBlock];
+                    cur = stack_pop(stack, over, sp, stack_cap);
                 } else {
                     cur = kEntryDone;
                 }
@@ -758,8 +792,7 @@ __global__ void __launch_bounds__(kBlock, 8) k_trace(DScene sc, DPools p, TraceP
             if (stop) {
                 cur = kEntryDone;
             } else if (sp > 0) {
-                sp--;
-                cur = stack[sp * kBlock];
+                cur = stack_pop(stack, over, sp, stack_cap);
             } else {
                 cur = kEntryDone;
             }
@@ -798,8 +831,8 @@ __global__ void k_copy_f4(const float4 *__restrict__ src, float4 *__restrict__ d
 // ============================================================================ host side
 struct rt_scene {
     int device = 0;
-    int n_tris = 0, n_pairs = 0, max_depth = 0, n_leaves = 0, n_lights = 0, n_mats = 0;
-    float4 *d_pairs = nullptr;
+    int n_tris = 0, n_nodes = 0, max_depth = 0, stack_bound = 1, n_leaves = 0, n_lights = 0, n_mats = 0;
+    float4 *d_nodes = nullptr;
     float4 *d_tris = nullptr;
     int2 *d_tri_info = nullptr;
     Material *d_mats = nullptr;
@@ -811,7 +844,7 @@ struct rt_scene {
     std::vector<int> h_inverse;   // original -> leaf order
     DScene dev() const {
         DScene s;
-        s.pairs = d_pairs;
+        s.nodes = d_nodes;
         s.tris = d_tris;
         s.tri_info = d_tri_info;
         s.mats = d_mats;
@@ -887,6 +920,7 @@ const std::vector<uint32_t> &jump_powers() {
 struct Context {
     int device = -1;
     int n = 0;
+    int lane = 0;  // concurrent sub-shards of one render use separate contexts (and streams)
     DPools pools{};
     std::vector<void *> allocs;
     DCounters *d_ctr = nullptr;
@@ -915,18 +949,19 @@ int dev_alloc(Context &c, T *&ptr, size_t count) {
     return 0;
 }
 
-int get_context(int n, Context **out) {
+int get_context(int n, int lane, Context **out) {
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lock(g_ctx_mutex);
     for (auto &c : g_contexts)
-        if (c->device == dev && c->n == n) {
+        if (c->device == dev && c->n == n && c->lane == lane) {
             *out = c.get();
             return 0;
         }
     auto c = std::make_unique<Context>();
     c->device = dev;
     c->n = n;
+    c->lane = lane;
     DPools &p = c->pools;
     float **fptrs[] = {&p.ox, &p.oy, &p.oz, &p.dx, &p.dy, &p.dz, &p.hpx, &p.hpy, &p.hpz, &p.hnx, &p.hny, &p.hnz, &p.br, &p.bg, &p.bb,
                        &p.sox, &p.soy, &p.soz, &p.sdx, &p.sdy, &p.sdz, &p.stmax, &p.slr, &p.slg, &p.slb};
@@ -956,6 +991,44 @@ int get_context(int n, Context **out) {
 
 int grid_for(int n) { return (n + kBlock - 1) / kBlock; }
 
+// Global overflow part of the traversal stacks: `levels` entries for each of kOverStride lanes, one
+// buffer per device, grown on demand (never shrunk).  Shared by concurrent renders on a device: every
+// lane of every trace grid indexes its own column (grids are at most kOverStride lanes), and a lane
+// only reads back what it pushed itself.
+struct OverflowBuf {
+    int device = -1;
+    int levels = 0;
+    int *ptr = nullptr;
+};
+std::mutex g_over_mutex;
+std::vector<OverflowBuf> g_over;
+int ensure_overflow(int levels, int **out) {
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    levels = std::max(levels, 1);
+    std::lock_guard<std::mutex> lock(g_over_mutex);
+    for (auto &b : g_over)
+        if (b.device == dev) {
+            if (b.levels < levels) {
+                int *np = nullptr;
+                HIP_TRY(hipMalloc((void **)&np, sizeof(int) * (size_t)levels * kOverStride));
+                // the old buffer may still be in use by a concurrent render: leak-free swap is not worth
+                // the bookkeeping; it is released at process exit
+                b.ptr = np;
+                b.levels = levels;
+            }
+            *out = b.ptr;
+            return 0;
+        }
+    OverflowBuf b;
+    b.device = dev;
+    b.levels = levels;
+    HIP_TRY(hipMalloc((void **)&b.ptr, sizeof(int) * (size_t)levels * kOverStride));
+    g_over.push_back(b);
+    *out = b.ptr;
+    return 0;
+}
+
 int ensure_rng(Context &c, uint64_t seed, int slot_lo, hipStream_t st, double *seconds) {
     const size_t bytes = sizeof(uint32_t) * (size_t)c.n;
     uint32_t *parts[6] = {c.pools.rd, c.pools.r0, c.pools.r1, c.pools.r2, c.pools.r3, c.pools.r4};
@@ -984,7 +1057,7 @@ int ensure_rng(Context &c, uint64_t seed, int slot_lo, hipStream_t st, double *s
 
 int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width, int height, int spp,
                       int max_bounces, uint64_t seed, int shard_index, int shard_count, uint32_t flags,
-                      float *d_sum, hipStream_t st, rt_stats *stats) {
+                      float *d_sum, hipStream_t st, rt_stats *stats, int ctx_lane = 0) {
     if (!scene || !camera || !d_sum) return fail("rt_render_shard: null argument");
     if (width <= 0 || height <= 0 || spp <= 0 || max_bounces < 0) return fail("rt_render_shard: bad dimensions");
     if (shard_count <= 0 || kW % shard_count != 0 || shard_index < 0 || shard_index >= shard_count)
@@ -998,7 +1071,7 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
     const int n = kW / shard_count;
     const int slot_lo = shard_index * n;
     Context *cp = nullptr;
-    if (get_context(n, &cp)) return 1;
+    if (get_context(n, ctx_lane, &cp)) return 1;
     Context &c = *cp;
     double rng_seconds = 0.0;
     if (ensure_rng(c, seed, slot_lo, st, &rng_seconds)) return 1;
@@ -1017,8 +1090,10 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
         HIP_TRY(hipMemsetAsync(c.d_rows, 0, sizeof(DWaveRow) * (size_t)c.n_rows, st));
         HIP_TRY(hipStreamSynchronize(st));  // h_ctr[0] is reused as a snapshot slot below
     }
-    const int stack_depth = std::max(1, scene->max_depth);
-    const size_t lds_bytes = sizeof(int) * (size_t)kBlock * (size_t)(stack_depth + 1);  // stack + pending
+    const int stack_cap = std::min(kLdsStack, std::max(1, scene->stack_bound));
+    const size_t lds_bytes = sizeof(int) * (size_t)kBlock * (size_t)(stack_cap + 1);  // stack + pending
+    int *d_over = nullptr;
+    if (ensure_overflow(scene->stack_bound - stack_cap, &d_over)) return 1;
     hipLaunchKernelGGL(k_pool_init, dim3(grid_for(n)), dim3(kBlock), 0, st, c.pools, n, max_bounces);
     HIP_TRY(hipGetLastError());
 
@@ -1091,7 +1166,7 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
                 else
                     hipLaunchKernelGGL(k_advance<false>, grid, block, 0, st, sc, c.pools, cam, ap, d_sum, c.d_ctr, c.d_rows);
                 HIP_TRY(hipEventRecord(e1, st));
-                hipLaunchKernelGGL(k_trace<MODE_POOL>, grid_trace, block, lds_bytes, st, sc, c.pools, tpp, stack_depth);
+                hipLaunchKernelGGL(k_trace<MODE_POOL>, grid_trace, block, lds_bytes, st, sc, c.pools, tpp, stack_cap, d_over);
                 HIP_TRY(hipEventRecord(e2, st));
                 HIP_TRY(hipEventRecord(e3, st));
             } else {
@@ -1099,7 +1174,7 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
                     hipLaunchKernelGGL(k_advance<true>, grid, block, 0, st, sc, c.pools, cam, ap, d_sum, c.d_ctr, c.d_rows);
                 else
                     hipLaunchKernelGGL(k_advance<false>, grid, block, 0, st, sc, c.pools, cam, ap, d_sum, c.d_ctr, c.d_rows);
-                hipLaunchKernelGGL(k_trace<MODE_POOL>, grid_trace, block, lds_bytes, st, sc, c.pools, tpp, stack_depth);
+                hipLaunchKernelGGL(k_trace<MODE_POOL>, grid_trace, block, lds_bytes, st, sc, c.pools, tpp, stack_cap, d_over);
             }
             rounds++;
         }
@@ -1133,7 +1208,7 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
                 HIP_TRY(hipStreamSynchronize(st));
                 if (c.h_ctr[0].round_shades == 0) break;
             }
-            hipLaunchKernelGGL(k_trace<MODE_POOL>, grid_trace, block, lds_bytes, st, sc, c.pools, tpp, stack_depth);
+            hipLaunchKernelGGL(k_trace<MODE_POOL>, grid_trace, block, lds_bytes, st, sc, c.pools, tpp, stack_cap, d_over);
             HIP_TRY(hipGetLastError());
         }
     }
@@ -1170,7 +1245,7 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
         stats->shadow_adds = (int64_t)fin[C_SHADOW_ADD];
         stats->rr_draws = (int64_t)fin[C_RR];
         stats->iterations = rounds;
-        stats->bvh_nodes = scene->n_pairs;
+        stats->bvh_nodes = scene->n_nodes;
         stats->bvh_depth = scene->max_depth;
         stats->seconds_render = ms_total * 1e-3;
         stats->seconds_rng_init = rng_seconds;
@@ -1182,6 +1257,62 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
         stats->seconds_advance = t_adv * 1e-3 * scale_up;
         stats->launches_trace = rounds;
         stats->reserved[0] = n_sampled;
+    }
+    return 0;
+}
+
+// A shard may be rendered as `split` interleaved sub-shards on separate HIP streams (one host thread
+// each): slot sets are independent, so the sub-shards only meet in the framebuffer atomics, and the
+// tail of one sub-shard's persistent trace kernel overlaps the head of the other's.
+int render_overlapped(const rt_scene *scene, const rt_camera *camera, int width, int height, int spp,
+                      int max_bounces, uint64_t seed, int shard_index, int shard_count, uint32_t flags,
+                      float *d_sum, hipStream_t st, rt_stats *stats) {
+    int split = 1;
+    if (const char *e = getenv("RT_SPLIT")) split = std::max(1, std::min(8, atoi(e)));
+    while (split > 1 && (shard_count <= 0 || kW % (shard_count * split) != 0 || kW / (shard_count * split) < 4096)) split >>= 1;
+    if (split <= 1)
+        return render_shard_impl(scene, camera, width, height, spp, max_bounces, seed, shard_index, shard_count, flags,
+                                 d_sum, st, stats);
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    HIP_TRY(hipStreamSynchronize(st));  // the caller zeroed d_sum on its stream
+    std::vector<rt_stats> sub(split);
+    std::vector<int> rc(split, 0);
+    std::vector<std::string> err(split);
+    std::vector<std::thread> th;
+    for (int k = 0; k < split; k++)
+        th.emplace_back([&, k] {
+            if (hipSetDevice(dev) != hipSuccess) { rc[k] = 1; err[k] = "hipSetDevice failed"; return; }
+            hipStream_t s2;
+            if (hipStreamCreateWithFlags(&s2, hipStreamNonBlocking) != hipSuccess) { rc[k] = 1; err[k] = "stream create failed"; return; }
+            rc[k] = render_shard_impl(scene, camera, width, height, spp, max_bounces, seed, shard_index * split + k,
+                                      shard_count * split, flags, d_sum, s2, &sub[k], k + 1);
+            if (rc[k]) err[k] = g_last_error;
+            (void)hipStreamSynchronize(s2);
+            (void)hipStreamDestroy(s2);
+        });
+    for (auto &t : th) t.join();
+    for (int k = 0; k < split; k++)
+        if (rc[k]) return fail(err[k]);
+    if (stats) {
+        rt_stats tot = sub[0];
+        for (int k = 1; k < split; k++) {
+            tot.camera_rays += sub[k].camera_rays;
+            tot.shade_events += sub[k].shade_events;
+            tot.closest_rays += sub[k].closest_rays;
+            tot.any_rays += sub[k].any_rays;
+            tot.emission_adds += sub[k].emission_adds;
+            tot.shadow_adds += sub[k].shadow_adds;
+            tot.rr_draws += sub[k].rr_draws;
+            tot.iterations += sub[k].iterations;
+            tot.launches_trace += sub[k].launches_trace;
+            tot.seconds_trace += sub[k].seconds_trace;
+            tot.seconds_advance += sub[k].seconds_advance;
+            tot.seconds_render = std::max(tot.seconds_render, sub[k].seconds_render);
+            tot.seconds_rng_init = std::max(tot.seconds_rng_init, sub[k].seconds_rng_init);
+            tot.reserved[0] += sub[k].reserved[0];
+        }
+        *stats = tot;
     }
     return 0;
 }
@@ -1222,11 +1353,13 @@ int rt_scene_create(const float *tri_p0p1p2, int n_tris, const int32_t *tri_mate
     auto sc = std::make_unique<rt_scene>();
     HIP_TRY(hipGetDevice(&sc->device));
     rtbvh::Result bvh = rtbvh::build(tri_p0p1p2, n_tris);
-    if (bvh.max_depth > kMaxStackDepth)
+    if (!bvh.ok) return fail("rt_scene_create: BVH build produced an unreferenceable leaf");
+    if (bvh.stack_bound > kMaxStackBound)
         return fail("rt_scene_create: BVH depth " + std::to_string(bvh.max_depth) + " exceeds the traversal stack");
     sc->n_tris = n_tris;
-    sc->n_pairs = (int)bvh.pairs.size();
+    sc->n_nodes = (int)bvh.nodes.size();
     sc->max_depth = bvh.max_depth;
+    sc->stack_bound = bvh.stack_bound;
     sc->n_leaves = bvh.num_leaves;
     sc->n_lights = n_lights;
     sc->n_mats = n_materials;
@@ -1259,8 +1392,8 @@ int rt_scene_create(const float *tri_p0p1p2, int n_tris, const int32_t *tri_mate
     static_assert(sizeof(Light) == sizeof(rt_light), "light layout");
     static_assert(sizeof(Material) == sizeof(rt_material), "material layout");
     static_assert(sizeof(Camera) == sizeof(rt_camera), "camera layout");
-    HIP_TRY(hipMalloc((void **)&sc->d_pairs, sizeof(rtbvh::Pair) * bvh.pairs.size()));
-    HIP_TRY(hipMemcpy(sc->d_pairs, bvh.pairs.data(), sizeof(rtbvh::Pair) * bvh.pairs.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc((void **)&sc->d_nodes, sizeof(rtbvh::Node4) * bvh.nodes.size()));
+    HIP_TRY(hipMemcpy(sc->d_nodes, bvh.nodes.data(), sizeof(rtbvh::Node4) * bvh.nodes.size(), hipMemcpyHostToDevice));
     HIP_TRY(hipMalloc((void **)&sc->d_tris, sizeof(float) * trec.size()));
     HIP_TRY(hipMemcpy(sc->d_tris, trec.data(), sizeof(float) * trec.size(), hipMemcpyHostToDevice));
     HIP_TRY(hipMalloc((void **)&sc->d_tri_info, sizeof(int2) * info.size()));
@@ -1287,7 +1420,7 @@ int rt_scene_create(const float *tri_p0p1p2, int n_tris, const int32_t *tri_mate
 
 void rt_scene_destroy(rt_scene *scene) {
     if (!scene) return;
-    (void)hipFree(scene->d_pairs);
+    (void)hipFree(scene->d_nodes);
     (void)hipFree(scene->d_tris);
     (void)hipFree(scene->d_tri_info);
     (void)hipFree(scene->d_mats);
@@ -1299,7 +1432,7 @@ void rt_scene_destroy(rt_scene *scene) {
 
 int rt_scene_info(const rt_scene *scene, int64_t out[4]) {
     if (!scene || !out) return fail("rt_scene_info: null argument");
-    out[0] = scene->n_pairs;
+    out[0] = scene->n_nodes;
     out[1] = scene->n_tris;
     out[2] = scene->max_depth;
     out[3] = scene->n_leaves;
@@ -1344,7 +1477,7 @@ int rt_camera_make(const float lookfrom[3], const float lookat[3], const float u
 int rt_render_shard(const rt_scene *scene, const rt_camera *camera, int width, int height, int num_samples,
                     int max_bounces, uint64_t seed, int shard_index, int shard_count, uint32_t flags,
                     float *d_sum_rgb, void *stream, rt_stats *stats) {
-    return render_shard_impl(scene, camera, width, height, num_samples, max_bounces, seed, shard_index, shard_count,
+    return render_overlapped(scene, camera, width, height, num_samples, max_bounces, seed, shard_index, shard_count,
                              flags, d_sum_rgb, (hipStream_t)stream, stats);
 }
 
@@ -1367,7 +1500,7 @@ int rt_render(const rt_scene *scene, const rt_camera *camera, int width, int hei
     int rc = 0;
     do {
         if (hipMemsetAsync(d_fb, 0, bytes, nullptr) != hipSuccess) { rc = fail("rt_render: memset failed"); break; }
-        rc = render_shard_impl(scene, camera, width, height, num_samples, max_bounces, seed, 0, 1, flags, d_fb,
+        rc = render_overlapped(scene, camera, width, height, num_samples, max_bounces, seed, 0, 1, flags, d_fb,
                                nullptr, stats);
         if (rc) break;
         rc = rt_post_process(d_fb, width * height, num_samples, nullptr);
@@ -1396,7 +1529,9 @@ int rt_trace_closest(const rt_scene *scene, int n, const float *origin_xyz, cons
     HIP_TRY(hipMemcpy(d_d, dir_xyz, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d_tm, tmax, sizeof(float) * (size_t)n, hipMemcpyHostToDevice));
     const int test_grid = std::min(grid_for(n), 2048);
-    const int stack_depth = std::max(1, scene->max_depth);
+    const int stack_cap = std::min(kLdsStack, std::max(1, scene->stack_bound));
+    int *d_over = nullptr;
+    if (ensure_overflow(scene->stack_bound - stack_cap, &d_over)) return 1;
     {
         TraceParams tp{};
         tp.total = n;
@@ -1410,7 +1545,7 @@ int rt_trace_closest(const rt_scene *scene, int n, const float *origin_xyz, cons
         tp.out_v = d_v;
         DPools none{};
         hipLaunchKernelGGL(k_trace<MODE_TEST_CLOSEST>, dim3(test_grid), dim3(kBlock),
-                           sizeof(int) * kBlock * (size_t)(stack_depth + 1), nullptr, scene->dev(), none, tp, stack_depth);
+                           sizeof(int) * kBlock * (size_t)(stack_cap + 1), nullptr, scene->dev(), none, tp, stack_cap, d_over);
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(hit_tri, d_h, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost));
@@ -1444,7 +1579,9 @@ int rt_trace_any(const rt_scene *scene, int n, const float *origin_xyz, const fl
     HIP_TRY(hipMemcpy(d_tm, tmax, sizeof(float) * (size_t)n, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d_e, excl.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice));
     const int test_grid = std::min(grid_for(n), 2048);
-    const int stack_depth = std::max(1, scene->max_depth);
+    const int stack_cap = std::min(kLdsStack, std::max(1, scene->stack_bound));
+    int *d_over = nullptr;
+    if (ensure_overflow(scene->stack_bound - stack_cap, &d_over)) return 1;
     {
         TraceParams tp{};
         tp.total = n;
@@ -1455,7 +1592,7 @@ int rt_trace_any(const rt_scene *scene, int n, const float *origin_xyz, const fl
         tp.out_i = d_occ;
         DPools none{};
         hipLaunchKernelGGL(k_trace<MODE_TEST_ANY>, dim3(test_grid), dim3(kBlock),
-                           sizeof(int) * kBlock * (size_t)(stack_depth + 1), nullptr, scene->dev(), none, tp, stack_depth);
+                           sizeof(int) * kBlock * (size_t)(stack_cap + 1), nullptr, scene->dev(), none, tp, stack_cap, d_over);
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(occluded, d_occ, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost));

@@ -142,13 +142,14 @@ def _hostcheck():
 
 
 def _selfcheck(L, tris, ro, rd):
-    out = np.zeros(8, np.int64)
+    out = np.zeros(10, np.int64)
     tris = np.ascontiguousarray(tris, np.float32)
     ro = np.ascontiguousarray(ro, np.float32)
     rd = np.ascontiguousarray(rd, np.float32)
     L.rt_bvh_selfcheck(tris.ctypes.data, tris.shape[0], ro.shape[0], ro.ctypes.data if len(ro) else None,
                        rd.ctypes.data if len(rd) else None, out.ctypes.data)
-    return dict(zip(["pairs", "leaves", "depth", "maxleaf", "errors", "mismatch", "maxstack", "maxsteps"], out.tolist()))
+    return dict(zip(["nodes", "leaves", "depth", "maxleaf", "errors", "mismatch", "maxstack", "maxsteps", "stack_bound",
+                     "bin_depth"], out.tolist()))
 
 
 def test_product_bvh_structure_and_cpu_walk(oracle, bunny_matte):
@@ -158,8 +159,8 @@ def test_product_bvh_structure_and_cpu_walk(oracle, bunny_matte):
     ao, ad = raygen.axis_aligned_rays(300, seed=4)
     r = _selfcheck(L, bunny_matte.tris, np.concatenate([ro, ao]), np.concatenate([rd, ad]))
     assert r["errors"] == 0 and r["mismatch"] == 0
-    assert r["depth"] <= 40 and r["maxleaf"] <= 4 and r["maxstack"] < r["depth"]
-    assert r["pairs"] + 1 == r["leaves"]  # binary tree: internal pairs + 1 leaves
+    assert r["depth"] <= 16 and r["maxleaf"] <= 4 and r["maxstack"] <= r["stack_bound"] <= 160
+    assert r["nodes"] < r["leaves"]  # 4-wide: fewer node records than leaves
 
 
 @pytest.mark.parametrize("n", [0, 1, 2, 3, 5, 64])
