@@ -17,7 +17,7 @@ import numpy as np
 from .scenes import SceneArrays
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "librtcuda_amd.so")
+LIB_PATH = os.path.join(_PKG, os.environ.get("RT_LIB_NAME", "librtcuda_amd.so"))  # RT_LIB_NAME: instrumented dev builds
 CSRC = os.path.join(_PKG, "csrc")
 
 W = 1 << 20  # RT_NUM_WORKING_PATHS

@@ -80,6 +80,18 @@ inline float cell_size(uint32_t exps, int axis) {
 }
 inline float decode(float origin, uint32_t q, float cell) { return origin + (float)q * cell; }
 
+// 2-wide alternative: both children's exact fp32 boxes (padded outward by 2 ulps) + both links in one
+// 64-byte record.  w0..w5 left box lo xyz / hi xyz, w6..w11 right box, w12 left link, w13 right link
+// (same link encoding as Node4), w14, w15 spare.  One node test costs ~1/3 of the VALU work of a
+// quantised 4-wide test, at about twice the number of 64-byte fetches per ray.
+struct Pair {
+    float lbox[6];
+    float rbox[6];
+    int32_t llink, rlink;
+    int32_t spare[2];
+};
+static_assert(sizeof(Pair) == 64, "pair record must be one 64-byte line");
+
 struct BinNode {
     Box box;         // exact (unpadded) box of the subtree
     int left = -1;   // children (binary) or -1
@@ -89,7 +101,9 @@ struct BinNode {
 };
 
 struct Result {
-    std::vector<Node4> nodes;
+    std::vector<Node4> nodes;    // 4-wide quantised records
+    std::vector<Pair> pairs;     // 2-wide full-precision records (same binary tree)
+    int pair_depth = 0;          // depth of the pair tree (= binary depth - 1, root pair = 1)
     std::vector<int32_t> order;  // leaf order -> original triangle index
     int max_depth = 0;           // depth of the 4-wide tree (root = 1)
     int bin_depth = 0;           // depth of the binary tree it was collapsed from
@@ -296,7 +310,12 @@ inline Result build(const float *verts, int n) {
     };
     if (n == 0) {
         res.nodes.push_back(empty_node());
+        Pair ep;
+        memset(&ep, 0, sizeof(ep));
+        ep.llink = ep.rlink = kNoChild;
+        res.pairs.push_back(ep);
         res.max_depth = 1;
+        res.pair_depth = 1;
         res.stack_bound = 1;
         return res;
     }
@@ -354,6 +373,57 @@ inline Result build(const float *verts, int n) {
         res.nodes[t.out_node] = nd;
     }
     res.stack_bound = 3 * res.max_depth + 1;
+    // ---- 2-wide records from the same binary tree
+    {
+        auto link_of = [&](int bn, std::vector<std::pair<int, int>> &todo, int &next) -> int32_t {
+            const BinNode &c = bin[bn];
+            if (c.left < 0) return leaf_ref(c.first, std::min(c.count, 7));
+            int idx = next++;
+            todo.push_back({bn, idx});
+            return idx;
+        };
+        auto set_box = [&](float *dst, const Box &b) {
+            for (int a = 0; a < 3; a++) {
+                dst[a] = pad_down(b.lo[a], 2);
+                dst[3 + a] = pad_up(b.hi[a], 2);
+            }
+        };
+        std::vector<std::pair<int, int>> todo;  // (binary node, pair index), depth-first
+        int next = 1;
+        Pair empty;
+        memset(&empty, 0, sizeof(empty));
+        empty.llink = empty.rlink = kNoChild;
+        res.pairs.assign(1, empty);
+        if (bin[0].left < 0) {  // single leaf: left child = the leaf, right child empty
+            set_box(res.pairs[0].lbox, bin[0].box);
+            res.pairs[0].llink = leaf_ref(bin[0].first, std::min(bin[0].count, 7));
+            res.pairs[0].rbox[0] = res.pairs[0].rbox[1] = res.pairs[0].rbox[2] = FLT_MAX;
+            res.pairs[0].rbox[3] = res.pairs[0].rbox[4] = res.pairs[0].rbox[5] = -FLT_MAX;
+            res.pair_depth = 1;
+        } else {
+            todo.push_back({0, 0});
+            std::vector<int> depth_of(1, 1);
+            while (!todo.empty()) {
+                auto [bn, pi] = todo.back();
+                todo.pop_back();
+                if ((int)res.pairs.size() < next) res.pairs.resize(next, empty);
+                if ((int)depth_of.size() < next) depth_of.resize(next, 0);
+                int d = depth_of[pi];
+                res.pair_depth = std::max(res.pair_depth, d);
+                const BinNode &b = bin[bn];
+                Pair p = empty;
+                set_box(p.lbox, bin[b.left].box);
+                set_box(p.rbox, bin[b.right].box);
+                int before = next;
+                p.rlink = link_of(b.right, todo, next);
+                p.llink = link_of(b.left, todo, next);  // left pushed last -> processed first
+                if ((int)res.pairs.size() < next) res.pairs.resize(next, empty);
+                if ((int)depth_of.size() < next) depth_of.resize(next, 0);
+                for (int k = before; k < next; k++) depth_of[k] = d + 1;
+                res.pairs[pi] = p;
+            }
+        }
+    }
     return res;
 }
 

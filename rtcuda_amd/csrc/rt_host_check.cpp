@@ -169,6 +169,53 @@ int rt_bvh_selfcheck(const float *verts, int n, int n_rays, const float *o3, con
         for (int k = 0; k < n; k++) if (tri_hit(tris[k], o, d, bt, t)) { bt = t; bb = k; }
         if ((bb < 0) != (best < 0) || (bb >= 0 && bt != tmax)) mism++;
     }
+    // ---- the 2-wide records of the same tree: same walk, two exact boxes per record
+    {
+        int64_t pair_inner = 0;
+        std::vector<int> pseen(r.pairs.size(), 0);
+        pseen[0] = 1;
+        for (size_t pi = 0; pi < r.pairs.size(); pi++)
+            for (int side = 0; side < 2; side++) {
+                int link = side ? r.pairs[pi].rlink : r.pairs[pi].llink;
+                if (link >= 0) { if (link >= (int)r.pairs.size() || link <= (int)pi) mism += 1000000; else pseen[link]++; }
+            }
+        for (size_t i = 0; i < r.pairs.size(); i++) if (pseen[i] != 1) mism += 1000000;
+        std::vector<int> pstack(r.pair_depth + 8);
+        for (int i = 0; i < n_rays && mism < 1000000; i++) {
+            V3 o{o3[3 * i], o3[3 * i + 1], o3[3 * i + 2]}, d{d3[3 * i], d3[3 * i + 1], d3[3 * i + 2]};
+            auto clampinv = [](float x) { return 1.f / ((fabsf(x) < FLT_EPSILON) ? copysignf(FLT_EPSILON, x) : x); };
+            V3 inv{clampinv(d.x), clampinv(d.y), clampinv(d.z)};
+            float tmax = FLT_MAX, t;
+            int best = -1, sp = 0, cur = 0;
+            int64_t steps = 0;
+            while (cur != rtbvh::kNoChild) {
+                if (++steps > 1000000) { mism += 1000000; break; }
+                if (cur >= 0) {
+                    pair_inner++;
+                    const rtbvh::Pair &p = r.pairs[cur];
+                    float el, er;
+                    bool hl = box_hit(o, inv, p.lbox, p.lbox + 3, tmax, el) && p.llink != rtbvh::kNoChild;
+                    bool hr = box_hit(o, inv, p.rbox, p.rbox + 3, tmax, er) && p.rlink != rtbvh::kNoChild;
+                    if (hl && hr) {
+                        bool lf = !(el > er);
+                        if (sp >= (int)pstack.size()) { mism += 1000000; break; }
+                        pstack[sp++] = lf ? p.rlink : p.llink;
+                        cur = lf ? p.llink : p.rlink;
+                    } else if (hl) cur = p.llink;
+                    else if (hr) cur = p.rlink;
+                    else cur = sp > 0 ? pstack[--sp] : rtbvh::kNoChild;
+                } else {
+                    int ref = ~cur, first = ref >> 3, count = ref & 7;
+                    for (int k = first; k < first + count; k++) if (tri_hit(tris[k], o, d, tmax, t)) { tmax = t; best = k; }
+                    cur = sp > 0 ? pstack[--sp] : rtbvh::kNoChild;
+                }
+            }
+            float bt = FLT_MAX; int bb = -1;
+            for (int k = 0; k < n; k++) if (tri_hit(tris[k], o, d, bt, t)) { bt = t; bb = k; }
+            if ((bb < 0) != (best < 0) || (bb >= 0 && bt != tmax)) mism++;
+        }
+        if (getenv("RT_BVH_STATS") && n_rays > 0) fprintf(stderr, "pair walk: inner %.2f per ray, %zu pairs, depth %d\n", (double)pair_inner / n_rays, r.pairs.size(), r.pair_depth);
+    }
     out10[5] = mism; out10[6] = max_stack; out10[7] = max_steps;
     if (getenv("RT_BVH_STATS") && n_rays > 0)
         fprintf(stderr, "bvh walk: inner %.2f leaf %.2f tri %.2f per ray\n", (double)sum_inner / n_rays, (double)sum_leaf / n_rays, (double)sum_tri / n_rays);

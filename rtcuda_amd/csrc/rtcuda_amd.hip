@@ -567,6 +567,7 @@ struct TraceParams {
     int debug_no_deposit;  // perf experiments only: skip the framebuffer atomics
     float *fb;             // MODE_POOL: raw-sum framebuffer
     DWaveRow *rows;        // MODE_POOL: counter rows
+    unsigned long long *prof;  // RT_TRACE_PROFILE builds only
     // test modes
     const float *o3, *d3, *tmax;
     const int *order, *excluded;
@@ -579,7 +580,7 @@ struct TraceParams {
 // carries its kind with its ray, so closest-hit and any-hit rays share waves; the two kinds differ
 // only in what a triangle hit does and in how the finished ray is finalised.
 // LDS layout (dynamic): [stack: stack_cap x kBlock ints][pending: kBlock ints]
-template <int MODE>
+template <int MODE, bool WIDE>
 __global__ void __launch_bounds__(kBlock, 8) k_trace(DScene sc, DPools p, TraceParams tp, int stack_cap, int *overflow) {
     extern __shared__ int s_lds[];
     int *stack = s_lds + threadIdx.x;
@@ -608,12 +609,24 @@ __global__ void __launch_bounds__(kBlock, 8) k_trace(DScene sc, DPools p, TraceP
     V3 o = mk(0, 0, 0), d = mk(0, 0, 0), inv = mk(0, 0, 0);
     float tmax = 0.f, hu = 0.f, hv = 0.f;
     unsigned long long deposits = 0;
+#ifdef RT_TRACE_PROFILE
+    unsigned long long pf_outer = 0, pf_refill = 0, pf_inner_it = 0, pf_inner_lanes = 0, pf_leaf_it = 0, pf_leaf_lanes = 0,
+                       pf_tri_it = 0, pf_tri_lanes = 0, pf_act_at_top = 0, pf_fin_lanes = 0, pf_new_lanes = 0;
+#endif
 
     while (true) {
         unsigned long long act = __ballot(id >= 0 && cur != kEntryDone);
+#ifdef RT_TRACE_PROFILE
+        pf_outer++;
+        pf_act_at_top += __popcll(act);
+#endif
         if (__popcll(act) <= kRefillAt) {
             // ---- finalise finished lanes
             const bool fin = id >= 0 && cur == kEntryDone;
+#ifdef RT_TRACE_PROFILE
+            pf_refill++;
+            pf_fin_lanes += __popcll(__ballot(fin));
+#endif
             const bool is_any = MODE == MODE_POOL ? (id & kAnyBit) != 0 : MODE == MODE_TEST_ANY;
             if (MODE == MODE_POOL) deposits += __popcll(__ballot(fin && is_any && hu == 0.f));
             if (fin) {
@@ -717,7 +730,33 @@ __global__ void __launch_bounds__(kBlock, 8) k_trace(DScene sc, DPools p, TraceP
         }
         // ---- inner phase: step through 4-wide node records until no lane holds an inner entry
         while (__ballot(cur >= 0) != 0) {
-            if (cur >= 0) {
+#ifdef RT_TRACE_PROFILE
+            pf_inner_it++;
+            pf_inner_lanes += __popcll(__ballot(cur >= 0));
+#endif
+            if (cur >= 0 && !WIDE) {
+                // 2-wide record: two exact boxes, near child first, far child onto the stack
+                const float4 *q = sc.nodes + 4 * (size_t)cur;
+                float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+                int cl = __float_as_int(q3.x), cr = __float_as_int(q3.y);
+                float el, er;
+                bool hl = box_hit(o, inv, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tmax, el) && cl != kEntryDone;
+                bool hr = box_hit(o, inv, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tmax, er) && cr != kEntryDone;
+                if (hl && hr) {
+                    bool left_first = !(el > er);
+                    stack_push(stack, over, sp, stack_cap, left_first ? cr : cl);
+                    cur = left_first ? cl : cr;
+                } else if (hl) {
+                    cur = cl;
+                } else if (hr) {
+                    cur = cr;
+                } else if (sp > 0) {
+                    cur = stack_pop(stack, over, sp, stack_cap);
+                } else {
+                    cur = kEntryDone;
+                }
+            }
+            if (cur >= 0 && WIDE) {
                 const float4 *q = sc.nodes + 4 * (size_t)cur;
                 float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
                 const unsigned exps = __float_as_uint(q0.w);
@@ -766,6 +805,20 @@ __global__ void __launch_bounds__(kBlock, 8) k_trace(DScene sc, DPools p, TraceP
             }
         }
         // ---- leaf phase: every lane that holds a leaf tests its triangles (triangle.cuh:39-58)
+#ifdef RT_TRACE_PROFILE
+        {
+            unsigned long long lm = __ballot(cur != kEntryDone && cur < 0);
+            if (lm) {
+                pf_leaf_it++;
+                pf_leaf_lanes += __popcll(lm);
+                int cnt_l = (cur != kEntryDone && cur < 0) ? ((~cur) & 7) : 0;
+                int mx = cnt_l, sm = cnt_l;
+                for (int off = 32; off > 0; off >>= 1) { mx = max(mx, __shfl_xor(mx, off)); sm += __shfl_xor(sm, off); }
+                pf_tri_it += mx;
+                pf_tri_lanes += sm;
+            }
+        }
+#endif
         if (cur != kEntryDone && cur < 0) {
             const bool is_any = MODE == MODE_POOL ? (id & kAnyBit) != 0 : MODE == MODE_TEST_ANY;
             int ref = ~cur;
@@ -801,6 +854,14 @@ __global__ void __launch_bounds__(kBlock, 8) k_trace(DScene sc, DPools p, TraceP
     if (MODE == MODE_POOL) {
         if (deposits != 0 && lane == 0) atomicAdd(&tp.rows[wave_index()].c[C_SHADOW_ADD], deposits);
     }
+#ifdef RT_TRACE_PROFILE
+    if (MODE == MODE_POOL && lane == 0 && tp.prof) {
+        atomicAdd(&tp.prof[0], pf_outer); atomicAdd(&tp.prof[1], pf_refill); atomicAdd(&tp.prof[2], pf_inner_it);
+        atomicAdd(&tp.prof[3], pf_inner_lanes); atomicAdd(&tp.prof[4], pf_leaf_it); atomicAdd(&tp.prof[5], pf_leaf_lanes);
+        atomicAdd(&tp.prof[6], pf_tri_it); atomicAdd(&tp.prof[7], pf_tri_lanes); atomicAdd(&tp.prof[8], pf_act_at_top);
+        atomicAdd(&tp.prof[9], pf_fin_lanes); atomicAdd(&tp.prof[10], 1ull);
+    }
+#endif
 }
 
 // post_process_framebuffer (render.cuh:330-338): c = sqrt(c * (1/spp))
@@ -833,6 +894,7 @@ struct rt_scene {
     int device = 0;
     int n_tris = 0, n_nodes = 0, max_depth = 0, stack_bound = 1, n_leaves = 0, n_lights = 0, n_mats = 0;
     float4 *d_nodes = nullptr;
+    bool wide = false;  // node records: 4-wide quantised (rtbvh::Node4) or 2-wide exact (rtbvh::Pair)
     float4 *d_tris = nullptr;
     int2 *d_tri_info = nullptr;
     Material *d_mats = nullptr;
@@ -991,6 +1053,13 @@ int get_context(int n, int lane, Context **out) {
 
 int grid_for(int n) { return (n + kBlock - 1) / kBlock; }
 
+// launches k_trace<MODE, wide?> -- the node format is a property of the scene
+#define RT_LAUNCH_TRACE(MODE, wide, grid, lds, stream, ...)                                                \
+    do {                                                                                                   \
+        if (wide) hipLaunchKernelGGL((k_trace<MODE, true>), grid, dim3(kBlock), lds, stream, __VA_ARGS__);   \
+        else hipLaunchKernelGGL((k_trace<MODE, false>), grid, dim3(kBlock), lds, stream, __VA_ARGS__);       \
+    } while (0)
+
 // Global overflow part of the traversal stacks: `levels` entries for each of kOverStride lanes, one
 // buffer per device, grown on demand (never shrunk).  Shared by concurrent renders on a device: every
 // lane of every trace grid indexes its own column (grids are at most kOverStride lanes), and a lane
@@ -1130,7 +1199,10 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
     // advance grid, whose wave count sizes the counter rows)
     int dev_cus = 0, occ_c = 0;
     HIP_TRY(hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, dev));
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_c, k_trace<MODE_POOL>, kBlock, lds_bytes));
+    if (scene->wide)
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_c, k_trace<MODE_POOL, true>, kBlock, lds_bytes));
+    else
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_c, k_trace<MODE_POOL, false>, kBlock, lds_bytes));
     int per_cu = std::max(1, occ_c);
     if (const char *e = getenv("RT_TRACE_BLOCKS_PER_CU")) per_cu = std::max(1, std::min(per_cu, atoi(e)));
     const int resident = std::max(1, dev_cus * per_cu);
@@ -1140,6 +1212,12 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
     tpp.fb = d_sum;
     tpp.rows = c.d_rows;
     tpp.debug_no_deposit = (flags & 0x100u) ? 1 : 0;
+#ifdef RT_TRACE_PROFILE
+    unsigned long long *d_prof = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_prof, sizeof(unsigned long long) * 16));
+    HIP_TRY(hipMemset(d_prof, 0, sizeof(unsigned long long) * 16));
+    tpp.prof = d_prof;
+#endif
     // RT_FLAG_TIME_KERNELS: every kTimeStride-th round is bracketed with HIP events on the launch
     // stream (no host synchronisation); the events are resolved after the loop.
     const int kTimeStride = 4;
@@ -1166,7 +1244,7 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
                 else
                     hipLaunchKernelGGL(k_advance<false>, grid, block, 0, st, sc, c.pools, cam, ap, d_sum, c.d_ctr, c.d_rows);
                 HIP_TRY(hipEventRecord(e1, st));
-                hipLaunchKernelGGL(k_trace<MODE_POOL>, grid_trace, block, lds_bytes, st, sc, c.pools, tpp, stack_cap, d_over);
+                RT_LAUNCH_TRACE(MODE_POOL, scene->wide, grid_trace, lds_bytes, st, sc, c.pools, tpp, stack_cap, d_over);
                 HIP_TRY(hipEventRecord(e2, st));
                 HIP_TRY(hipEventRecord(e3, st));
             } else {
@@ -1174,7 +1252,7 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
                     hipLaunchKernelGGL(k_advance<true>, grid, block, 0, st, sc, c.pools, cam, ap, d_sum, c.d_ctr, c.d_rows);
                 else
                     hipLaunchKernelGGL(k_advance<false>, grid, block, 0, st, sc, c.pools, cam, ap, d_sum, c.d_ctr, c.d_rows);
-                hipLaunchKernelGGL(k_trace<MODE_POOL>, grid_trace, block, lds_bytes, st, sc, c.pools, tpp, stack_cap, d_over);
+                RT_LAUNCH_TRACE(MODE_POOL, scene->wide, grid_trace, lds_bytes, st, sc, c.pools, tpp, stack_cap, d_over);
             }
             rounds++;
         }
@@ -1208,12 +1286,23 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
                 HIP_TRY(hipStreamSynchronize(st));
                 if (c.h_ctr[0].round_shades == 0) break;
             }
-            hipLaunchKernelGGL(k_trace<MODE_POOL>, grid_trace, block, lds_bytes, st, sc, c.pools, tpp, stack_cap, d_over);
+            RT_LAUNCH_TRACE(MODE_POOL, scene->wide, grid_trace, lds_bytes, st, sc, c.pools, tpp, stack_cap, d_over);
             HIP_TRY(hipGetLastError());
         }
     }
     HIP_TRY(hipEventRecord(ev_stop, st));
     HIP_TRY(hipEventSynchronize(ev_stop));
+#ifdef RT_TRACE_PROFILE
+    {
+        unsigned long long h[16];
+        HIP_TRY(hipMemcpy(h, d_prof, sizeof(h), hipMemcpyDeviceToHost));
+        fprintf(stderr, "trace profile: waves %llu outer_it %llu refills %llu | inner_it %llu avg_lanes %.1f | leaf_it %llu avg_lanes %.1f | "
+                        "tri_it %llu avg_lanes %.1f | active lanes at loop top %.1f | finalised lanes per refill %.1f\n",
+                h[10], h[0], h[1], h[2], h[2] ? (double)h[3] / h[2] : 0.0, h[4], h[4] ? (double)h[5] / h[4] : 0.0, h[6],
+                h[6] ? (double)h[7] / h[6] : 0.0, h[0] ? (double)h[8] / h[0] : 0.0, h[1] ? (double)h[9] / h[1] : 0.0);
+        (void)hipFree(d_prof);
+    }
+#endif
     float ms_total = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms_total, ev_start, ev_stop));
     HIP_TRY(hipEventDestroy(ev_start));
@@ -1357,9 +1446,11 @@ int rt_scene_create(const float *tri_p0p1p2, int n_tris, const int32_t *tri_mate
     if (bvh.stack_bound > kMaxStackBound)
         return fail("rt_scene_create: BVH depth " + std::to_string(bvh.max_depth) + " exceeds the traversal stack");
     sc->n_tris = n_tris;
-    sc->n_nodes = (int)bvh.nodes.size();
-    sc->max_depth = bvh.max_depth;
-    sc->stack_bound = bvh.stack_bound;
+    sc->wide = false;  // 2-wide exact records: cheaper per test, and the trace kernel is VALU-bound
+    if (const char *e = getenv("RT_BVH_WIDE")) sc->wide = atoi(e) != 0;
+    sc->n_nodes = sc->wide ? (int)bvh.nodes.size() : (int)bvh.pairs.size();
+    sc->max_depth = sc->wide ? bvh.max_depth : bvh.pair_depth;
+    sc->stack_bound = sc->wide ? bvh.stack_bound : bvh.pair_depth + 1;
     sc->n_leaves = bvh.num_leaves;
     sc->n_lights = n_lights;
     sc->n_mats = n_materials;
@@ -1392,8 +1483,11 @@ int rt_scene_create(const float *tri_p0p1p2, int n_tris, const int32_t *tri_mate
     static_assert(sizeof(Light) == sizeof(rt_light), "light layout");
     static_assert(sizeof(Material) == sizeof(rt_material), "material layout");
     static_assert(sizeof(Camera) == sizeof(rt_camera), "camera layout");
-    HIP_TRY(hipMalloc((void **)&sc->d_nodes, sizeof(rtbvh::Node4) * bvh.nodes.size()));
-    HIP_TRY(hipMemcpy(sc->d_nodes, bvh.nodes.data(), sizeof(rtbvh::Node4) * bvh.nodes.size(), hipMemcpyHostToDevice));
+    {
+        const void *src = sc->wide ? (const void *)bvh.nodes.data() : (const void *)bvh.pairs.data();
+        HIP_TRY(hipMalloc((void **)&sc->d_nodes, 64 * (size_t)sc->n_nodes));
+        HIP_TRY(hipMemcpy(sc->d_nodes, src, 64 * (size_t)sc->n_nodes, hipMemcpyHostToDevice));
+    }
     HIP_TRY(hipMalloc((void **)&sc->d_tris, sizeof(float) * trec.size()));
     HIP_TRY(hipMemcpy(sc->d_tris, trec.data(), sizeof(float) * trec.size(), hipMemcpyHostToDevice));
     HIP_TRY(hipMalloc((void **)&sc->d_tri_info, sizeof(int2) * info.size()));
@@ -1544,8 +1638,8 @@ int rt_trace_closest(const rt_scene *scene, int n, const float *origin_xyz, cons
         tp.out_u = d_u;
         tp.out_v = d_v;
         DPools none{};
-        hipLaunchKernelGGL(k_trace<MODE_TEST_CLOSEST>, dim3(test_grid), dim3(kBlock),
-                           sizeof(int) * kBlock * (size_t)(stack_cap + 1), nullptr, scene->dev(), none, tp, stack_cap, d_over);
+        RT_LAUNCH_TRACE(MODE_TEST_CLOSEST, scene->wide, dim3(test_grid), sizeof(int) * kBlock * (size_t)(stack_cap + 1), nullptr,
+                        scene->dev(), none, tp, stack_cap, d_over);
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(hit_tri, d_h, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost));
@@ -1591,8 +1685,8 @@ int rt_trace_any(const rt_scene *scene, int n, const float *origin_xyz, const fl
         tp.excluded = d_e;
         tp.out_i = d_occ;
         DPools none{};
-        hipLaunchKernelGGL(k_trace<MODE_TEST_ANY>, dim3(test_grid), dim3(kBlock),
-                           sizeof(int) * kBlock * (size_t)(stack_cap + 1), nullptr, scene->dev(), none, tp, stack_cap, d_over);
+        RT_LAUNCH_TRACE(MODE_TEST_ANY, scene->wide, dim3(test_grid), sizeof(int) * kBlock * (size_t)(stack_cap + 1), nullptr,
+                        scene->dev(), none, tp, stack_cap, d_over);
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(occluded, d_occ, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost));
