@@ -75,7 +75,9 @@ typedef struct rt_stats {
     double seconds_unused;
     double seconds_advance;  /* same for the advance kernel */
     int64_t launches_trace;  /* launches of each stage kernel (= iterations) */
-    int64_t reserved[7];     /* reserved[0] = rounds actually sampled by the event timer */
+    int64_t reserved[7];     /* reserved[0] = launches actually sampled by the event timer;
+                                reserved[1] = 1 when the frame ran as one persistent k_paths launch (then
+                                seconds_trace is that launch's duration and launches_trace is 1) */
 } rt_stats;
 
 /* Flags for rt_render / rt_render_shard */

@@ -63,7 +63,7 @@ int fail(const std::string &msg) {
 constexpr int kW = RT_NUM_WORKING_PATHS;
 constexpr int kBlock = 256;       // 4 waves per workgroup
 constexpr int kLdsStack = 16;          // traversal stack entries kept in LDS per lane
-constexpr int kOverStride = 1 << 19;   // lanes of the overflow stack (>= lanes of the largest trace grid)
+constexpr int kOverStride = 1 << 20;   // lanes of the overflow stack (>= lanes of the largest grid that traverses)
 constexpr int kMaxStackBound = 160;    // deepest traversal stack a scene may need (3 per level + 1)
 }  // namespace
 
@@ -261,10 +261,158 @@ __device__ __forceinline__ Light tab_light(const float *tab, int n_mats, int i) 
     return l;
 }
 
-// init() + mat() + gen() for one slot (render.cuh:84-275).
+// ---------------------------------------------------------------------------------------------
+// advance_core: init() + mat() + gen() for ONE slot (render.cuh:84-275), on register state.
+// Shared by k_advance (state loaded from / stored to the pools) and k_paths (state lives in
+// registers for the whole frame).
+struct SlotState {
+    int bounces, hit_info, pixel, gen;
+    Rng rs;
+    V3 beta, wo, isect_p, isect_n;
+};
+struct AdvanceOut {
+    bool did_gen, did_shade, has_shadow, did_emit, new_ray;
+    int rr_draws;
+    V3 ray_o, ray_d;            // next path ray (valid when new_ray)
+    V3 s_o, s_d, s_L;           // shadow ray + radiance to deposit if unoccluded (valid when has_shadow)
+    float s_tmax;
+    int s_target;
+};
+
+__device__ __forceinline__ void advance_core(const DScene &sc, const float *tab, const Camera &cam,
+                                             const AdvanceParams &ap, int slot_global, SlotState &st, AdvanceOut &out,
+                                             float *__restrict__ fb) {
+    const int off_ltri = tab_off_ltri(sc.num_mats, sc.num_lights);
+    const int off_lpre = tab_off_lpre(sc.num_mats, sc.num_lights);
+    out.did_gen = out.did_shade = out.has_shadow = out.did_emit = out.new_ray = false;
+    out.rr_draws = 0;
+    const bool hit = st.hit_info >= 0;
+    const int light_of_hit = hit ? ((st.hit_info >> 16) & 0xffff) - 1 : -1;
+    // Emulate consecutive init() calls (render.cuh:84-137) until one of them ends in mat() or
+    // gen(): a slot whose path missed idles (no RNG use) until bounces reaches max_bounces,
+    // a slot that Russian roulette "killed" is re-rolled every iteration (Appendix A.1).
+    while (true) {
+        if (st.bounces == 0 && hit && light_of_hit >= 0) {  // :98-103 emission only at bounce 0
+            Light l = tab_light(tab, sc.num_mats, light_of_hit);
+            atomicAdd(&fb[3 * (size_t)st.pixel + 0], l.lx);
+            atomicAdd(&fb[3 * (size_t)st.pixel + 1], l.ly);
+            atomicAdd(&fb[3 * (size_t)st.pixel + 2], l.lz);
+            out.did_emit = true;
+        }
+        bool cont = st.bounces < ap.max_bounces;  // :109
+        bool local_hit = hit;
+        if (cont && hit && st.bounces > kRrStart) {  // :112-124
+            float bm = max3(st.beta);
+            if (bm < kRrThreshold) {
+                float pt = fmaxf(0.05f, 1 - bm);
+                out.rr_draws++;
+                if (rng_uniform(st.rs) < pt) local_hit = false;
+                else st.beta = divf(st.beta, 1 - pt);
+            }
+        }
+        st.bounces = st.bounces + 1;  // :126
+        if (cont) {
+            if (local_hit) {
+                out.did_shade = true;
+                break;
+            }
+            if (ap.lockstep) break;                    // exactly one init() per round
+            if (!hit) st.bounces = ap.max_bounces;     // idle iterations consume nothing: skip them
+            continue;
+        }
+        // ---- gen() :250-275.  Camera ray id = generation * W + slot (see file header).
+        long long cid = (long long)st.gen * kW + slot_global;
+        if (cid >= ap.cam_end) {
+            st.bounces = kDone;
+            break;
+        }
+        if (!ap.lockstep && st.gen == ap.last_gen) {
+            st.bounces = kParked;
+            break;
+        }
+        st.gen = st.gen + 1;
+        st.pixel = (int)(cid / ap.spp);
+        int px = st.pixel % ap.width;
+        int py = st.pixel / ap.width;
+        float jx = rng_uniform(st.rs);  // x first, then y (Appendix A.7)
+        float jy = rng_uniform(st.rs);
+        camera_get_ray(cam, (px + jx) / ap.width, (py + jy) / ap.height, out.ray_o, out.ray_d);
+        out.new_ray = true;
+        st.bounces = 0;
+        st.beta = mk(1.f, 1.f, 1.f);
+        out.did_gen = true;
+        break;
+    }
+    if (!out.did_shade) return;
+    // ---- mat() :139-248
+    Material m = tab_material(tab, st.hit_info & 0xffff);
+    V3 multiplier = scale(st.beta, (float)sc.num_lights);  // taken BEFORE the beta update (:150)
+    {
+        V3 n = st.isect_n, wi;
+        float pdf;
+        V3 f = mat_sample_f(m, st.wo, st.rs, n, wi, pdf);
+        out.ray_o = offset_ray_origin(st.isect_p, n);
+        out.ray_d = wi;
+        out.new_ray = true;
+        st.beta = mul(st.beta, divf(scale(f, dot(wi, n)), pdf));  // :166
+    }
+    if (sc.num_lights > 0) {
+        int light_idx = min((int)(rng_uniform(st.rs) * sc.num_lights), sc.num_lights - 1);  // :178
+        Light light = tab_light(tab, sc.num_mats, light_idx);
+        V3 wi, Li;
+        float lt, lpdf;
+        // Light::sample_Li light.cuh:29-48
+        if (light.type == 0) {
+            wi = sub(mk(light.px, light.py, light.pz), st.isect_p);
+            lt = len(wi);
+            Li = divf(mk(light.lx, light.ly, light.lz), lt * lt);
+            wi = divf(wi, lt);
+            lpdf = 1.f;
+        } else {
+            const float *q = tab + off_ltri + 12 * light_idx;
+            const float *pre = tab + off_lpre + 4 * light_idx;
+            Tri lt_tri;
+            lt_tri.p0 = mk(q[0], q[1], q[2]);
+            lt_tri.e1 = mk(q[3], q[4], q[5]);
+            lt_tri.e2 = mk(q[6], q[7], q[8]);
+            lt_tri.n = mk(q[9], q[10], q[11]);
+            lpdf = pre[0];                        // 1 / area
+            V3 lun = mk(pre[1], pre[2], pre[3]);   // unit normal of the light triangle
+            float a = sqrtf(rng_uniform(st.rs));   // Triangle::sample_p triangle.cuh:78-82
+            float u2 = rng_uniform(st.rs);
+            V3 tp = tri_point(lt_tri, 1 - a, u2 * a);
+            wi = sub(tp, st.isect_p);
+            lt = len(wi);
+            wi = divf(wi, lt);
+            Li = mk(light.lx, light.ly, light.lz);
+            lpdf *= len2(sub(tp, st.isect_p)) / fabsf(dot(lun, wi));
+        }
+        V3 n = dot(st.isect_n, wi) > 0.f ? st.isect_n : neg(st.isect_n);  // :187
+        V3 f;
+        float spdf;
+        if (mat_get_f(m, st.wo, wi, n, f, spdf)) {
+            f = scale(f, dot(wi, n));
+            out.s_o = offset_ray_origin(st.isect_p, n);
+            out.s_d = wi;
+            out.s_tmax = lt;
+            out.s_target = light.type == 1 ? light.tri : -1;
+            if (light.type == 0) {
+                out.s_L = divf(mul(mul(multiplier, f), Li), lpdf);  // :199
+            } else {
+                float weight = power_heuristic(lpdf, spdf);  // :201 (int-truncating)
+                out.s_L = divf(scale(mul(mul(multiplier, f), Li), weight), lpdf);  // :202
+            }
+            out.has_shadow = true;
+        }
+        // "sample BSDF with MIS" block :213-245: its ray cannot contribute; keep its draws
+        if (light.type != 0) mat_sample_f_burn(m, st.wo, st.isect_n, st.rs);
+    }
+}
+
+// k_advance: one slot per thread, state in the pools.
 // Every per-slot input is indexed by the slot id, so all of a lane's loads are issued together
 // (one memory round trip); the small shared tables are staged in LDS with one more independent
-// round trip; the hit record written by k_trace<POOL_CLOSEST> already carries the shading point,
+// round trip; the hit record written by k_trace<MODE_POOL> already carries the shading point,
 // the flipped unit normal and the material / light ids, so no triangle is gathered here.  The
 // kernel has no atomics on shared words and one barrier (the table staging): the shadow ray goes
 // to the slot's own record, event counts go to the wave's own counter row.
@@ -277,19 +425,23 @@ k_advance(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool in_range = i < ap.n;
     // ---- issue all per-slot loads up front
-    int bounces = kDone, hit_info = -1, pixel = 0, gen = 0;
-    Rng rs{0, 0, 0, 0, 0, 0};
-    V3 beta = mk(0, 0, 0), wo = mk(0, 0, 0), isect_p = mk(0, 0, 0), isect_n = mk(0, 0, 0);
+    SlotState st;
+    st.bounces = kDone;
+    st.hit_info = -1;
+    st.pixel = 0;
+    st.gen = 0;
+    st.rs = Rng{0, 0, 0, 0, 0, 0};
+    st.beta = st.wo = st.isect_p = st.isect_n = mk(0, 0, 0);
     if (in_range) {
-        bounces = p.bounces[i];
-        hit_info = p.hit_info[i];
-        pixel = p.pixel[i];
-        gen = p.gen[i];
-        rs = Rng{p.rd[i], p.r0[i], p.r1[i], p.r2[i], p.r3[i], p.r4[i]};
-        beta = mk(p.br[i], p.bg[i], p.bb[i]);
-        wo = mk(p.dx[i], p.dy[i], p.dz[i]);
-        isect_p = mk(p.hpx[i], p.hpy[i], p.hpz[i]);
-        isect_n = mk(p.hnx[i], p.hny[i], p.hnz[i]);
+        st.bounces = p.bounces[i];
+        st.hit_info = p.hit_info[i];
+        st.pixel = p.pixel[i];
+        st.gen = p.gen[i];
+        st.rs = Rng{p.rd[i], p.r0[i], p.r1[i], p.r2[i], p.r3[i], p.r4[i]};
+        st.beta = mk(p.br[i], p.bg[i], p.bb[i]);
+        st.wo = mk(p.dx[i], p.dy[i], p.dz[i]);
+        st.isect_p = mk(p.hpx[i], p.hpy[i], p.hpz[i]);
+        st.isect_n = mk(p.hnx[i], p.hny[i], p.hnz[i]);
     }
     const float *tab = sc.tables;
     if (LDS_TABLES) {
@@ -297,200 +449,72 @@ k_advance(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__
         __syncthreads();
         tab = s_tab;
     }
-    const int off_ltri = tab_off_ltri(sc.num_mats, sc.num_lights);
-    const int off_lpre = tab_off_lpre(sc.num_mats, sc.num_lights);
-
     // Final generation: the reference stops the whole render at the first iteration in which no slot
     // shades (render.cuh:436), which can cut off slots that Russian roulette would have revived
     // later.  That is a global condition, so the last generation runs in lockstep: slots that finish
     // generation last_gen - 1 park, and once all are parked the host drives one init() per round.
-    if (ap.lockstep && bounces == kParked) {
-        bounces = ap.max_bounces;  // routes the slot to gen() below
-        hit_info = -1;
+    if (ap.lockstep && st.bounces == kParked) {
+        st.bounces = ap.max_bounces;  // routes the slot to gen() below
+        st.hit_info = -1;
     }
-    const bool alive = bounces != kDone && bounces != kParked;
-    bool did_gen = false, did_shade = false, has_shadow = false, did_emit = false;
-    int rr_draws = 0;
-
+    const bool alive = st.bounces != kDone && st.bounces != kParked;
+    AdvanceOut out;
+    out.did_gen = out.did_shade = out.has_shadow = out.did_emit = out.new_ray = false;
+    out.rr_draws = 0;
     if (alive) {
-        bool beta_dirty = false;
-        const bool hit = hit_info >= 0;
-        const int light_of_hit = hit ? ((hit_info >> 16) & 0xffff) - 1 : -1;
-        // Emulate consecutive init() calls (render.cuh:84-137) until one of them ends in mat() or
-        // gen(): a slot whose path missed idles (no RNG use) until bounces reaches max_bounces,
-        // a slot that Russian roulette "killed" is re-rolled every iteration (Appendix A.1).
-        while (true) {
-            if (bounces == 0 && hit && light_of_hit >= 0) {  // :98-103 emission only at bounce 0
-                Light l = tab_light(tab, sc.num_mats, light_of_hit);
-                atomicAdd(&fb[3 * (size_t)pixel + 0], l.lx);
-                atomicAdd(&fb[3 * (size_t)pixel + 1], l.ly);
-                atomicAdd(&fb[3 * (size_t)pixel + 2], l.lz);
-                did_emit = true;
-            }
-            bool cont = bounces < ap.max_bounces;  // :109
-            bool local_hit = hit;
-            if (cont && hit && bounces > kRrStart) {  // :112-124
-                float bm = max3(beta);
-                if (bm < kRrThreshold) {
-                    float pt = fmaxf(0.05f, 1 - bm);
-                    rr_draws++;
-                    if (rng_uniform(rs) < pt) {
-                        local_hit = false;
-                    } else {
-                        beta = divf(beta, 1 - pt);
-                        beta_dirty = true;
-                    }
-                }
-            }
-            bounces = bounces + 1;  // :126
-            if (cont) {
-                if (local_hit) {
-                    did_shade = true;
-                    break;
-                }
-                if (ap.lockstep) break;              // exactly one init() per round
-                if (!hit) bounces = ap.max_bounces;  // idle iterations consume nothing: skip them
-                continue;
-            }
-            // ---- gen() :250-275.  Camera ray id = generation * W + slot (see file header).
-            long long cid = (long long)gen * kW + (ap.slot_lo + i);
-            if (cid >= ap.cam_end) {
-                bounces = kDone;
-                break;
-            }
-            if (!ap.lockstep && gen == ap.last_gen) {
-                bounces = kParked;
-                break;
-            }
-            p.gen[i] = gen + 1;
-            pixel = (int)(cid / ap.spp);
-            int px = pixel % ap.width;
-            int py = pixel / ap.width;
-            float jx = rng_uniform(rs);  // x first, then y (Appendix A.7)
-            float jy = rng_uniform(rs);
-            V3 o, d;
-            camera_get_ray(cam, (px + jx) / ap.width, (py + jy) / ap.height, o, d);
-            p.ox[i] = o.x;
-            p.oy[i] = o.y;
-            p.oz[i] = o.z;
-            p.dx[i] = d.x;
-            p.dy[i] = d.y;
-            p.dz[i] = d.z;
-            p.pixel[i] = pixel;
-            bounces = 0;
-            beta = mk(1.f, 1.f, 1.f);
-            beta_dirty = true;
-            did_gen = true;
-            break;
+        const int gen_before = st.gen;
+        advance_core(sc, tab, cam, ap, ap.slot_lo + i, st, out, fb);
+        if (out.new_ray) {
+            p.ox[i] = out.ray_o.x;
+            p.oy[i] = out.ray_o.y;
+            p.oz[i] = out.ray_o.z;
+            p.dx[i] = out.ray_d.x;
+            p.dy[i] = out.ray_d.y;
+            p.dz[i] = out.ray_d.z;
         }
-
-        if (did_shade) {
-            // ---- mat() :139-248
-            Material m = tab_material(tab, hit_info & 0xffff);
-            V3 multiplier = scale(beta, (float)sc.num_lights);  // taken BEFORE the beta update (:150)
-            {
-                V3 n = isect_n, wi;
-                float pdf;
-                V3 f = mat_sample_f(m, wo, rs, n, wi, pdf);
-                V3 o = offset_ray_origin(isect_p, n);
-                p.ox[i] = o.x;
-                p.oy[i] = o.y;
-                p.oz[i] = o.z;
-                p.dx[i] = wi.x;
-                p.dy[i] = wi.y;
-                p.dz[i] = wi.z;
-                beta = mul(beta, divf(scale(f, dot(wi, n)), pdf));  // :166
-                beta_dirty = true;
-            }
-            if (sc.num_lights > 0) {
-                int light_idx = min((int)(rng_uniform(rs) * sc.num_lights), sc.num_lights - 1);  // :178
-                Light light = tab_light(tab, sc.num_mats, light_idx);
-                V3 wi, Li;
-                float lt, lpdf;
-                // Light::sample_Li light.cuh:29-48
-                if (light.type == 0) {
-                    wi = sub(mk(light.px, light.py, light.pz), isect_p);
-                    lt = len(wi);
-                    Li = divf(mk(light.lx, light.ly, light.lz), lt * lt);
-                    wi = divf(wi, lt);
-                    lpdf = 1.f;
-                } else {
-                    const float *q = tab + off_ltri + 12 * light_idx;
-                    const float *pre = tab + off_lpre + 4 * light_idx;
-                    Tri lt_tri;
-                    lt_tri.p0 = mk(q[0], q[1], q[2]);
-                    lt_tri.e1 = mk(q[3], q[4], q[5]);
-                    lt_tri.e2 = mk(q[6], q[7], q[8]);
-                    lt_tri.n = mk(q[9], q[10], q[11]);
-                    lpdf = pre[0];                       // 1 / area
-                    V3 lun = mk(pre[1], pre[2], pre[3]);  // unit normal of the light triangle
-                    float a = sqrtf(rng_uniform(rs));     // Triangle::sample_p triangle.cuh:78-82
-                    float u2 = rng_uniform(rs);
-                    V3 tp = tri_point(lt_tri, 1 - a, u2 * a);
-                    wi = sub(tp, isect_p);
-                    lt = len(wi);
-                    wi = divf(wi, lt);
-                    Li = mk(light.lx, light.ly, light.lz);
-                    lpdf *= len2(sub(tp, isect_p)) / fabsf(dot(lun, wi));
-                }
-                V3 n = dot(isect_n, wi) > 0.f ? isect_n : neg(isect_n);  // :187
-                V3 f;
-                float spdf;
-                if (mat_get_f(m, wo, wi, n, f, spdf)) {
-                    f = scale(f, dot(wi, n));
-                    V3 s_o = offset_ray_origin(isect_p, n);
-                    V3 s_L;
-                    if (light.type == 0) {
-                        s_L = divf(mul(mul(multiplier, f), Li), lpdf);  // :199
-                    } else {
-                        float weight = power_heuristic(lpdf, spdf);  // :201 (int-truncating)
-                        s_L = divf(scale(mul(mul(multiplier, f), Li), weight), lpdf);  // :202
-                    }
-                    p.sox[i] = s_o.x;
-                    p.soy[i] = s_o.y;
-                    p.soz[i] = s_o.z;
-                    p.sdx[i] = wi.x;
-                    p.sdy[i] = wi.y;
-                    p.sdz[i] = wi.z;
-                    p.slr[i] = s_L.x;
-                    p.slg[i] = s_L.y;
-                    p.slb[i] = s_L.z;
-                    p.starget[i] = light.type == 1 ? light.tri : -1;
-                    p.stmax[i] = lt;
-                    has_shadow = true;
-                }
-                // "sample BSDF with MIS" block :213-245: its ray cannot contribute; keep its draws
-                if (light.type != 0) mat_sample_f_burn(m, wo, isect_n, rs);
-            }
+        if (st.gen != gen_before) {
+            p.gen[i] = st.gen;
+            p.pixel[i] = st.pixel;
         }
-        if (beta_dirty) {
-            p.br[i] = beta.x;
-            p.bg[i] = beta.y;
-            p.bb[i] = beta.z;
+        if (out.has_shadow) {
+            p.sox[i] = out.s_o.x;
+            p.soy[i] = out.s_o.y;
+            p.soz[i] = out.s_o.z;
+            p.sdx[i] = out.s_d.x;
+            p.sdy[i] = out.s_d.y;
+            p.sdz[i] = out.s_d.z;
+            p.slr[i] = out.s_L.x;
+            p.slg[i] = out.s_L.y;
+            p.slb[i] = out.s_L.z;
+            p.starget[i] = out.s_target;
+            p.stmax[i] = out.s_tmax;
         }
-        p.bounces[i] = bounces;
-        p.rd[i] = rs.d;
-        p.r0[i] = rs.v0;
-        p.r1[i] = rs.v1;
-        p.r2[i] = rs.v2;
-        p.r3[i] = rs.v3;
-        p.r4[i] = rs.v4;
+        p.br[i] = st.beta.x;
+        p.bg[i] = st.beta.y;
+        p.bb[i] = st.beta.z;
+        p.bounces[i] = st.bounces;
+        p.rd[i] = st.rs.d;
+        p.r0[i] = st.rs.v0;
+        p.r1[i] = st.rs.v1;
+        p.r2[i] = st.rs.v2;
+        p.r3[i] = st.rs.v3;
+        p.r4[i] = st.rs.v4;
     }
-    if (in_range && !has_shadow) p.stmax[i] = -1.f;  // no shadow ray from this slot this round
+    if (in_range && !out.has_shadow) p.stmax[i] = -1.f;  // no shadow ray from this slot this round
 
     // ---- event counters: this wave's own row
-    unsigned long long traced = __ballot(did_gen || did_shade);
-    int rr_tot = rr_draws;
-    if (__ballot(rr_draws != 0)) {
+    unsigned long long traced = __ballot(out.did_gen || out.did_shade);
+    int rr_tot = out.rr_draws;
+    if (__ballot(out.rr_draws != 0)) {
         for (int off = 32; off > 0; off >>= 1) rr_tot += __shfl_xor(rr_tot, off);
     } else {
         rr_tot = 0;
     }
-    unsigned long long v[C_COUNT] = {(unsigned long long)__popcll(__ballot(did_gen)),
-                                     (unsigned long long)__popcll(__ballot(did_shade)),
+    unsigned long long v[C_COUNT] = {(unsigned long long)__popcll(__ballot(out.did_gen)),
+                                     (unsigned long long)__popcll(__ballot(out.did_shade)),
                                      (unsigned long long)__popcll(traced),
-                                     (unsigned long long)__popcll(__ballot(has_shadow)),
-                                     (unsigned long long)__popcll(__ballot(did_emit)),
+                                     (unsigned long long)__popcll(__ballot(out.has_shadow)),
+                                     (unsigned long long)__popcll(__ballot(out.did_emit)),
                                      0ull,
                                      (unsigned long long)rr_tot,
                                      0ull};
@@ -499,7 +523,7 @@ k_advance(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__
     // round that closes a batch: one plain store per live wave in 1 round out of 8
     if ((ap.round & ap.batch_mask) == ap.batch_mask && traced != 0 && lane_id() == 0) ctr->last_live_round = ap.round;
     if (ap.lockstep) {
-        unsigned long long sm = __ballot(did_shade);
+        unsigned long long sm = __ballot(out.did_shade);
         if (sm != 0 && lane_id() == 0) atomicAdd(&ctr->round_shades, (unsigned)__popcll(sm));
     }
 }
@@ -559,6 +583,82 @@ __device__ __forceinline__ int stack_pop(int *lds_col, int *over_col, int &sp, i
 }
 constexpr int kRefillAt = 40;                // finalise + refill once <= this many lanes still traverse
 __device__ __forceinline__ int leaf_ref(int first, int count) { return ~((first << 3) | count); }
+
+// One node step of a lane whose current entry is an inner record (cur >= 0): test the children,
+// continue with the nearest one that the ray may enter, push the others (far first).
+template <bool WIDE>
+__device__ __forceinline__ void inner_step(const DScene &sc, V3 o, V3 inv, float tmax, int &cur, int &sp, int *stack,
+                                           int *over, int stack_cap) {
+    if (!WIDE) {
+        // 2-wide record: two exact boxes, near child first, far child onto the stack
+        const float4 *q = sc.nodes + 4 * (size_t)cur;
+        float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+        int cl = __float_as_int(q3.x), cr = __float_as_int(q3.y);
+        float el, er;
+        bool hl = box_hit(o, inv, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tmax, el) && cl != kEntryDone;
+        bool hr = box_hit(o, inv, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tmax, er) && cr != kEntryDone;
+        if (hl && hr) {
+            bool left_first = !(el > er);
+            stack_push(stack, over, sp, stack_cap, left_first ? cr : cl);
+            cur = left_first ? cl : cr;
+        } else if (hl) {
+            cur = cl;
+        } else if (hr) {
+            cur = cr;
+        } else if (sp > 0) {
+            cur = stack_pop(stack, over, sp, stack_cap);
+        } else {
+            cur = kEntryDone;
+        }
+    }
+    if (WIDE) {
+        const float4 *q = sc.nodes + 4 * (size_t)cur;
+        float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+        const unsigned exps = __float_as_uint(q0.w);
+        const float cx = __uint_as_float((exps & 0xffu) << 23);
+        const float cy = __uint_as_float(((exps >> 8) & 0xffu) << 23);
+        const float cz = __uint_as_float(((exps >> 16) & 0xffu) << 23);
+        const unsigned lox = __float_as_uint(q2.x), loy = __float_as_uint(q2.y), loz = __float_as_uint(q2.z);
+        const unsigned hix = __float_as_uint(q2.w), hiy = __float_as_uint(q3.x), hiz = __float_as_uint(q3.y);
+        const int links[4] = {__float_as_int(q1.x), __float_as_int(q1.y), __float_as_int(q1.z), __float_as_int(q1.w)};
+        // (entry distance, link) of every child the ray may enter; a miss sorts last
+        unsigned key[4];
+        int lnk[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int sh = 8 * k;
+            // bound = origin + float(q) * cell : the expression the builder verified (rt_bvh.h)
+            float bx0 = q0.x + (float)((lox >> sh) & 0xffu) * cx, bx1 = q0.x + (float)((hix >> sh) & 0xffu) * cx;
+            float by0 = q0.y + (float)((loy >> sh) & 0xffu) * cy, by1 = q0.y + (float)((hiy >> sh) & 0xffu) * cy;
+            float bz0 = q0.z + (float)((loz >> sh) & 0xffu) * cz, bz1 = q0.z + (float)((hiz >> sh) & 0xffu) * cz;
+            float e;
+            bool h = box_hit(o, inv, bx0, by0, bz0, bx1, by1, bz1, tmax, e) && links[k] != kEntryDone;
+            key[k] = h ? __float_as_uint(fmaxf(e, 0.f)) : 0xffffffffu;
+            lnk[k] = links[k];
+        }
+        // sorting network on 4 (key, link) pairs, ascending by entry distance
+#define RT_CSWAP(a, b)                                                     \
+    {                                                                      \
+        bool sw = key[b] < key[a];                                         \
+        unsigned ka = sw ? key[b] : key[a], kb = sw ? key[a] : key[b];     \
+        int la = sw ? lnk[b] : lnk[a], lb = sw ? lnk[a] : lnk[b];          \
+        key[a] = ka; key[b] = kb; lnk[a] = la; lnk[b] = lb;                \
+    }
+        RT_CSWAP(0, 1) RT_CSWAP(2, 3) RT_CSWAP(0, 2) RT_CSWAP(1, 3) RT_CSWAP(1, 2)
+#undef RT_CSWAP
+        // far children first onto the stack, nearest becomes the current entry
+        if (key[3] != 0xffffffffu) { stack_push(stack, over, sp, stack_cap, lnk[3]); }
+        if (key[2] != 0xffffffffu) { stack_push(stack, over, sp, stack_cap, lnk[2]); }
+        if (key[1] != 0xffffffffu) { stack_push(stack, over, sp, stack_cap, lnk[1]); }
+        if (key[0] != 0xffffffffu) {
+            cur = lnk[0];
+        } else if (sp > 0) {
+            cur = stack_pop(stack, over, sp, stack_cap);
+        } else {
+            cur = kEntryDone;
+        }
+    }
+}
 
 enum { MODE_POOL = 0, MODE_TEST_CLOSEST = 2, MODE_TEST_ANY = 3 };
 
@@ -728,81 +828,13 @@ __global__ void __launch_bounds__(kBlock, 8) k_trace(DScene sc, DPools p, TraceP
                 continue;
             }
         }
-        // ---- inner phase: step through 4-wide node records until no lane holds an inner entry
+        // ---- inner phase: step through node records until no lane holds an inner entry
         while (__ballot(cur >= 0) != 0) {
 #ifdef RT_TRACE_PROFILE
             pf_inner_it++;
             pf_inner_lanes += __popcll(__ballot(cur >= 0));
 #endif
-            if (cur >= 0 && !WIDE) {
-                // 2-wide record: two exact boxes, near child first, far child onto the stack
-                const float4 *q = sc.nodes + 4 * (size_t)cur;
-                float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
-                int cl = __float_as_int(q3.x), cr = __float_as_int(q3.y);
-                float el, er;
-                bool hl = box_hit(o, inv, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tmax, el) && cl != kEntryDone;
-                bool hr = box_hit(o, inv, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tmax, er) && cr != kEntryDone;
-                if (hl && hr) {
-                    bool left_first = !(el > er);
-                    stack_push(stack, over, sp, stack_cap, left_first ? cr : cl);
-                    cur = left_first ? cl : cr;
-                } else if (hl) {
-                    cur = cl;
-                } else if (hr) {
-                    cur = cr;
-                } else if (sp > 0) {
-                    cur = stack_pop(stack, over, sp, stack_cap);
-                } else {
-                    cur = kEntryDone;
-                }
-            }
-            if (cur >= 0 && WIDE) {
-                const float4 *q = sc.nodes + 4 * (size_t)cur;
-                float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
-                const unsigned exps = __float_as_uint(q0.w);
-                const float cx = __uint_as_float((exps & 0xffu) << 23);
-                const float cy = __uint_as_float(((exps >> 8) & 0xffu) << 23);
-                const float cz = __uint_as_float(((exps >> 16) & 0xffu) << 23);
-                const unsigned lox = __float_as_uint(q2.x), loy = __float_as_uint(q2.y), loz = __float_as_uint(q2.z);
-                const unsigned hix = __float_as_uint(q2.w), hiy = __float_as_uint(q3.x), hiz = __float_as_uint(q3.y);
-                const int links[4] = {__float_as_int(q1.x), __float_as_int(q1.y), __float_as_int(q1.z), __float_as_int(q1.w)};
-                // (entry distance, link) of every child the ray may enter; a miss sorts last
-                unsigned key[4];
-                int lnk[4];
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const int sh = 8 * k;
-                    // bound = origin + float(q) * cell : the expression the builder verified (rt_bvh.h)
-                    float bx0 = q0.x + (float)((lox >> sh) & 0xffu) * cx, bx1 = q0.x + (float)((hix >> sh) & 0xffu) * cx;
-                    float by0 = q0.y + (float)((loy >> sh) & 0xffu) * cy, by1 = q0.y + (float)((hiy >> sh) & 0xffu) * cy;
-                    float bz0 = q0.z + (float)((loz >> sh) & 0xffu) * cz, bz1 = q0.z + (float)((hiz >> sh) & 0xffu) * cz;
-                    float e;
-                    bool h = box_hit(o, inv, bx0, by0, bz0, bx1, by1, bz1, tmax, e) && links[k] != kEntryDone;
-                    key[k] = h ? __float_as_uint(fmaxf(e, 0.f)) : 0xffffffffu;
-                    lnk[k] = links[k];
-                }
-                // sorting network on 4 (key, link) pairs, ascending by entry distance
-#define RT_CSWAP(a, b)                                                     \
-    {                                                                      \
-        bool sw = key[b] < key[a];                                         \
-        unsigned ka = sw ? key[b] : key[a], kb = sw ? key[a] : key[b];     \
-        int la = sw ? lnk[b] : lnk[a], lb = sw ? lnk[a] : lnk[b];          \
-        key[a] = ka; key[b] = kb; lnk[a] = la; lnk[b] = lb;                \
-    }
-                RT_CSWAP(0, 1) RT_CSWAP(2, 3) RT_CSWAP(0, 2) RT_CSWAP(1, 3) RT_CSWAP(1, 2)
-#undef RT_CSWAP
-                // far children first onto the stack, nearest becomes the current entry
-                if (key[3] != 0xffffffffu) { stack_push(stack, over, sp, stack_cap, lnk[3]); }
-                if (key[2] != 0xffffffffu) { stack_push(stack, over, sp, stack_cap, lnk[2]); }
-                if (key[1] != 0xffffffffu) { stack_push(stack, over, sp, stack_cap, lnk[1]); }
-                if (key[0] != 0xffffffffu) {
-                    cur = lnk[0];
-                } else if (sp > 0) {
-                    cur = stack_pop(stack, over, sp, stack_cap);
-                } else {
-                    cur = kEntryDone;
-                }
-            }
+            if (cur >= 0) inner_step<WIDE>(sc, o, inv, tmax, cur, sp, stack, over, stack_cap);
         }
         // ---- leaf phase: every lane that holds a leaf tests its triangles (triangle.cuh:39-58)
 #ifdef RT_TRACE_PROFILE
@@ -862,6 +894,205 @@ __global__ void __launch_bounds__(kBlock, 8) k_trace(DScene sc, DPools p, TraceP
         atomicAdd(&tp.prof[9], pf_fin_lanes); atomicAdd(&tp.prof[10], 1ull);
     }
 #endif
+}
+
+// ============================================================================ k_paths
+// The whole asynchronous part of a frame in ONE launch.  A lane owns one path slot for the entire
+// render and keeps its state in registers; the reference's stage kernels become PHASES of the lane:
+//     ADV      init() + mat() + gen()        (advance_core)
+//     ANY      ah():  the slot's shadow ray  (any hit, deposit if unoccluded)
+//     CLOSEST  ch():  the slot's path ray    (closest hit -> hit record for the next ADV)
+// Because a slot never depends on another slot (see the file header) there is no barrier of any
+// kind between rounds: a wave simply keeps all 64 of its slots moving until each has run out of
+// camera rays (or parks for the lockstep final generation).  That removes what dominated the
+// per-round design -- every k_trace launch ended in a drain where a wave waited for its longest
+// ray with ~10 of 64 lanes active, 1 700 times per frame -- together with the per-round state
+// traffic (rays, hit records and shadow rays never leave registers) and 3 400 kernel launches.
+// Divergence between phases is handled by wave-level scheduling: the expensive ADV block runs when
+// at least `adv_batch` lanes wait for it (or nothing else can run), otherwise the wave takes one
+// node step and one leaf step for the lanes that need them.
+enum { PH_ADV = 0, PH_ANY = 1, PH_CLOSEST = 2, PH_IDLE = 3 };
+
+template <bool LDS_TABLES, bool WIDE>
+__global__ void __launch_bounds__(kBlock)
+k_paths(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__ fb, DWaveRow *__restrict__ rows,
+        int stack_cap, int *overflow, int adv_batch, int debug_no_deposit) {
+    extern __shared__ int s_lds[];
+    int *stack = s_lds + threadIdx.x;
+    int *over = overflow + (blockIdx.x * kBlock + threadIdx.x) % kOverStride;
+    float *s_tab = (float *)(s_lds + stack_cap * kBlock);
+    const float *tab = sc.tables;
+    if (LDS_TABLES) {
+        for (int k = threadIdx.x; k < sc.tab_dwords; k += kBlock) s_tab[k] = sc.tables[k];
+        __syncthreads();
+        tab = s_tab;
+    }
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool in_range = i < ap.n;
+    SlotState st;
+    st.bounces = kDone;
+    st.hit_info = -1;
+    st.pixel = 0;
+    st.gen = 0;
+    st.rs = Rng{0, 0, 0, 0, 0, 0};
+    st.beta = st.wo = st.isect_p = st.isect_n = mk(0, 0, 0);
+    if (in_range) {
+        st.bounces = p.bounces[i];
+        st.pixel = p.pixel[i];
+        st.gen = p.gen[i];
+        st.rs = Rng{p.rd[i], p.r0[i], p.r1[i], p.r2[i], p.r3[i], p.r4[i]};
+        st.beta = mk(p.br[i], p.bg[i], p.bb[i]);
+    }
+    int phase = (in_range && st.bounces != kDone && st.bounces != kParked) ? PH_ADV : PH_IDLE;
+    V3 po = mk(0, 0, 0), pd = mk(0, 0, 0);                                // path ray
+    V3 so = mk(0, 0, 0), sd = mk(0, 0, 0), sL = mk(0, 0, 0);               // shadow ray + radiance
+    float s_tmax = 0.f;
+    int s_target = -1;
+    // traversal state of the ray being traced (`tri`: best hit so far / excluded triangle; `hu` doubles
+    // as the occluded flag of a shadow ray, exactly as in k_trace)
+    V3 inv = mk(0, 0, 0);
+    float tmax = 0.f, hu = 0.f, hv = 0.f;
+    int cur = kEntryDone, sp = 0, tri = -1;
+    // wave-uniform event counters
+    unsigned long long n_gen = 0, n_shade = 0, n_traced = 0, n_shadow = 0, n_emit = 0, n_deposit = 0, n_rr = 0;
+
+    while (true) {
+        const unsigned long long m_adv = __ballot(phase == PH_ADV);
+        const unsigned long long m_trav = __ballot(phase == PH_ANY || phase == PH_CLOSEST);
+        if (m_adv == 0 && m_trav == 0) break;
+        if (__popcll(m_adv) >= adv_batch || m_trav == 0) {
+            // ---------------- ADV block
+            AdvanceOut out;
+            out.did_gen = out.did_shade = out.has_shadow = out.did_emit = out.new_ray = false;
+            out.rr_draws = 0;
+            if (phase == PH_ADV) {
+                advance_core(sc, tab, cam, ap, ap.slot_lo + i, st, out, fb);
+                if (out.new_ray) {
+                    po = out.ray_o;
+                    pd = out.ray_d;
+                }
+                if (out.has_shadow) {
+                    so = out.s_o;
+                    sd = out.s_d;
+                    sL = out.s_L;
+                    s_tmax = out.s_tmax;
+                    s_target = out.s_target;
+                    phase = PH_ANY;
+                    inv = inv_dir(sd);
+                    tmax = s_tmax;
+                    tri = s_target;
+                    hu = 0.f;
+                    cur = 0;
+                    sp = 0;
+                } else if (out.new_ray) {
+                    phase = PH_CLOSEST;
+                    inv = inv_dir(pd);
+                    tmax = kFltMax;
+                    tri = -1;
+                    cur = 0;
+                    sp = 0;
+                } else {
+                    phase = PH_IDLE;  // out of camera rays, or parked for the lockstep final generation
+                }
+            }
+            n_gen += __popcll(__ballot(out.did_gen));
+            n_shade += __popcll(__ballot(out.did_shade));
+            n_traced += __popcll(__ballot(out.new_ray));
+            n_shadow += __popcll(__ballot(out.has_shadow));
+            n_emit += __popcll(__ballot(out.did_emit));
+            int rr = out.rr_draws;
+            if (__ballot(rr != 0)) {
+                for (int off = 32; off > 0; off >>= 1) rr += __shfl_xor(rr, off);
+                n_rr += (unsigned long long)rr;
+            }
+            continue;
+        }
+        // ---------------- traversal blocks: one node step, one leaf step
+        const bool trav = phase == PH_ANY || phase == PH_CLOSEST;
+        const bool is_any = phase == PH_ANY;
+        const V3 o = is_any ? so : po;
+        const V3 d = is_any ? sd : pd;
+        if (__ballot(trav && cur >= 0) != 0) {
+            if (trav && cur >= 0) inner_step<WIDE>(sc, o, inv, tmax, cur, sp, stack, over, stack_cap);
+        }
+        if (__ballot(trav && cur != kEntryDone && cur < 0) != 0) {
+            if (trav && cur != kEntryDone && cur < 0) {
+                int ref = ~cur;
+                int first = ref >> 3, count = ref & 7;
+                bool stop = false;
+                for (int k = first; k < first + count; k++) {
+                    Tri tr = load_tri(sc.tris, k);
+                    float t, u, v;
+                    if (tri_intersect(tr, o, d, tmax, t, u, v)) {
+                        if (is_any) {
+                            if (k != tri) {  // bvh.cuh:243
+                                hu = 1.f;
+                                stop = true;
+                                break;
+                            }
+                        } else {  // bvh.cuh:227-231
+                            tmax = t;
+                            hu = u;
+                            hv = v;
+                            tri = k;
+                        }
+                    }
+                }
+                if (stop) cur = kEntryDone;
+                else if (sp > 0) cur = stack_pop(stack, over, sp, stack_cap);
+                else cur = kEntryDone;
+            }
+        }
+        // ---------------- finished rays
+        const bool fin = trav && cur == kEntryDone;
+        n_deposit += __popcll(__ballot(fin && is_any && hu == 0.f));
+        if (fin) {
+            if (is_any) {
+                if (hu == 0.f && !debug_no_deposit) {  // unoccluded: render.cuh:291-293
+                    atomicAdd(&fb[3 * (size_t)st.pixel + 0], sL.x);
+                    atomicAdd(&fb[3 * (size_t)st.pixel + 1], sL.y);
+                    atomicAdd(&fb[3 * (size_t)st.pixel + 2], sL.z);
+                }
+                phase = PH_CLOSEST;  // now the slot's path ray
+                inv = inv_dir(pd);
+                tmax = kFltMax;
+                tri = -1;
+                cur = 0;
+                sp = 0;
+            } else {
+                // hit record in the form mat() consumes (render.cuh:152-153, 311-316)
+                st.hit_info = -1;
+                if (tri >= 0) {
+                    Tri tr = load_tri(sc.tris, tri);
+                    int2 ml = sc.tri_info[tri];
+                    st.isect_p = tri_point(tr, hu, hv);
+                    st.isect_n = neg(unit(tr.n));
+                    st.hit_info = (ml.x & 0xffff) | ((ml.y + 1) << 16);
+                }
+                st.wo = pd;
+                phase = PH_ADV;
+            }
+        }
+    }
+    // ---- hand the slots back to the pools: the lockstep rounds of the final generation continue from here
+    if (in_range) {
+        p.bounces[i] = st.bounces;
+        p.pixel[i] = st.pixel;
+        p.gen[i] = st.gen;
+        p.hit_info[i] = -1;
+        p.stmax[i] = -1.f;
+        p.br[i] = st.beta.x;
+        p.bg[i] = st.beta.y;
+        p.bb[i] = st.beta.z;
+        p.rd[i] = st.rs.d;
+        p.r0[i] = st.rs.v0;
+        p.r1[i] = st.rs.v1;
+        p.r2[i] = st.rs.v2;
+        p.r3[i] = st.rs.v3;
+        p.r4[i] = st.rs.v4;
+    }
+    unsigned long long v[C_COUNT] = {n_gen, n_shade, n_traced, n_shadow, n_emit, n_deposit, n_rr, 0ull};
+    row_add(rows, v);
 }
 
 // post_process_framebuffer (render.cuh:330-338): c = sqrt(c * (1/spp))
@@ -1232,6 +1463,32 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
         *out = evs[ev_used++];
         return 0;
     };
+    // ---- asynchronous part of the frame: ONE persistent launch (k_paths), or -- RT_PERSISTENT=0 -- the
+    // round-per-launch pipeline (k_advance + k_trace) that the lockstep final generation also uses
+    bool persistent = true;
+    if (const char *e = getenv("RT_PERSISTENT")) persistent = atoi(e) != 0;
+    float ms_paths = 0.f;
+    if (persistent) {
+        int adv_batch = 24;
+        if (const char *e = getenv("RT_ADV_BATCH")) adv_batch = std::max(1, std::min(64, atoi(e)));
+        const int paths_cap = std::min(12, std::max(1, scene->stack_bound));
+        int *d_over2 = nullptr;
+        if (ensure_overflow(scene->stack_bound - paths_cap, &d_over2)) return 1;
+        const size_t lds_paths = sizeof(int) * (size_t)kBlock * (size_t)paths_cap + (lds_tables ? sizeof(float) * kTabDwordsMax : 0);
+        const int dbg = (flags & 0x100u) ? 1 : 0;
+        HIP_TRY(hipEventRecord(c.ev_a, st));
+#define RT_LAUNCH_PATHS(T, WD) hipLaunchKernelGGL((k_paths<T, WD>), grid, block, lds_paths, st, sc, c.pools, cam, ap, d_sum, c.d_rows, paths_cap, d_over2, adv_batch, dbg)
+        if (lds_tables && scene->wide) RT_LAUNCH_PATHS(true, true);
+        else if (lds_tables) RT_LAUNCH_PATHS(true, false);
+        else if (scene->wide) RT_LAUNCH_PATHS(false, true);
+        else RT_LAUNCH_PATHS(false, false);
+#undef RT_LAUNCH_PATHS
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(c.ev_b, st));
+        HIP_TRY(hipEventSynchronize(c.ev_b));
+        HIP_TRY(hipEventElapsedTime(&ms_paths, c.ev_a, c.ev_b));
+        finished = true;
+    }
     while (!finished && rounds < max_rounds) {
         for (int k = 0; k < kBatch; k++) {
             ap.round = (int)(rounds & 0x3fffffff);
@@ -1346,6 +1603,13 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
         stats->seconds_advance = t_adv * 1e-3 * scale_up;
         stats->launches_trace = rounds;
         stats->reserved[0] = n_sampled;
+        if (persistent) {  // the frame's dominant kernel is the one k_paths launch
+            stats->seconds_trace = ms_paths * 1e-3;
+            stats->seconds_advance = 0.0;
+            stats->launches_trace = 1;
+            stats->reserved[0] = 1;
+            stats->reserved[1] = 1;
+        }
     }
     return 0;
 }
