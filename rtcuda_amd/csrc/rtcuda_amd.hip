@@ -86,21 +86,61 @@ __device__ __host__ inline int tab_off_ltri(int n_mats, int n_lights) { return 5
 __device__ __host__ inline int tab_off_lpre(int n_mats, int n_lights) { return 5 * n_mats + 20 * n_lights; }
 
 // Structure-of-arrays path state for the slots of one shard (n slots each)
+// Structure-of-arrays path state for the slots of one shard: A_COUNT arrays of n dwords in ONE
+// allocation, array k at base + k * n.  A kernel therefore carries one base pointer (2 SGPRs)
+// instead of 36 array pointers -- the persistent kernel otherwise spends VGPRs and scratch on
+// addresses.
+//   ox..dz            current path ray
+//   hit_info          -1 = miss, else material | (light index + 1) << 16
+//   hpx..hpz          Triangle::p(u, v) of the last closest hit              (render.cuh:152)
+//   hnx..hnz          -d_triangle->n.unit_vector()                           (render.cuh:153)
+//   br, bg, bb        beta
+//   bounces           as PathRayPayload::bounces; kDone / kParked are sentinels
+//   pixel, gen        pixel of the current camera ray; index of the slot's NEXT generation
+//   rd, r0..r4        XORWOW state
+//   sox..slb, starget shadow ray of the slot for this round (stmax < 0: none) + radiance + excluded triangle
+enum { A_OX, A_OY, A_OZ, A_DX, A_DY, A_DZ, A_HPX, A_HPY, A_HPZ, A_HNX, A_HNY, A_HNZ, A_BR, A_BG, A_BB, A_SOX, A_SOY, A_SOZ, A_SDX, A_SDY, A_SDZ, A_STMAX, A_SLR, A_SLG, A_SLB, A_HIT_INFO, A_BOUNCES, A_PIXEL, A_GEN, A_STARGET, A_RD, A_R0, A_R1, A_R2, A_R3, A_R4, A_COUNT };
 struct DPools {
-    float *ox, *oy, *oz, *dx, *dy, *dz;  // current path ray
-    // hit record of the last closest-hit trace, already in the form mat() consumes:
-    int *hit_info;                       // -1 = miss, else material | (light index + 1) << 16
-    float *hpx, *hpy, *hpz;              // Triangle::p(u, v)                      (render.cuh:152)
-    float *hnx, *hny, *hnz;              // -d_triangle->n.unit_vector()           (render.cuh:153)
-    float *br, *bg, *bb;  // beta
-    int *bounces;         // as PathRayPayload::bounces; kDone marks an exhausted slot
-    int *pixel;
-    int *gen;  // index of the slot's NEXT camera-ray generation
-    uint32_t *rd, *r0, *r1, *r2, *r3, *r4;  // XORWOW state
-    // shadow ray of the slot for this round (stmax < 0: none); the any-hit kernel compacts them
-    // wave-locally while it pulls work, so the producer needs no queue, atomics or barriers
-    float *sox, *soy, *soz, *sdx, *sdy, *sdz, *stmax, *slr, *slg, *slb;
-    int *starget;
+    float *base;
+    int n;
+    __device__ __forceinline__ float &ox(int i) const { return base[(size_t)A_OX * n + i]; }
+    __device__ __forceinline__ float &oy(int i) const { return base[(size_t)A_OY * n + i]; }
+    __device__ __forceinline__ float &oz(int i) const { return base[(size_t)A_OZ * n + i]; }
+    __device__ __forceinline__ float &dx(int i) const { return base[(size_t)A_DX * n + i]; }
+    __device__ __forceinline__ float &dy(int i) const { return base[(size_t)A_DY * n + i]; }
+    __device__ __forceinline__ float &dz(int i) const { return base[(size_t)A_DZ * n + i]; }
+    __device__ __forceinline__ float &hpx(int i) const { return base[(size_t)A_HPX * n + i]; }
+    __device__ __forceinline__ float &hpy(int i) const { return base[(size_t)A_HPY * n + i]; }
+    __device__ __forceinline__ float &hpz(int i) const { return base[(size_t)A_HPZ * n + i]; }
+    __device__ __forceinline__ float &hnx(int i) const { return base[(size_t)A_HNX * n + i]; }
+    __device__ __forceinline__ float &hny(int i) const { return base[(size_t)A_HNY * n + i]; }
+    __device__ __forceinline__ float &hnz(int i) const { return base[(size_t)A_HNZ * n + i]; }
+    __device__ __forceinline__ float &br(int i) const { return base[(size_t)A_BR * n + i]; }
+    __device__ __forceinline__ float &bg(int i) const { return base[(size_t)A_BG * n + i]; }
+    __device__ __forceinline__ float &bb(int i) const { return base[(size_t)A_BB * n + i]; }
+    __device__ __forceinline__ float &sox(int i) const { return base[(size_t)A_SOX * n + i]; }
+    __device__ __forceinline__ float &soy(int i) const { return base[(size_t)A_SOY * n + i]; }
+    __device__ __forceinline__ float &soz(int i) const { return base[(size_t)A_SOZ * n + i]; }
+    __device__ __forceinline__ float &sdx(int i) const { return base[(size_t)A_SDX * n + i]; }
+    __device__ __forceinline__ float &sdy(int i) const { return base[(size_t)A_SDY * n + i]; }
+    __device__ __forceinline__ float &sdz(int i) const { return base[(size_t)A_SDZ * n + i]; }
+    __device__ __forceinline__ float &stmax(int i) const { return base[(size_t)A_STMAX * n + i]; }
+    __device__ __forceinline__ float &slr(int i) const { return base[(size_t)A_SLR * n + i]; }
+    __device__ __forceinline__ float &slg(int i) const { return base[(size_t)A_SLG * n + i]; }
+    __device__ __forceinline__ float &slb(int i) const { return base[(size_t)A_SLB * n + i]; }
+    __device__ __forceinline__ int &hit_info(int i) const { return ((int *)base)[(size_t)A_HIT_INFO * n + i]; }
+    __device__ __forceinline__ int &bounces(int i) const { return ((int *)base)[(size_t)A_BOUNCES * n + i]; }
+    __device__ __forceinline__ int &pixel(int i) const { return ((int *)base)[(size_t)A_PIXEL * n + i]; }
+    __device__ __forceinline__ int &gen(int i) const { return ((int *)base)[(size_t)A_GEN * n + i]; }
+    __device__ __forceinline__ int &starget(int i) const { return ((int *)base)[(size_t)A_STARGET * n + i]; }
+    __device__ __forceinline__ uint32_t &rd(int i) const { return ((uint32_t *)base)[(size_t)A_RD * n + i]; }
+    __device__ __forceinline__ uint32_t &r0(int i) const { return ((uint32_t *)base)[(size_t)A_R0 * n + i]; }
+    __device__ __forceinline__ uint32_t &r1(int i) const { return ((uint32_t *)base)[(size_t)A_R1 * n + i]; }
+    __device__ __forceinline__ uint32_t &r2(int i) const { return ((uint32_t *)base)[(size_t)A_R2 * n + i]; }
+    __device__ __forceinline__ uint32_t &r3(int i) const { return ((uint32_t *)base)[(size_t)A_R3 * n + i]; }
+    __device__ __forceinline__ uint32_t &r4(int i) const { return ((uint32_t *)base)[(size_t)A_R4 * n + i]; }
+    // host-side address of array k
+    float *array(int k) const { return base + (size_t)k * n; }
 };
 
 // Global words that need atomics / host polling.  Event counters are NOT here: they live in
@@ -169,12 +209,12 @@ __global__ void k_rng_init(DPools p, int n, int slot_lo, Rng seed_state, const u
 #pragma unroll
         for (int w = 0; w < 5; w++) v[w] = r[w];
     }
-    p.rd[i] = seed_state.d;
-    p.r0[i] = v[0];
-    p.r1[i] = v[1];
-    p.r2[i] = v[2];
-    p.r3[i] = v[3];
-    p.r4[i] = v[4];
+    p.rd(i) = seed_state.d;
+    p.r0(i) = v[0];
+    p.r1(i) = v[1];
+    p.r2(i) = v[2];
+    p.r3(i) = v[3];
+    p.r4(i) = v[4];
 }
 
 // init_path_ray_payload (render.cuh:75-82): every slot starts "finished" so the first round
@@ -183,10 +223,10 @@ __global__ void k_rng_init(DPools p, int n, int slot_lo, Rng seed_state, const u
 __global__ void k_pool_init(DPools p, int n, int max_bounces) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    p.hit_info[i] = -1;
-    p.bounces[i] = max_bounces;
-    p.gen[i] = 0;
-    p.pixel[i] = 0;
+    p.hit_info(i) = -1;
+    p.bounces(i) = max_bounces;
+    p.gen(i) = 0;
+    p.pixel(i) = 0;
 }
 
 // ============================================================================ k_advance
@@ -433,15 +473,15 @@ k_advance(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__
     st.rs = Rng{0, 0, 0, 0, 0, 0};
     st.beta = st.wo = st.isect_p = st.isect_n = mk(0, 0, 0);
     if (in_range) {
-        st.bounces = p.bounces[i];
-        st.hit_info = p.hit_info[i];
-        st.pixel = p.pixel[i];
-        st.gen = p.gen[i];
-        st.rs = Rng{p.rd[i], p.r0[i], p.r1[i], p.r2[i], p.r3[i], p.r4[i]};
-        st.beta = mk(p.br[i], p.bg[i], p.bb[i]);
-        st.wo = mk(p.dx[i], p.dy[i], p.dz[i]);
-        st.isect_p = mk(p.hpx[i], p.hpy[i], p.hpz[i]);
-        st.isect_n = mk(p.hnx[i], p.hny[i], p.hnz[i]);
+        st.bounces = p.bounces(i);
+        st.hit_info = p.hit_info(i);
+        st.pixel = p.pixel(i);
+        st.gen = p.gen(i);
+        st.rs = Rng{p.rd(i), p.r0(i), p.r1(i), p.r2(i), p.r3(i), p.r4(i)};
+        st.beta = mk(p.br(i), p.bg(i), p.bb(i));
+        st.wo = mk(p.dx(i), p.dy(i), p.dz(i));
+        st.isect_p = mk(p.hpx(i), p.hpy(i), p.hpz(i));
+        st.isect_n = mk(p.hnx(i), p.hny(i), p.hnz(i));
     }
     const float *tab = sc.tables;
     if (LDS_TABLES) {
@@ -465,42 +505,42 @@ k_advance(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__
         const int gen_before = st.gen;
         advance_core(sc, tab, cam, ap, ap.slot_lo + i, st, out, fb);
         if (out.new_ray) {
-            p.ox[i] = out.ray_o.x;
-            p.oy[i] = out.ray_o.y;
-            p.oz[i] = out.ray_o.z;
-            p.dx[i] = out.ray_d.x;
-            p.dy[i] = out.ray_d.y;
-            p.dz[i] = out.ray_d.z;
+            p.ox(i) = out.ray_o.x;
+            p.oy(i) = out.ray_o.y;
+            p.oz(i) = out.ray_o.z;
+            p.dx(i) = out.ray_d.x;
+            p.dy(i) = out.ray_d.y;
+            p.dz(i) = out.ray_d.z;
         }
         if (st.gen != gen_before) {
-            p.gen[i] = st.gen;
-            p.pixel[i] = st.pixel;
+            p.gen(i) = st.gen;
+            p.pixel(i) = st.pixel;
         }
         if (out.has_shadow) {
-            p.sox[i] = out.s_o.x;
-            p.soy[i] = out.s_o.y;
-            p.soz[i] = out.s_o.z;
-            p.sdx[i] = out.s_d.x;
-            p.sdy[i] = out.s_d.y;
-            p.sdz[i] = out.s_d.z;
-            p.slr[i] = out.s_L.x;
-            p.slg[i] = out.s_L.y;
-            p.slb[i] = out.s_L.z;
-            p.starget[i] = out.s_target;
-            p.stmax[i] = out.s_tmax;
+            p.sox(i) = out.s_o.x;
+            p.soy(i) = out.s_o.y;
+            p.soz(i) = out.s_o.z;
+            p.sdx(i) = out.s_d.x;
+            p.sdy(i) = out.s_d.y;
+            p.sdz(i) = out.s_d.z;
+            p.slr(i) = out.s_L.x;
+            p.slg(i) = out.s_L.y;
+            p.slb(i) = out.s_L.z;
+            p.starget(i) = out.s_target;
+            p.stmax(i) = out.s_tmax;
         }
-        p.br[i] = st.beta.x;
-        p.bg[i] = st.beta.y;
-        p.bb[i] = st.beta.z;
-        p.bounces[i] = st.bounces;
-        p.rd[i] = st.rs.d;
-        p.r0[i] = st.rs.v0;
-        p.r1[i] = st.rs.v1;
-        p.r2[i] = st.rs.v2;
-        p.r3[i] = st.rs.v3;
-        p.r4[i] = st.rs.v4;
+        p.br(i) = st.beta.x;
+        p.bg(i) = st.beta.y;
+        p.bb(i) = st.beta.z;
+        p.bounces(i) = st.bounces;
+        p.rd(i) = st.rs.d;
+        p.r0(i) = st.rs.v0;
+        p.r1(i) = st.rs.v1;
+        p.r2(i) = st.rs.v2;
+        p.r3(i) = st.rs.v3;
+        p.r4(i) = st.rs.v4;
     }
-    if (in_range && !out.has_shadow) p.stmax[i] = -1.f;  // no shadow ray from this slot this round
+    if (in_range && !out.has_shadow) p.stmax(i) = -1.f;  // no shadow ray from this slot this round
 
     // ---- event counters: this wave's own row
     unsigned long long traced = __ballot(out.did_gen || out.did_shade);
@@ -740,20 +780,20 @@ __global__ void __launch_bounds__(kBlock, 8) k_trace(DScene sc, DPools p, TraceP
                             int2 ml = sc.tri_info[tri];
                             V3 hp = tri_point(tr, hu, hv);
                             V3 hn = neg(unit(tr.n));
-                            p.hpx[slot] = hp.x;
-                            p.hpy[slot] = hp.y;
-                            p.hpz[slot] = hp.z;
-                            p.hnx[slot] = hn.x;
-                            p.hny[slot] = hn.y;
-                            p.hnz[slot] = hn.z;
+                            p.hpx(slot) = hp.x;
+                            p.hpy(slot) = hp.y;
+                            p.hpz(slot) = hp.z;
+                            p.hnx(slot) = hn.x;
+                            p.hny(slot) = hn.y;
+                            p.hnz(slot) = hn.z;
                             info = (ml.x & 0xffff) | ((ml.y + 1) << 16);
                         }
-                        p.hit_info[slot] = info;
+                        p.hit_info(slot) = info;
                     } else if (hu == 0.f && !tp.debug_no_deposit) {  // unoccluded: render.cuh:291-293
-                        int pixel = p.pixel[slot];
-                        atomicAdd(&tp.fb[3 * (size_t)pixel + 0], p.slr[slot]);
-                        atomicAdd(&tp.fb[3 * (size_t)pixel + 1], p.slg[slot]);
-                        atomicAdd(&tp.fb[3 * (size_t)pixel + 2], p.slb[slot]);
+                        int pixel = p.pixel(slot);
+                        atomicAdd(&tp.fb[3 * (size_t)pixel + 0], p.slr(slot));
+                        atomicAdd(&tp.fb[3 * (size_t)pixel + 1], p.slg(slot));
+                        atomicAdd(&tp.fb[3 * (size_t)pixel + 2], p.slb(slot));
                     }
                 } else if (MODE == MODE_TEST_CLOSEST) {
                     tp.out_i[slot] = tri >= 0 ? tp.order[tri] : -1;
@@ -780,7 +820,7 @@ __global__ void __launch_bounds__(kBlock, 8) k_trace(DScene sc, DPools p, TraceP
                         int cand = (any_chunk ? chunk - n_chunks : chunk) * 64 + (int)lane;
                         bool valid = cand < total;
                         if (MODE == MODE_POOL && valid)
-                            valid = any_chunk ? p.stmax[cand] >= 0.f : (p.bounces[cand] != kDone && p.bounces[cand] != kParked);
+                            valid = any_chunk ? p.stmax(cand) >= 0.f : (p.bounces(cand) != kDone && p.bounces(cand) != kParked);
                         unsigned long long vm = __ballot(valid);
                         if (valid) pend[prefix_popc(vm)] = any_chunk ? (cand | kAnyBit) : cand;
                         pend_lo = 0;
@@ -795,13 +835,13 @@ __global__ void __launch_bounds__(kBlock, 8) k_trace(DScene sc, DPools p, TraceP
                         int slot = my & (kAnyBit - 1);
                         if (MODE == MODE_POOL) {
                             if (my & kAnyBit) {
-                                o = mk(p.sox[slot], p.soy[slot], p.soz[slot]);
-                                d = mk(p.sdx[slot], p.sdy[slot], p.sdz[slot]);
-                                tmax = p.stmax[slot];
-                                tri = p.starget[slot];
+                                o = mk(p.sox(slot), p.soy(slot), p.soz(slot));
+                                d = mk(p.sdx(slot), p.sdy(slot), p.sdz(slot));
+                                tmax = p.stmax(slot);
+                                tri = p.starget(slot);
                             } else {
-                                o = mk(p.ox[slot], p.oy[slot], p.oz[slot]);
-                                d = mk(p.dx[slot], p.dy[slot], p.dz[slot]);
+                                o = mk(p.ox(slot), p.oy(slot), p.oz(slot));
+                                d = mk(p.dx(slot), p.dy(slot), p.dz(slot));
                                 tmax = kFltMax;
                                 tri = -1;
                             }
@@ -913,86 +953,155 @@ __global__ void __launch_bounds__(kBlock, 8) k_trace(DScene sc, DPools p, TraceP
 // node step and one leaf step for the lanes that need them.
 enum { PH_ADV = 0, PH_ANY = 1, PH_CLOSEST = 2, PH_IDLE = 3 };
 
-template <bool LDS_TABLES, bool WIDE>
-__global__ void __launch_bounds__(kBlock)
+// Register diet: a lane carries across loop iterations only the slot's persistent state (bounces,
+// pixel, gen, RNG, beta = 12 dwords), ONE ray (o, d, 1/d, tmax) and the traversal cursor (cur, sp,
+// tri, hu, hv).  While a shadow ray is traced, the slot's path ray and the radiance to deposit wait
+// in 9 dwords of LDS per lane; the hit record is rebuilt from (tri, hu, hv) inside the ADV block.
+// LDS layout (dynamic): [stack: stack_cap x kBlock][parked: 9 x kBlock][tables]
+template <bool LDS_TABLES, bool WIDE, bool MAJORITY>
+__global__ void __launch_bounds__(kBlock, 4)
 k_paths(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__ fb, DWaveRow *__restrict__ rows,
         int stack_cap, int *overflow, int adv_batch, int debug_no_deposit) {
     extern __shared__ int s_lds[];
     int *stack = s_lds + threadIdx.x;
+    float *park = (float *)(s_lds + stack_cap * kBlock) + threadIdx.x;  // element k at park[k * kBlock]
     int *over = overflow + (blockIdx.x * kBlock + threadIdx.x) % kOverStride;
-    float *s_tab = (float *)(s_lds + stack_cap * kBlock);
+    float *s_tab = (float *)(s_lds + (stack_cap + 9) * kBlock);
     const float *tab = sc.tables;
     if (LDS_TABLES) {
         for (int k = threadIdx.x; k < sc.tab_dwords; k += kBlock) s_tab[k] = sc.tables[k];
         __syncthreads();
         tab = s_tab;
     }
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool in_range = i < ap.n;
-    SlotState st;
-    st.bounces = kDone;
-    st.hit_info = -1;
-    st.pixel = 0;
-    st.gen = 0;
-    st.rs = Rng{0, 0, 0, 0, 0, 0};
-    st.beta = st.wo = st.isect_p = st.isect_n = mk(0, 0, 0);
-    if (in_range) {
-        st.bounces = p.bounces[i];
-        st.pixel = p.pixel[i];
-        st.gen = p.gen[i];
-        st.rs = Rng{p.rd[i], p.r0[i], p.r1[i], p.r2[i], p.r3[i], p.r4[i]};
-        st.beta = mk(p.br[i], p.bg[i], p.bb[i]);
-    }
-    int phase = (in_range && st.bounces != kDone && st.bounces != kParked) ? PH_ADV : PH_IDLE;
-    V3 po = mk(0, 0, 0), pd = mk(0, 0, 0);                                // path ray
-    V3 so = mk(0, 0, 0), sd = mk(0, 0, 0), sL = mk(0, 0, 0);               // shadow ray + radiance
-    float s_tmax = 0.f;
-    int s_target = -1;
-    // traversal state of the ray being traced (`tri`: best hit so far / excluded triangle; `hu` doubles
-    // as the occluded flag of a shadow ray, exactly as in k_trace)
-    V3 inv = mk(0, 0, 0);
+    // A lane works through the slots i, i + G, i + 2G, ... (G = lanes of the grid), each for the whole
+    // frame, one after the other: with G dividing the slot count every lane gets the same number of
+    // slots, so all lanes -- and all workgroups, which are all resident -- finish together.
+    const int lanes_in_grid = (int)(gridDim.x * blockDim.x);
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    // persistent slot state
+    int bounces = kDone, pixel = 0, gen = 0;
+    Rng rs{0, 0, 0, 0, 0, 0};
+    V3 beta = mk(0, 0, 0);
+    auto load_slot = [&](int k) {
+        bounces = p.bounces(k);
+        pixel = p.pixel(k);
+        gen = p.gen(k);
+        rs = Rng{p.rd(k), p.r0(k), p.r1(k), p.r2(k), p.r3(k), p.r4(k)};
+        beta = mk(p.br(k), p.bg(k), p.bb(k));
+    };
+    // hand a finished slot back to the pools: the lockstep rounds of the final generation continue from there
+    auto store_slot = [&](int k) {
+        p.bounces(k) = bounces;
+        p.pixel(k) = pixel;
+        p.gen(k) = gen;
+        p.hit_info(k) = -1;
+        p.stmax(k) = -1.f;
+        p.br(k) = beta.x;
+        p.bg(k) = beta.y;
+        p.bb(k) = beta.z;
+        p.rd(k) = rs.d;
+        p.r0(k) = rs.v0;
+        p.r1(k) = rs.v1;
+        p.r2(k) = rs.v2;
+        p.r3(k) = rs.v3;
+        p.r4(k) = rs.v4;
+    };
+    int phase = PH_IDLE;
+    // the ray being traced, and the traversal cursor (`tri`: best hit so far / excluded triangle;
+    // `hu` doubles as the occluded flag of a shadow ray, exactly as in k_trace).  Between the end of
+    // a closest-hit trace and the ADV block, (tri, hu, hv, d) ARE the hit record.
+    V3 o = mk(0, 0, 0), d = mk(0, 0, 0), inv = mk(0, 0, 0);
     float tmax = 0.f, hu = 0.f, hv = 0.f;
     int cur = kEntryDone, sp = 0, tri = -1;
+    if (i < ap.n) {
+        load_slot(i);
+        phase = (bounces != kDone && bounces != kParked) ? PH_ADV : PH_IDLE;
+    }
     // wave-uniform event counters
     unsigned long long n_gen = 0, n_shade = 0, n_traced = 0, n_shadow = 0, n_emit = 0, n_deposit = 0, n_rr = 0;
 
     while (true) {
-        const unsigned long long m_adv = __ballot(phase == PH_ADV);
-        const unsigned long long m_trav = __ballot(phase == PH_ANY || phase == PH_CLOSEST);
-        if (m_adv == 0 && m_trav == 0) break;
-        if (__popcll(m_adv) >= adv_batch || m_trav == 0) {
+        // ---- what each lane wants next: the ADV block, a node step, or triangle tests
+        const bool trav = phase == PH_ANY || phase == PH_CLOSEST;
+        const bool want_node = trav && cur >= 0;
+        const bool want_tri = trav && cur != kEntryDone && cur < 0;
+        const int n_adv = __popcll(__ballot(phase == PH_ADV));
+        const int n_node = __popcll(__ballot(want_node));
+        const int n_tri = __popcll(__ballot(want_tri));
+        if (n_adv + n_node + n_tri == 0) break;
+        // Every block is issued for the whole wave whatever the number of lanes that need it.  The ADV
+        // block is ~15x longer than a node step or a triangle test, so it waits for `adv_batch` lanes
+        // unless nothing else can run.  MAJORITY additionally runs only the more popular of the two
+        // traversal blocks per iteration (one triangle per lane per iteration).
+        bool run_adv = n_adv > 0 && (n_adv >= adv_batch || n_node + n_tri == 0);
+        if (MAJORITY) run_adv = n_adv > 0 && ((n_adv >= adv_batch && n_adv >= n_node && n_adv >= n_tri) || n_node + n_tri == 0);
+        if (run_adv) {
             // ---------------- ADV block
             AdvanceOut out;
             out.did_gen = out.did_shade = out.has_shadow = out.did_emit = out.new_ray = false;
             out.rr_draws = 0;
             if (phase == PH_ADV) {
-                advance_core(sc, tab, cam, ap, ap.slot_lo + i, st, out, fb);
-                if (out.new_ray) {
-                    po = out.ray_o;
-                    pd = out.ray_d;
+                SlotState st;
+                st.bounces = bounces;
+                st.pixel = pixel;
+                st.gen = gen;
+                st.rs = rs;
+                st.beta = beta;
+                st.wo = d;
+                st.hit_info = -1;
+                st.isect_p = st.isect_n = mk(0, 0, 0);
+                if (tri >= 0) {  // hit record in the form mat() consumes (render.cuh:152-153, 311-316)
+                    Tri tr = load_tri(sc.tris, tri);
+                    int2 ml = sc.tri_info[tri];
+                    st.isect_p = tri_point(tr, hu, hv);
+                    st.isect_n = neg(unit(tr.n));
+                    st.hit_info = (ml.x & 0xffff) | ((ml.y + 1) << 16);
                 }
+                advance_core(sc, tab, cam, ap, ap.slot_lo + i, st, out, fb);
+                bounces = st.bounces;
+                pixel = st.pixel;
+                gen = st.gen;
+                rs = st.rs;
+                beta = st.beta;
                 if (out.has_shadow) {
-                    so = out.s_o;
-                    sd = out.s_d;
-                    sL = out.s_L;
-                    s_tmax = out.s_tmax;
-                    s_target = out.s_target;
+                    park[0 * kBlock] = out.ray_o.x;
+                    park[1 * kBlock] = out.ray_o.y;
+                    park[2 * kBlock] = out.ray_o.z;
+                    park[3 * kBlock] = out.ray_d.x;
+                    park[4 * kBlock] = out.ray_d.y;
+                    park[5 * kBlock] = out.ray_d.z;
+                    park[6 * kBlock] = out.s_L.x;
+                    park[7 * kBlock] = out.s_L.y;
+                    park[8 * kBlock] = out.s_L.z;
+                    o = out.s_o;
+                    d = out.s_d;
                     phase = PH_ANY;
-                    inv = inv_dir(sd);
-                    tmax = s_tmax;
-                    tri = s_target;
+                    tmax = out.s_tmax;
+                    tri = out.s_target;
                     hu = 0.f;
-                    cur = 0;
-                    sp = 0;
                 } else if (out.new_ray) {
+                    o = out.ray_o;
+                    d = out.ray_d;
                     phase = PH_CLOSEST;
-                    inv = inv_dir(pd);
                     tmax = kFltMax;
                     tri = -1;
+                } else {
+                    // this slot is out of camera rays (or parked for the lockstep final generation):
+                    // hand it back and take the lane's next slot
+                    store_slot(i);
+                    phase = PH_IDLE;
+                    tri = -1;
+                    i += lanes_in_grid;
+                    if (i < ap.n) {
+                        load_slot(i);
+                        if (bounces != kDone && bounces != kParked) phase = PH_ADV;
+                        else i = ap.n;  // (cannot happen: untouched slots start alive)
+                    }
+                }
+                if (phase == PH_ANY || phase == PH_CLOSEST) {
+                    inv = inv_dir(d);
                     cur = 0;
                     sp = 0;
-                } else {
-                    phase = PH_IDLE;  // out of camera rays, or parked for the lockstep final generation
                 }
             }
             n_gen += __popcll(__ballot(out.did_gen));
@@ -1007,40 +1116,38 @@ k_paths(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__ f
             }
             continue;
         }
-        // ---------------- traversal blocks: one node step, one leaf step
-        const bool trav = phase == PH_ANY || phase == PH_CLOSEST;
         const bool is_any = phase == PH_ANY;
-        const V3 o = is_any ? so : po;
-        const V3 d = is_any ? sd : pd;
-        if (__ballot(trav && cur >= 0) != 0) {
-            if (trav && cur >= 0) inner_step<WIDE>(sc, o, inv, tmax, cur, sp, stack, over, stack_cap);
+        // ---------------- node step
+        if (n_node > 0 && (!MAJORITY || n_node >= n_tri)) {
+            if (want_node) inner_step<WIDE>(sc, o, inv, tmax, cur, sp, stack, over, stack_cap);
         }
-        if (__ballot(trav && cur != kEntryDone && cur < 0) != 0) {
-            if (trav && cur != kEntryDone && cur < 0) {
-                int ref = ~cur;
-                int first = ref >> 3, count = ref & 7;
+        // ---------------- triangle tests (triangle.cuh:39-58): the leaf reference is the cursor
+        if (n_tri > 0 && (!MAJORITY || n_tri > n_node)) {
+            if (want_tri) {
                 bool stop = false;
-                for (int k = first; k < first + count; k++) {
+                do {
+                    int ref = ~cur;
+                    int k = ref >> 3, count = ref & 7;
                     Tri tr = load_tri(sc.tris, k);
                     float t, u, v;
                     if (tri_intersect(tr, o, d, tmax, t, u, v)) {
                         if (is_any) {
-                            if (k != tri) {  // bvh.cuh:243
+                            if (k != tri) {  // bvh.cuh:243: first accepted hit that is not the excluded triangle
                                 hu = 1.f;
                                 stop = true;
-                                break;
                             }
-                        } else {  // bvh.cuh:227-231
+                        } else {  // bvh.cuh:227-231: later equal-t hit wins (t <= tmax)
                             tmax = t;
                             hu = u;
                             hv = v;
                             tri = k;
                         }
                     }
-                }
-                if (stop) cur = kEntryDone;
-                else if (sp > 0) cur = stack_pop(stack, over, sp, stack_cap);
-                else cur = kEntryDone;
+                    if (stop) cur = kEntryDone;
+                    else if (count > 1) cur = leaf_ref(k + 1, count - 1);
+                    else if (sp > 0) cur = stack_pop(stack, over, sp, stack_cap);
+                    else cur = kEntryDone;
+                } while (!MAJORITY && cur != kEntryDone && cur < 0 && !stop);  // !MAJORITY: the whole leaf (and chained leaves) now
             }
         }
         // ---------------- finished rays
@@ -1049,47 +1156,23 @@ k_paths(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__ f
         if (fin) {
             if (is_any) {
                 if (hu == 0.f && !debug_no_deposit) {  // unoccluded: render.cuh:291-293
-                    atomicAdd(&fb[3 * (size_t)st.pixel + 0], sL.x);
-                    atomicAdd(&fb[3 * (size_t)st.pixel + 1], sL.y);
-                    atomicAdd(&fb[3 * (size_t)st.pixel + 2], sL.z);
+                    atomicAdd(&fb[3 * (size_t)pixel + 0], park[6 * kBlock]);
+                    atomicAdd(&fb[3 * (size_t)pixel + 1], park[7 * kBlock]);
+                    atomicAdd(&fb[3 * (size_t)pixel + 2], park[8 * kBlock]);
                 }
-                phase = PH_CLOSEST;  // now the slot's path ray
-                inv = inv_dir(pd);
+                // now the slot's path ray
+                o = mk(park[0 * kBlock], park[1 * kBlock], park[2 * kBlock]);
+                d = mk(park[3 * kBlock], park[4 * kBlock], park[5 * kBlock]);
+                phase = PH_CLOSEST;
+                inv = inv_dir(d);
                 tmax = kFltMax;
                 tri = -1;
                 cur = 0;
                 sp = 0;
             } else {
-                // hit record in the form mat() consumes (render.cuh:152-153, 311-316)
-                st.hit_info = -1;
-                if (tri >= 0) {
-                    Tri tr = load_tri(sc.tris, tri);
-                    int2 ml = sc.tri_info[tri];
-                    st.isect_p = tri_point(tr, hu, hv);
-                    st.isect_n = neg(unit(tr.n));
-                    st.hit_info = (ml.x & 0xffff) | ((ml.y + 1) << 16);
-                }
-                st.wo = pd;
-                phase = PH_ADV;
+                phase = PH_ADV;  // (tri, hu, hv, d) carry the hit to the ADV block
             }
         }
-    }
-    // ---- hand the slots back to the pools: the lockstep rounds of the final generation continue from here
-    if (in_range) {
-        p.bounces[i] = st.bounces;
-        p.pixel[i] = st.pixel;
-        p.gen[i] = st.gen;
-        p.hit_info[i] = -1;
-        p.stmax[i] = -1.f;
-        p.br[i] = st.beta.x;
-        p.bg[i] = st.beta.y;
-        p.bb[i] = st.beta.z;
-        p.rd[i] = st.rs.d;
-        p.r0[i] = st.rs.v0;
-        p.r1[i] = st.rs.v1;
-        p.r2[i] = st.rs.v2;
-        p.r3[i] = st.rs.v3;
-        p.r4[i] = st.rs.v4;
     }
     unsigned long long v[C_COUNT] = {n_gen, n_shade, n_traced, n_shadow, n_emit, n_deposit, n_rr, 0ull};
     row_add(rows, v);
@@ -1105,7 +1188,7 @@ __global__ void k_post_process(float *fb, int n_values, float inv_spp) {
 __global__ void k_test_draw(DPools p, int n, int draws, uint32_t *__restrict__ state6, float *__restrict__ uni) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    Rng rs{p.rd[i], p.r0[i], p.r1[i], p.r2[i], p.r3[i], p.r4[i]};
+    Rng rs{p.rd(i), p.r0(i), p.r1(i), p.r2(i), p.r3(i), p.r4(i)};
     for (int k = 0; k < draws; k++) uni[(size_t)i * draws + k] = rng_uniform(rs);
     state6[6 * (size_t)i + 0] = rs.d;
     state6[6 * (size_t)i + 1] = rs.v0;
@@ -1256,16 +1339,8 @@ int get_context(int n, int lane, Context **out) {
     c->n = n;
     c->lane = lane;
     DPools &p = c->pools;
-    float **fptrs[] = {&p.ox, &p.oy, &p.oz, &p.dx, &p.dy, &p.dz, &p.hpx, &p.hpy, &p.hpz, &p.hnx, &p.hny, &p.hnz, &p.br, &p.bg, &p.bb,
-                       &p.sox, &p.soy, &p.soz, &p.sdx, &p.sdy, &p.sdz, &p.stmax, &p.slr, &p.slg, &p.slb};
-    for (float **f : fptrs)
-        if (dev_alloc(*c, *f, (size_t)n)) return 1;
-    int **iptrs[] = {&p.hit_info, &p.bounces, &p.pixel, &p.gen, &p.starget};
-    for (int **f : iptrs)
-        if (dev_alloc(*c, *f, (size_t)n)) return 1;
-    uint32_t **uptrs[] = {&p.rd, &p.r0, &p.r1, &p.r2, &p.r3, &p.r4};
-    for (uint32_t **f : uptrs)
-        if (dev_alloc(*c, *f, (size_t)n)) return 1;
+    p.n = n;
+    if (dev_alloc(*c, p.base, (size_t)A_COUNT * n)) return 1;
     if (dev_alloc(*c, c->rng_backup, (size_t)6 * n)) return 1;
     if (dev_alloc(*c, c->d_ctr, 1)) return 1;
     c->n_rows = ((n + kBlock - 1) / kBlock) * (kBlock / 64);
@@ -1331,7 +1406,8 @@ int ensure_overflow(int levels, int **out) {
 
 int ensure_rng(Context &c, uint64_t seed, int slot_lo, hipStream_t st, double *seconds) {
     const size_t bytes = sizeof(uint32_t) * (size_t)c.n;
-    uint32_t *parts[6] = {c.pools.rd, c.pools.r0, c.pools.r1, c.pools.r2, c.pools.r3, c.pools.r4};
+    uint32_t *parts[6];
+    for (int k = 0; k < 6; k++) parts[k] = (uint32_t *)c.pools.array(A_RD + k);
     *seconds = 0.0;
     if (!(c.rng_valid && c.rng_seed == seed && c.rng_lo == slot_lo)) {
         HIP_TRY(hipEventRecord(c.ev_a, st));
@@ -1474,14 +1550,31 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
         const int paths_cap = std::min(12, std::max(1, scene->stack_bound));
         int *d_over2 = nullptr;
         if (ensure_overflow(scene->stack_bound - paths_cap, &d_over2)) return 1;
-        const size_t lds_paths = sizeof(int) * (size_t)kBlock * (size_t)paths_cap + (lds_tables ? sizeof(float) * kTabDwordsMax : 0);
+        const size_t lds_paths = sizeof(int) * (size_t)kBlock * (size_t)(paths_cap + 9) + (lds_tables ? sizeof(float) * kTabDwordsMax : 0);
+        bool majority = false;
+        if (const char *e = getenv("RT_MAJORITY")) majority = atoi(e) != 0;
         const int dbg = (flags & 0x100u) ? 1 : 0;
+        // all workgroups resident at once (4 per CU at <= 128 VGPRs), lane count a divisor of n
+        int paths_blocks = grid_for(n);
+        {
+            int want = 1024;
+            if (const char *e = getenv("RT_PATHS_BLOCKS")) want = std::max(1, atoi(e));
+            while (paths_blocks > want && paths_blocks % 2 == 0) paths_blocks /= 2;
+        }
+        const dim3 grid_paths(paths_blocks);
         HIP_TRY(hipEventRecord(c.ev_a, st));
-#define RT_LAUNCH_PATHS(T, WD) hipLaunchKernelGGL((k_paths<T, WD>), grid, block, lds_paths, st, sc, c.pools, cam, ap, d_sum, c.d_rows, paths_cap, d_over2, adv_batch, dbg)
-        if (lds_tables && scene->wide) RT_LAUNCH_PATHS(true, true);
-        else if (lds_tables) RT_LAUNCH_PATHS(true, false);
-        else if (scene->wide) RT_LAUNCH_PATHS(false, true);
-        else RT_LAUNCH_PATHS(false, false);
+#define RT_LAUNCH_PATHS(T, WD, MJ) hipLaunchKernelGGL((k_paths<T, WD, MJ>), grid_paths, block, lds_paths, st, sc, c.pools, cam, ap, d_sum, c.d_rows, paths_cap, d_over2, adv_batch, dbg)
+        if (majority) {
+            if (lds_tables && scene->wide) RT_LAUNCH_PATHS(true, true, true);
+            else if (lds_tables) RT_LAUNCH_PATHS(true, false, true);
+            else if (scene->wide) RT_LAUNCH_PATHS(false, true, true);
+            else RT_LAUNCH_PATHS(false, false, true);
+        } else {
+            if (lds_tables && scene->wide) RT_LAUNCH_PATHS(true, true, false);
+            else if (lds_tables) RT_LAUNCH_PATHS(true, false, false);
+            else if (scene->wide) RT_LAUNCH_PATHS(false, true, false);
+            else RT_LAUNCH_PATHS(false, false, false);
+        }
 #undef RT_LAUNCH_PATHS
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(c.ev_b, st));
@@ -1967,8 +2060,8 @@ int rt_xorwow_states(uint64_t seed, uint32_t first, uint32_t count, int draws, u
     uint32_t *buf = nullptr, *d_state = nullptr, *d_jump = nullptr;
     float *d_uni = nullptr;
     HIP_TRY(hipMalloc((void **)&buf, sizeof(uint32_t) * 6 * (size_t)count));
-    p.rd = buf; p.r0 = buf + count; p.r1 = buf + 2 * (size_t)count; p.r2 = buf + 3 * (size_t)count;
-    p.r3 = buf + 4 * (size_t)count; p.r4 = buf + 5 * (size_t)count;
+    p.n = (int)count;  // only the six RNG arrays are touched: place array A_RD at buf
+    p.base = (float *)buf - (size_t)A_RD * count;
     HIP_TRY(hipMalloc((void **)&d_state, sizeof(uint32_t) * 6 * (size_t)count));
     HIP_TRY(hipMalloc((void **)&d_uni, sizeof(float) * std::max<size_t>(1, (size_t)count * draws)));
     HIP_TRY(hipMalloc((void **)&d_jump, sizeof(uint32_t) * 20 * 800));
