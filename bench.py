@@ -60,6 +60,7 @@ def main():
     ap.add_argument("--cpu-spp", type=int, default=4, help="spp of the bounded CPU-baseline sample")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--save-image", default="")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--debug-flags", type=int, default=0, help="perf experiments only (results invalid)")
     args = ap.parse_args()
 
@@ -74,10 +75,14 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP library is the product and there is no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    dev_index = local_rank % max(torch.cuda.device_count(), 1)  # rehearsals may put several ranks on one GPU
+    torch.cuda.set_device(dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(args.backend)
 
     from rtcuda_amd import api, scenes, dist as rtdist
 
@@ -160,25 +165,45 @@ def main():
                 np_src = f"oracle statistics of the cpu_baseline sample ({args.cpu_spp} spp)"
         else:
             out["cpu_baseline"] = None
-        # ---- roofline of the dominant kernel: k_trace<MODE_POOL> (closest-hit + any-hit rays, one launch/round)
+        # ---- roofline of the dominant kernel.  Default pipeline: ONE k_paths launch per frame (init + mat +
+        # gen + ch + ah of every slot as phases of a persistent kernel), so "per launch" = per frame and the
+        # algorithmic bytes are SURVEY 8d's whole-sample formula
+        #   B = 153 g + 49 (max_bounces + 1) g + 430 m + closest_bytes c + any_bytes a
+        # (g camera rays, m shade events, c / a closest- / any-hit rays, counted by the run itself).
+        # With RT_PERSISTENT=0 the dominant kernel is k_trace<MODE_POOL> (one launch per round) and only the
+        # two ray terms apply.
         if agg["launches_trace"] > 0 and agg["seconds_trace"] > 0:
             launches = agg["launches_trace"]
+            persistent = launches == args.steps
             c_per = agg["closest_rays"] / launches
             a_per = agg["any_rays"] / launches
             avg_s = agg["seconds_trace"] / launches
             bytes_per_launch = closest_ray_bytes(np_c, tt_c) * c_per + any_ray_bytes(np_a, tt_a) * a_per
+            if persistent:
+                g_per = float(w) * h * spp / world
+                m_per = agg["shade_events"] / launches
+                bytes_per_launch += (153.0 + 49.0 * (args.max_bounces + 1)) * g_per + 430.0 * m_per
             achieved = bytes_per_launch / avg_s / 1e9
             out["roofline"] = {
-                "kernel": "k_trace<MODE_POOL>", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                "kernel": "k_paths" if persistent else "k_trace<MODE_POOL>", "bound": "hbm",
+                "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                 "bytes_per_closest_ray": round(closest_ray_bytes(np_c, tt_c), 1),
                 "bytes_per_any_ray": round(any_ray_bytes(np_a, tt_a), 1), "np_tt_source": np_src,
+                "bytes_per_sample": round(bytes_per_launch / (float(w) * h * spp / world), 1) if persistent else None,
                 "closest_rays_per_launch": round(c_per, 1), "any_rays_per_launch": round(a_per, 1),
                 "avg_launch_us": round(avg_s * 1e6, 2), "launches": launches,
                 "stage_share_of_render": {
-                    "trace": round(agg["seconds_trace"] / max(agg["seconds_render"], 1e-12), 4),
+                    "dominant": round(agg["seconds_trace"] / max(agg["seconds_render"], 1e-12), 4),
                     "advance": round(agg["seconds_advance"] / max(agg["seconds_render"], 1e-12), 4)},
                 "grays_per_s": round((agg["closest_rays"] + agg["any_rays"]) / max(agg["seconds_trace"], 1e-12) / 1e9, 3)}
+            traffic_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            if os.path.exists(traffic_file):
+                tr = json.load(open(traffic_file))
+                key = f"{args.scene}_{w}x{h}x{spp}_n{world}"
+                if key in tr and tr[key].get("kernel") == out["roofline"]["kernel"]:
+                    out["roofline"]["traffic"] = tr[key]["hbm_bytes_per_launch"]
+                    out["roofline"]["traffic_note"] = tr[key].get("note", "")
         else:
             out["roofline"] = None
         out["per_frame"] = {"closest_rays": agg["closest_rays"] // max(args.steps, 1),

@@ -953,11 +953,12 @@ __global__ void __launch_bounds__(kBlock, 8) k_trace(DScene sc, DPools p, TraceP
 // node step and one leaf step for the lanes that need them.
 enum { PH_ADV = 0, PH_ANY = 1, PH_CLOSEST = 2, PH_IDLE = 3 };
 
-// Register diet: a lane carries across loop iterations only the slot's persistent state (bounces,
-// pixel, gen, RNG, beta = 12 dwords), ONE ray (o, d, 1/d, tmax) and the traversal cursor (cur, sp,
-// tri, hu, hv).  While a shadow ray is traced, the slot's path ray and the radiance to deposit wait
-// in 9 dwords of LDS per lane; the hit record is rebuilt from (tri, hu, hv) inside the ADV block.
-// LDS layout (dynamic): [stack: stack_cap x kBlock][parked: 9 x kBlock][tables]
+// Register diet: across loop iterations a lane carries only ONE ray (o, d, 1/d, tmax) and the
+// traversal cursor (cur, sp, tri, hu, hv).  The slot's persistent state (bounces, pixel, gen, RNG,
+// beta = 12 dwords) lives in the lane's LDS column and is only in registers inside the ADV block;
+// while a shadow ray is traced, the slot's path ray and the radiance to deposit wait in 9 more
+// dwords of LDS; the hit record is rebuilt from (tri, hu, hv) inside the ADV block.
+// LDS layout (dynamic): [stack: stack_cap x kBlock][parked ray: 9 x kBlock][slot state: 12 x kBlock][tables]
 template <bool LDS_TABLES, bool WIDE, bool MAJORITY>
 __global__ void __launch_bounds__(kBlock, 4)
 k_paths(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__ fb, DWaveRow *__restrict__ rows,
@@ -966,7 +967,8 @@ k_paths(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__ f
     int *stack = s_lds + threadIdx.x;
     float *park = (float *)(s_lds + stack_cap * kBlock) + threadIdx.x;  // element k at park[k * kBlock]
     int *over = overflow + (blockIdx.x * kBlock + threadIdx.x) % kOverStride;
-    float *s_tab = (float *)(s_lds + (stack_cap + 9) * kBlock);
+    int *cold = s_lds + (stack_cap + 9) * kBlock + threadIdx.x;  // element k at cold[k * kBlock]
+    float *s_tab = (float *)(s_lds + (stack_cap + 21) * kBlock);
     const float *tab = sc.tables;
     if (LDS_TABLES) {
         for (int k = threadIdx.x; k < sc.tab_dwords; k += kBlock) s_tab[k] = sc.tables[k];
@@ -1006,6 +1008,28 @@ k_paths(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__ f
         p.r3(k) = rs.v3;
         p.r4(k) = rs.v4;
     };
+    auto cold_save = [&]() {
+        cold[0 * kBlock] = bounces;
+        cold[1 * kBlock] = pixel;
+        cold[2 * kBlock] = gen;
+        cold[3 * kBlock] = (int)rs.d;
+        cold[4 * kBlock] = (int)rs.v0;
+        cold[5 * kBlock] = (int)rs.v1;
+        cold[6 * kBlock] = (int)rs.v2;
+        cold[7 * kBlock] = (int)rs.v3;
+        cold[8 * kBlock] = (int)rs.v4;
+        cold[9 * kBlock] = __float_as_int(beta.x);
+        cold[10 * kBlock] = __float_as_int(beta.y);
+        cold[11 * kBlock] = __float_as_int(beta.z);
+    };
+    auto cold_load = [&]() {
+        bounces = cold[0 * kBlock];
+        pixel = cold[1 * kBlock];
+        gen = cold[2 * kBlock];
+        rs = Rng{(uint32_t)cold[3 * kBlock], (uint32_t)cold[4 * kBlock], (uint32_t)cold[5 * kBlock],
+                 (uint32_t)cold[6 * kBlock], (uint32_t)cold[7 * kBlock], (uint32_t)cold[8 * kBlock]};
+        beta = mk(__int_as_float(cold[9 * kBlock]), __int_as_float(cold[10 * kBlock]), __int_as_float(cold[11 * kBlock]));
+    };
     int phase = PH_IDLE;
     // the ray being traced, and the traversal cursor (`tri`: best hit so far / excluded triangle;
     // `hu` doubles as the occluded flag of a shadow ray, exactly as in k_trace).  Between the end of
@@ -1016,6 +1040,7 @@ k_paths(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__ f
     if (i < ap.n) {
         load_slot(i);
         phase = (bounces != kDone && bounces != kParked) ? PH_ADV : PH_IDLE;
+        cold_save();
     }
     // wave-uniform event counters
     unsigned long long n_gen = 0, n_shade = 0, n_traced = 0, n_shadow = 0, n_emit = 0, n_deposit = 0, n_rr = 0;
@@ -1041,6 +1066,7 @@ k_paths(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__ f
             out.did_gen = out.did_shade = out.has_shadow = out.did_emit = out.new_ray = false;
             out.rr_draws = 0;
             if (phase == PH_ADV) {
+                cold_load();  // the slot state is only live between here and cold_save() below
                 SlotState st;
                 st.bounces = bounces;
                 st.pixel = pixel;
@@ -1103,6 +1129,7 @@ k_paths(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__ f
                     cur = 0;
                     sp = 0;
                 }
+                if (phase != PH_IDLE) cold_save();
             }
             n_gen += __popcll(__ballot(out.did_gen));
             n_shade += __popcll(__ballot(out.did_shade));
@@ -1156,6 +1183,7 @@ k_paths(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__ f
         if (fin) {
             if (is_any) {
                 if (hu == 0.f && !debug_no_deposit) {  // unoccluded: render.cuh:291-293
+                    const int pixel = cold[1 * kBlock];
                     atomicAdd(&fb[3 * (size_t)pixel + 0], park[6 * kBlock]);
                     atomicAdd(&fb[3 * (size_t)pixel + 1], park[7 * kBlock]);
                     atomicAdd(&fb[3 * (size_t)pixel + 2], park[8 * kBlock]);
@@ -1545,13 +1573,13 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
     if (const char *e = getenv("RT_PERSISTENT")) persistent = atoi(e) != 0;
     float ms_paths = 0.f;
     if (persistent) {
-        int adv_batch = 24;
+        int adv_batch = 40;
         if (const char *e = getenv("RT_ADV_BATCH")) adv_batch = std::max(1, std::min(64, atoi(e)));
-        const int paths_cap = std::min(12, std::max(1, scene->stack_bound));
+        const int paths_cap = std::min(8, std::max(1, scene->stack_bound));
         int *d_over2 = nullptr;
         if (ensure_overflow(scene->stack_bound - paths_cap, &d_over2)) return 1;
-        const size_t lds_paths = sizeof(int) * (size_t)kBlock * (size_t)(paths_cap + 9) + (lds_tables ? sizeof(float) * kTabDwordsMax : 0);
-        bool majority = false;
+        const size_t lds_paths = sizeof(int) * (size_t)kBlock * (size_t)(paths_cap + 21) + (lds_tables ? sizeof(float) * kTabDwordsMax : 0);
+        bool majority = true;
         if (const char *e = getenv("RT_MAJORITY")) majority = atoi(e) != 0;
         const int dbg = (flags & 0x100u) ? 1 : 0;
         // all workgroups resident at once (4 per CU at <= 128 VGPRs), lane count a divisor of n
