@@ -231,3 +231,57 @@ def test_cpp_drop_in_driver_matches_python_path(api, gpu_matte, tmp_path):
     ref = np.clip((np.float32(256.0) * img).astype(np.int64), 0, 255)
     # identical contributions; a float-atomic ordering difference can flip a quantisation boundary
     assert (got != ref).mean() < 1e-3 and np.abs(got - ref).max() <= 1
+
+
+def test_round_pipeline_and_persistent_kernel_agree(api, oracle, gpu_full, monkeypatch):
+    """The frame as one persistent launch (k_paths, default) and as one launch per round
+    (k_advance + k_trace, RT_PERSISTENT=0) are the same estimator: identical event totals and image."""
+    w, h, spp = 160, 90, 16
+    cam = api.make_camera(aspect=w / h)
+    img_p, st_p = gpu_full.render(cam, w, h, spp)
+    monkeypatch.setenv("RT_PERSISTENT", "0")
+    img_r, st_r = gpu_full.render(cam, w, h, spp)
+    monkeypatch.delenv("RT_PERSISTENT")
+    for k in ("camera_rays", "shade_events", "closest_rays", "any_rays", "emission_adds", "shadow_adds", "rr_draws"):
+        assert st_p[k] == st_r[k], k
+    assert st_r["iterations"] > st_p["iterations"]
+    assert _rms(img_p, img_r).max() < 2e-6
+    # and the scheduling variants of the persistent kernel change nothing but speed
+    monkeypatch.setenv("RT_MAJORITY", "0")
+    monkeypatch.setenv("RT_ADV_BATCH", "7")
+    img_m, st_m = gpu_full.render(cam, w, h, spp)
+    assert st_m["shade_events"] == st_p["shade_events"] and _rms(img_m, img_p).max() < 2e-6
+
+
+def test_both_node_formats_match_oracle(api, oracle, cpu_matte, bunny_matte, monkeypatch):
+    """2-wide exact records (default) and 4-wide quantised records are both conservative culling
+    structures over the same triangle test: same hits as the oracle."""
+    cam = default_camera(oracle, 16 / 9)
+    o, d = raygen.camera_rays(cam, 1920, 1080, 150_000, seed=31)
+    tmax = np.full(len(o), FLT_MAX, np.float32)
+    c = cpu_matte.trace_closest(o, d, tmax)
+    o2, d2 = raygen.bounce_rays(o, d, c[1], c[0] >= 0, seed=32)
+    for wide in ("0", "1"):
+        monkeypatch.setenv("RT_BVH_WIDE", wide)
+        sc = api.Scene(bunny_matte)
+        assert sc.info()["pairs"] > 1000
+        _closest_compare(sc, cpu_matte, o, d, tmax, 2e-5)
+        _closest_compare(sc, cpu_matte, o2, d2, np.full(len(o2), FLT_MAX, np.float32), 2e-5)
+        sc.close()
+
+
+def test_deep_bvh_four_bunnies(api, oracle):
+    """BASELINE config 4's geometry (277 816 triangles, deeper tree): traversal parity and a small render."""
+    from rtcuda_amd import scenes
+    arrays = scenes.cornell_bunny("four_bunnies")
+    gpu, cpu = api.Scene(arrays), oracle.scene(arrays)
+    cam = default_camera(oracle, 16 / 9)
+    o, d = raygen.camera_rays(cam, 1920, 1080, 200_000, seed=41)
+    g, c, _ = _closest_compare(gpu, cpu, o, d, np.full(len(o), FLT_MAX, np.float32), 2e-5)
+    o2, d2 = raygen.bounce_rays(o, d, c[1], c[0] >= 0, seed=42)
+    _closest_compare(gpu, cpu, o2, d2, np.full(len(o2), FLT_MAX, np.float32), 2e-5)
+    w, h, spp = 64, 36, 8
+    img_c, _, st_c = cpu.render(cam, w, h, spp, threads=8)
+    img_g, st_g = gpu.render(api.make_camera(aspect=w / h), w, h, spp)
+    assert st_g["shade_events"] == st_c["sum_mat"] and st_g["any_rays"] == st_c["sum_ah"]
+    assert _rms(img_g, img_c).max() < 2e-6
