@@ -962,7 +962,7 @@ enum { PH_ADV = 0, PH_ANY = 1, PH_CLOSEST = 2, PH_IDLE = 3 };
 template <bool LDS_TABLES, bool WIDE, bool MAJORITY>
 __global__ void __launch_bounds__(kBlock, 4)
 k_paths(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__ fb, DWaveRow *__restrict__ rows,
-        int stack_cap, int *overflow, int adv_batch, int debug_no_deposit) {
+        int stack_cap, int *overflow, int adv_batch, int debug_no_deposit, unsigned long long *prof) {
     extern __shared__ int s_lds[];
     int *stack = s_lds + threadIdx.x;
     float *park = (float *)(s_lds + stack_cap * kBlock) + threadIdx.x;  // element k at park[k * kBlock]
@@ -1044,6 +1044,9 @@ k_paths(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__ f
     }
     // wave-uniform event counters
     unsigned long long n_gen = 0, n_shade = 0, n_traced = 0, n_shadow = 0, n_emit = 0, n_deposit = 0, n_rr = 0;
+#ifdef RT_TRACE_PROFILE
+    unsigned long long pf[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
 
     while (true) {
         // ---- what each lane wants next: the ADV block, a node step, or triangle tests
@@ -1061,6 +1064,9 @@ k_paths(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__ f
         bool run_adv = n_adv > 0 && (n_adv >= adv_batch || n_node + n_tri == 0);
         if (MAJORITY) run_adv = n_adv > 0 && ((n_adv >= adv_batch && n_adv >= n_node && n_adv >= n_tri) || n_node + n_tri == 0);
         if (run_adv) {
+#ifdef RT_TRACE_PROFILE
+            pf[0]++; pf[1] += n_adv;
+#endif
             // ---------------- ADV block
             AdvanceOut out;
             out.did_gen = out.did_shade = out.has_shadow = out.did_emit = out.new_ray = false;
@@ -1146,10 +1152,16 @@ k_paths(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__ f
         const bool is_any = phase == PH_ANY;
         // ---------------- node step
         if (n_node > 0 && (!MAJORITY || n_node >= n_tri)) {
+#ifdef RT_TRACE_PROFILE
+            pf[2]++; pf[3] += n_node; pf[6] += n_adv;
+#endif
             if (want_node) inner_step<WIDE>(sc, o, inv, tmax, cur, sp, stack, over, stack_cap);
         }
         // ---------------- triangle tests (triangle.cuh:39-58): the leaf reference is the cursor
         if (n_tri > 0 && (!MAJORITY || n_tri > n_node)) {
+#ifdef RT_TRACE_PROFILE
+            pf[4]++; pf[5] += n_tri; pf[7] += n_adv;
+#endif
             if (want_tri) {
                 bool stop = false;
                 do {
@@ -1202,6 +1214,10 @@ k_paths(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__ f
             }
         }
     }
+#ifdef RT_TRACE_PROFILE
+    if (prof && lane_id() == 0)
+        for (int k = 0; k < 8; k++) atomicAdd(&prof[k], pf[k]);
+#endif
     unsigned long long v[C_COUNT] = {n_gen, n_shade, n_traced, n_shadow, n_emit, n_deposit, n_rr, 0ull};
     row_add(rows, v);
 }
@@ -1340,6 +1356,7 @@ struct Context {
     bool rng_valid = false;
     uint32_t *rng_backup = nullptr;  // 6 x n words
     std::vector<hipEvent_t> timing_events;
+    std::mutex busy;  // a context (pools, counters, events) serves one render at a time
 };
 std::mutex g_ctx_mutex;
 std::vector<std::unique_ptr<Context>> g_contexts;
@@ -1477,6 +1494,7 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
     Context *cp = nullptr;
     if (get_context(n, ctx_lane, &cp)) return 1;
     Context &c = *cp;
+    std::lock_guard<std::mutex> busy_lock(c.busy);  // concurrent callers with the same (device, n) queue up here
     double rng_seconds = 0.0;
     if (ensure_rng(c, seed, slot_lo, st, &rng_seconds)) return 1;
 
@@ -1582,6 +1600,11 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
         bool majority = true;
         if (const char *e = getenv("RT_MAJORITY")) majority = atoi(e) != 0;
         const int dbg = (flags & 0x100u) ? 1 : 0;
+        unsigned long long *paths_prof = nullptr;
+#ifdef RT_TRACE_PROFILE
+        HIP_TRY(hipMalloc((void **)&paths_prof, 64));
+        HIP_TRY(hipMemset(paths_prof, 0, 64));
+#endif
         // all workgroups resident at once (4 per CU at <= 128 VGPRs), lane count a divisor of n
         int paths_blocks = grid_for(n);
         {
@@ -1591,7 +1614,7 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
         }
         const dim3 grid_paths(paths_blocks);
         HIP_TRY(hipEventRecord(c.ev_a, st));
-#define RT_LAUNCH_PATHS(T, WD, MJ) hipLaunchKernelGGL((k_paths<T, WD, MJ>), grid_paths, block, lds_paths, st, sc, c.pools, cam, ap, d_sum, c.d_rows, paths_cap, d_over2, adv_batch, dbg)
+#define RT_LAUNCH_PATHS(T, WD, MJ) hipLaunchKernelGGL((k_paths<T, WD, MJ>), grid_paths, block, lds_paths, st, sc, c.pools, cam, ap, d_sum, c.d_rows, paths_cap, d_over2, adv_batch, dbg, paths_prof)
         if (majority) {
             if (lds_tables && scene->wide) RT_LAUNCH_PATHS(true, true, true);
             else if (lds_tables) RT_LAUNCH_PATHS(true, false, true);
@@ -1608,6 +1631,16 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
         HIP_TRY(hipEventRecord(c.ev_b, st));
         HIP_TRY(hipEventSynchronize(c.ev_b));
         HIP_TRY(hipEventElapsedTime(&ms_paths, c.ev_a, c.ev_b));
+#ifdef RT_TRACE_PROFILE
+        {
+            unsigned long long h[8];
+            HIP_TRY(hipMemcpy(h, paths_prof, 64, hipMemcpyDeviceToHost));
+            fprintf(stderr, "k_paths profile: ADV blocks %llu avg lanes %.1f | node steps %llu avg lanes %.1f (ADV-waiting %.1f) | tri steps %llu avg lanes %.1f (ADV-waiting %.1f)\n",
+                    h[0], h[0] ? (double)h[1] / h[0] : 0.0, h[2], h[2] ? (double)h[3] / h[2] : 0.0, h[2] ? (double)h[6] / h[2] : 0.0, h[4],
+                    h[4] ? (double)h[5] / h[4] : 0.0, h[4] ? (double)h[7] / h[4] : 0.0);
+            (void)hipFree(paths_prof);
+        }
+#endif
         finished = true;
     }
     while (!finished && rounds < max_rounds) {
