@@ -78,9 +78,11 @@ struct Tri {
 };
 // 48-byte record = 3 x float4: (p0.xyz, e1.x) (e1.yz, e2.xy) (e2.z, n.xyz)
 RT_DEV Tri load_tri(const float4 *__restrict__ tris, int k) {
-    float4 a = tris[3 * k + 0];
-    float4 b = tris[3 * k + 1];
-    float4 c = tris[3 * k + 2];
+    // 32-bit byte offset from a uniform base: lets the compiler use the SGPR-base addressing form
+    const float4 *q = (const float4 *)((const char *)tris + (unsigned)k * 48u);
+    float4 a = q[0];
+    float4 b = q[1];
+    float4 c = q[2];
     Tri t;
     t.p0 = mk(a.x, a.y, a.z);
     t.e1 = mk(a.w, b.x, b.y);

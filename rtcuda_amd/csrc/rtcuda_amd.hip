@@ -103,42 +103,42 @@ enum { A_OX, A_OY, A_OZ, A_DX, A_DY, A_DZ, A_HPX, A_HPY, A_HPZ, A_HNX, A_HNY, A_
 struct DPools {
     float *base;
     int n;
-    __device__ __forceinline__ float &ox(int i) const { return base[(size_t)A_OX * n + i]; }
-    __device__ __forceinline__ float &oy(int i) const { return base[(size_t)A_OY * n + i]; }
-    __device__ __forceinline__ float &oz(int i) const { return base[(size_t)A_OZ * n + i]; }
-    __device__ __forceinline__ float &dx(int i) const { return base[(size_t)A_DX * n + i]; }
-    __device__ __forceinline__ float &dy(int i) const { return base[(size_t)A_DY * n + i]; }
-    __device__ __forceinline__ float &dz(int i) const { return base[(size_t)A_DZ * n + i]; }
-    __device__ __forceinline__ float &hpx(int i) const { return base[(size_t)A_HPX * n + i]; }
-    __device__ __forceinline__ float &hpy(int i) const { return base[(size_t)A_HPY * n + i]; }
-    __device__ __forceinline__ float &hpz(int i) const { return base[(size_t)A_HPZ * n + i]; }
-    __device__ __forceinline__ float &hnx(int i) const { return base[(size_t)A_HNX * n + i]; }
-    __device__ __forceinline__ float &hny(int i) const { return base[(size_t)A_HNY * n + i]; }
-    __device__ __forceinline__ float &hnz(int i) const { return base[(size_t)A_HNZ * n + i]; }
-    __device__ __forceinline__ float &br(int i) const { return base[(size_t)A_BR * n + i]; }
-    __device__ __forceinline__ float &bg(int i) const { return base[(size_t)A_BG * n + i]; }
-    __device__ __forceinline__ float &bb(int i) const { return base[(size_t)A_BB * n + i]; }
-    __device__ __forceinline__ float &sox(int i) const { return base[(size_t)A_SOX * n + i]; }
-    __device__ __forceinline__ float &soy(int i) const { return base[(size_t)A_SOY * n + i]; }
-    __device__ __forceinline__ float &soz(int i) const { return base[(size_t)A_SOZ * n + i]; }
-    __device__ __forceinline__ float &sdx(int i) const { return base[(size_t)A_SDX * n + i]; }
-    __device__ __forceinline__ float &sdy(int i) const { return base[(size_t)A_SDY * n + i]; }
-    __device__ __forceinline__ float &sdz(int i) const { return base[(size_t)A_SDZ * n + i]; }
-    __device__ __forceinline__ float &stmax(int i) const { return base[(size_t)A_STMAX * n + i]; }
-    __device__ __forceinline__ float &slr(int i) const { return base[(size_t)A_SLR * n + i]; }
-    __device__ __forceinline__ float &slg(int i) const { return base[(size_t)A_SLG * n + i]; }
-    __device__ __forceinline__ float &slb(int i) const { return base[(size_t)A_SLB * n + i]; }
-    __device__ __forceinline__ int &hit_info(int i) const { return ((int *)base)[(size_t)A_HIT_INFO * n + i]; }
-    __device__ __forceinline__ int &bounces(int i) const { return ((int *)base)[(size_t)A_BOUNCES * n + i]; }
-    __device__ __forceinline__ int &pixel(int i) const { return ((int *)base)[(size_t)A_PIXEL * n + i]; }
-    __device__ __forceinline__ int &gen(int i) const { return ((int *)base)[(size_t)A_GEN * n + i]; }
-    __device__ __forceinline__ int &starget(int i) const { return ((int *)base)[(size_t)A_STARGET * n + i]; }
-    __device__ __forceinline__ uint32_t &rd(int i) const { return ((uint32_t *)base)[(size_t)A_RD * n + i]; }
-    __device__ __forceinline__ uint32_t &r0(int i) const { return ((uint32_t *)base)[(size_t)A_R0 * n + i]; }
-    __device__ __forceinline__ uint32_t &r1(int i) const { return ((uint32_t *)base)[(size_t)A_R1 * n + i]; }
-    __device__ __forceinline__ uint32_t &r2(int i) const { return ((uint32_t *)base)[(size_t)A_R2 * n + i]; }
-    __device__ __forceinline__ uint32_t &r3(int i) const { return ((uint32_t *)base)[(size_t)A_R3 * n + i]; }
-    __device__ __forceinline__ uint32_t &r4(int i) const { return ((uint32_t *)base)[(size_t)A_R4 * n + i]; }
+    __device__ __forceinline__ float &ox(int i) const { return base[(unsigned)(A_OX * n + i)]; }
+    __device__ __forceinline__ float &oy(int i) const { return base[(unsigned)(A_OY * n + i)]; }
+    __device__ __forceinline__ float &oz(int i) const { return base[(unsigned)(A_OZ * n + i)]; }
+    __device__ __forceinline__ float &dx(int i) const { return base[(unsigned)(A_DX * n + i)]; }
+    __device__ __forceinline__ float &dy(int i) const { return base[(unsigned)(A_DY * n + i)]; }
+    __device__ __forceinline__ float &dz(int i) const { return base[(unsigned)(A_DZ * n + i)]; }
+    __device__ __forceinline__ float &hpx(int i) const { return base[(unsigned)(A_HPX * n + i)]; }
+    __device__ __forceinline__ float &hpy(int i) const { return base[(unsigned)(A_HPY * n + i)]; }
+    __device__ __forceinline__ float &hpz(int i) const { return base[(unsigned)(A_HPZ * n + i)]; }
+    __device__ __forceinline__ float &hnx(int i) const { return base[(unsigned)(A_HNX * n + i)]; }
+    __device__ __forceinline__ float &hny(int i) const { return base[(unsigned)(A_HNY * n + i)]; }
+    __device__ __forceinline__ float &hnz(int i) const { return base[(unsigned)(A_HNZ * n + i)]; }
+    __device__ __forceinline__ float &br(int i) const { return base[(unsigned)(A_BR * n + i)]; }
+    __device__ __forceinline__ float &bg(int i) const { return base[(unsigned)(A_BG * n + i)]; }
+    __device__ __forceinline__ float &bb(int i) const { return base[(unsigned)(A_BB * n + i)]; }
+    __device__ __forceinline__ float &sox(int i) const { return base[(unsigned)(A_SOX * n + i)]; }
+    __device__ __forceinline__ float &soy(int i) const { return base[(unsigned)(A_SOY * n + i)]; }
+    __device__ __forceinline__ float &soz(int i) const { return base[(unsigned)(A_SOZ * n + i)]; }
+    __device__ __forceinline__ float &sdx(int i) const { return base[(unsigned)(A_SDX * n + i)]; }
+    __device__ __forceinline__ float &sdy(int i) const { return base[(unsigned)(A_SDY * n + i)]; }
+    __device__ __forceinline__ float &sdz(int i) const { return base[(unsigned)(A_SDZ * n + i)]; }
+    __device__ __forceinline__ float &stmax(int i) const { return base[(unsigned)(A_STMAX * n + i)]; }
+    __device__ __forceinline__ float &slr(int i) const { return base[(unsigned)(A_SLR * n + i)]; }
+    __device__ __forceinline__ float &slg(int i) const { return base[(unsigned)(A_SLG * n + i)]; }
+    __device__ __forceinline__ float &slb(int i) const { return base[(unsigned)(A_SLB * n + i)]; }
+    __device__ __forceinline__ int &hit_info(int i) const { return ((int *)base)[(unsigned)(A_HIT_INFO * n + i)]; }
+    __device__ __forceinline__ int &bounces(int i) const { return ((int *)base)[(unsigned)(A_BOUNCES * n + i)]; }
+    __device__ __forceinline__ int &pixel(int i) const { return ((int *)base)[(unsigned)(A_PIXEL * n + i)]; }
+    __device__ __forceinline__ int &gen(int i) const { return ((int *)base)[(unsigned)(A_GEN * n + i)]; }
+    __device__ __forceinline__ int &starget(int i) const { return ((int *)base)[(unsigned)(A_STARGET * n + i)]; }
+    __device__ __forceinline__ uint32_t &rd(int i) const { return ((uint32_t *)base)[(unsigned)(A_RD * n + i)]; }
+    __device__ __forceinline__ uint32_t &r0(int i) const { return ((uint32_t *)base)[(unsigned)(A_R0 * n + i)]; }
+    __device__ __forceinline__ uint32_t &r1(int i) const { return ((uint32_t *)base)[(unsigned)(A_R1 * n + i)]; }
+    __device__ __forceinline__ uint32_t &r2(int i) const { return ((uint32_t *)base)[(unsigned)(A_R2 * n + i)]; }
+    __device__ __forceinline__ uint32_t &r3(int i) const { return ((uint32_t *)base)[(unsigned)(A_R3 * n + i)]; }
+    __device__ __forceinline__ uint32_t &r4(int i) const { return ((uint32_t *)base)[(unsigned)(A_R4 * n + i)]; }
     // host-side address of array k
     float *array(int k) const { return base + (size_t)k * n; }
 };
@@ -631,7 +631,7 @@ __device__ __forceinline__ void inner_step(const DScene &sc, V3 o, V3 inv, float
                                            int *over, int stack_cap) {
     if (!WIDE) {
         // 2-wide record: two exact boxes, near child first, far child onto the stack
-        const float4 *q = sc.nodes + 4 * (size_t)cur;
+        const float4 *q = (const float4 *)((const char *)sc.nodes + ((unsigned)cur << 6));
         float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
         int cl = __float_as_int(q3.x), cr = __float_as_int(q3.y);
         float el, er;
@@ -652,7 +652,7 @@ __device__ __forceinline__ void inner_step(const DScene &sc, V3 o, V3 inv, float
         }
     }
     if (WIDE) {
-        const float4 *q = sc.nodes + 4 * (size_t)cur;
+        const float4 *q = (const float4 *)((const char *)sc.nodes + ((unsigned)cur << 6));
         float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
         const unsigned exps = __float_as_uint(q0.w);
         const float cx = __uint_as_float((exps & 0xffu) << 23);
