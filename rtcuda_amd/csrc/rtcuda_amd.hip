@@ -334,9 +334,9 @@ __device__ __forceinline__ void advance_core(const DScene &sc, const float *tab,
     while (true) {
         if (st.bounces == 0 && hit && light_of_hit >= 0) {  // :98-103 emission only at bounce 0
             Light l = tab_light(tab, sc.num_mats, light_of_hit);
-            atomicAdd(&fb[3 * (size_t)st.pixel + 0], l.lx);
-            atomicAdd(&fb[3 * (size_t)st.pixel + 1], l.ly);
-            atomicAdd(&fb[3 * (size_t)st.pixel + 2], l.lz);
+            atomicAdd(&fb[(unsigned)(3 * st.pixel + 0)], l.lx);
+            atomicAdd(&fb[(unsigned)(3 * st.pixel + 1)], l.ly);
+            atomicAdd(&fb[(unsigned)(3 * st.pixel + 2)], l.lz);
             out.did_emit = true;
         }
         bool cont = st.bounces < ap.max_bounces;  // :109
@@ -777,7 +777,7 @@ __global__ void __launch_bounds__(kBlock, 8) k_trace(DScene sc, DPools p, TraceP
                         int info = -1;
                         if (tri >= 0) {
                             Tri tr = load_tri(sc.tris, tri);
-                            int2 ml = sc.tri_info[tri];
+                            int2 ml = sc.tri_info[(unsigned)tri];
                             V3 hp = tri_point(tr, hu, hv);
                             V3 hn = neg(unit(tr.n));
                             p.hpx(slot) = hp.x;
@@ -791,9 +791,9 @@ __global__ void __launch_bounds__(kBlock, 8) k_trace(DScene sc, DPools p, TraceP
                         p.hit_info(slot) = info;
                     } else if (hu == 0.f && !tp.debug_no_deposit) {  // unoccluded: render.cuh:291-293
                         int pixel = p.pixel(slot);
-                        atomicAdd(&tp.fb[3 * (size_t)pixel + 0], p.slr(slot));
-                        atomicAdd(&tp.fb[3 * (size_t)pixel + 1], p.slg(slot));
-                        atomicAdd(&tp.fb[3 * (size_t)pixel + 2], p.slb(slot));
+                        atomicAdd(&tp.fb[(unsigned)(3 * pixel + 0)], p.slr(slot));
+                        atomicAdd(&tp.fb[(unsigned)(3 * pixel + 1)], p.slg(slot));
+                        atomicAdd(&tp.fb[(unsigned)(3 * pixel + 2)], p.slb(slot));
                     }
                 } else if (MODE == MODE_TEST_CLOSEST) {
                     tp.out_i[slot] = tri >= 0 ? tp.order[tri] : -1;
@@ -959,8 +959,8 @@ enum { PH_ADV = 0, PH_ANY = 1, PH_CLOSEST = 2, PH_IDLE = 3 };
 // while a shadow ray is traced, the slot's path ray and the radiance to deposit wait in 9 more
 // dwords of LDS; the hit record is rebuilt from (tri, hu, hv) inside the ADV block.
 // LDS layout (dynamic): [stack: stack_cap x kBlock][parked ray: 9 x kBlock][slot state: 12 x kBlock][tables]
-template <bool LDS_TABLES, bool WIDE, bool MAJORITY>
-__global__ void __launch_bounds__(kBlock, 4)
+template <bool LDS_TABLES, bool WIDE, bool MAJORITY, int MIN_WAVES>
+__global__ void __launch_bounds__(kBlock, MIN_WAVES)
 k_paths(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__ fb, DWaveRow *__restrict__ rows,
         int stack_cap, int *overflow, int adv_batch, int debug_no_deposit, unsigned long long *prof) {
     extern __shared__ int s_lds[];
@@ -1084,7 +1084,7 @@ k_paths(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__ f
                 st.isect_p = st.isect_n = mk(0, 0, 0);
                 if (tri >= 0) {  // hit record in the form mat() consumes (render.cuh:152-153, 311-316)
                     Tri tr = load_tri(sc.tris, tri);
-                    int2 ml = sc.tri_info[tri];
+                    int2 ml = sc.tri_info[(unsigned)tri];
                     st.isect_p = tri_point(tr, hu, hv);
                     st.isect_n = neg(unit(tr.n));
                     st.hit_info = (ml.x & 0xffff) | ((ml.y + 1) << 16);
@@ -1196,9 +1196,9 @@ k_paths(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__ f
             if (is_any) {
                 if (hu == 0.f && !debug_no_deposit) {  // unoccluded: render.cuh:291-293
                     const int pixel = cold[1 * kBlock];
-                    atomicAdd(&fb[3 * (size_t)pixel + 0], park[6 * kBlock]);
-                    atomicAdd(&fb[3 * (size_t)pixel + 1], park[7 * kBlock]);
-                    atomicAdd(&fb[3 * (size_t)pixel + 2], park[8 * kBlock]);
+                    atomicAdd(&fb[(unsigned)(3 * pixel + 0)], park[6 * kBlock]);
+                    atomicAdd(&fb[(unsigned)(3 * pixel + 1)], park[7 * kBlock]);
+                    atomicAdd(&fb[(unsigned)(3 * pixel + 2)], park[8 * kBlock]);
                 }
                 // now the slot's path ray
                 o = mk(park[0 * kBlock], park[1 * kBlock], park[2 * kBlock]);
@@ -1613,8 +1613,21 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
             while (paths_blocks > want && paths_blocks % 2 == 0) paths_blocks /= 2;
         }
         const dim3 grid_paths(paths_blocks);
+        int dev_cus_paths = 0;
+        HIP_TRY(hipDeviceGetAttribute(&dev_cus_paths, hipDeviceAttributeMultiprocessorCount, dev));
         HIP_TRY(hipEventRecord(c.ev_a, st));
-#define RT_LAUNCH_PATHS(T, WD, MJ) hipLaunchKernelGGL((k_paths<T, WD, MJ>), grid_paths, block, lds_paths, st, sc, c.pools, cam, ap, d_sum, c.d_rows, paths_cap, d_over2, adv_batch, dbg, paths_prof)
+// MIN_WAVES: 4 waves per SIMD (128 VGPRs, some spills) when the grid fills the chip, 2 (256 VGPRs, no
+        // spills) when the shard is so small that only 2 workgroups per CU exist anyway (8-GPU runs)
+#define RT_LAUNCH_PATHS(T, WD, MJ)                                                                                     \
+    do {                                                                                                               \
+        if (few_blocks)                                                                                                \
+            hipLaunchKernelGGL((k_paths<T, WD, MJ, 2>), grid_paths, block, lds_paths, st, sc, c.pools, cam, ap, d_sum,   \
+                               c.d_rows, paths_cap, d_over2, adv_batch, dbg, paths_prof);                              \
+        else                                                                                                           \
+            hipLaunchKernelGGL((k_paths<T, WD, MJ, 4>), grid_paths, block, lds_paths, st, sc, c.pools, cam, ap, d_sum,   \
+                               c.d_rows, paths_cap, d_over2, adv_batch, dbg, paths_prof);                              \
+    } while (0)
+        const bool few_blocks = paths_blocks <= 2 * dev_cus_paths;
         if (majority) {
             if (lds_tables && scene->wide) RT_LAUNCH_PATHS(true, true, true);
             else if (lds_tables) RT_LAUNCH_PATHS(true, false, true);
