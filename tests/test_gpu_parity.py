@@ -285,3 +285,55 @@ def test_deep_bvh_four_bunnies(api, oracle):
     img_g, st_g = gpu.render(api.make_camera(aspect=w / h), w, h, spp)
     assert st_g["shade_events"] == st_c["sum_mat"] and st_g["any_rays"] == st_c["sum_ah"]
     assert _rms(img_g, img_c).max() < 2e-6
+
+
+def _box_scene(lights_kind):
+    """Bare Cornell box (12 triangles) with a chosen light set: edge cases of the light code paths."""
+    from rtcuda_amd import scenes
+    a = scenes.cornell_bunny("matte", bunny=False)
+    if lights_kind == "point":      # Light::make_point_light (light.cuh:70-76): is_delta, no MIS block, no emission
+        lights = np.zeros(1, scenes.LIGHT_DTYPE)
+        lights[0] = (scenes.POINT_LIGHT, (0.7, 0.15, -0.6), -1, (0.5, 0.5, 0.5))
+        a.lights = lights
+        a.tri_light = np.full(a.n_tris, -1, np.int32)
+    elif lights_kind == "mixed":    # one area light + one point light
+        lights = np.zeros(2, scenes.LIGHT_DTYPE)
+        lights[0] = a.lights[0]
+        lights[1] = (scenes.POINT_LIGHT, (0.3, 0.8, -0.3), -1, (0.2, 0.3, 0.4))
+        a.lights = lights
+        a.tri_light = np.where(a.tri_light == 0, 0, -1).astype(np.int32)
+    elif lights_kind == "none":     # num_lights == 0: mat() returns after the path ray (render.cuh:174-177)
+        a.lights = np.zeros(0, scenes.LIGHT_DTYPE)
+        a.tri_light = np.full(a.n_tris, -1, np.int32)
+    return a
+
+
+@pytest.mark.parametrize("kind", ["point", "mixed", "none"])
+def test_light_code_paths_match_oracle(api, oracle, kind):
+    arrays = _box_scene(kind)
+    w, h, spp = 48, 48, 8
+    img_c, _, st_c = oracle.scene(arrays).render(default_camera(oracle, 1.0), w, h, spp, threads=8)
+    img_g, st_g = api.Scene(arrays).render(api.make_camera(aspect=1.0), w, h, spp)
+    assert st_g["shade_events"] == st_c["sum_mat"] and st_g["any_rays"] == st_c["sum_ah"]
+    assert st_g["emission_adds"] == st_c["emission_adds"] and st_g["shadow_adds"] == st_c["ah_adds"]
+    assert _rms(img_g, img_c).max() < 2e-6
+    if kind == "none":
+        assert st_g["any_rays"] == 0 and not img_g.any()
+    else:
+        assert img_g.any()
+
+
+def test_empty_and_single_triangle_scenes(api, oracle):
+    from rtcuda_amd import scenes
+    base = scenes.cornell_bunny("matte", bunny=False)
+    empty = scenes.SceneArrays(tris=np.zeros((0, 9), np.float32), tri_material=np.zeros(0, np.int32),
+                               tri_light=np.zeros(0, np.int32), materials=base.materials,
+                               lights=np.zeros(0, scenes.LIGHT_DTYPE))
+    img, st = api.Scene(empty).render(api.make_camera(aspect=1.0), 16, 16, 4)
+    assert not img.any() and st["camera_rays"] == 16 * 16 * 4 and st["shade_events"] == 0
+    one = scenes.SceneArrays(tris=base.tris[8:9].copy(), tri_material=np.array([2], np.int32),
+                             tri_light=np.array([-1], np.int32), materials=base.materials,
+                             lights=np.zeros(0, scenes.LIGHT_DTYPE))
+    g = api.Scene(one)
+    o, d = raygen.camera_rays(default_camera(oracle, 1.0), 64, 64, 5000, seed=51)
+    _closest_compare(g, oracle.scene(one), o, d, np.full(len(o), FLT_MAX, np.float32), 0.0)
