@@ -3,8 +3,8 @@
 // Every function that feeds the image is written as an explicit sequence of fp32 operations in
 // the evaluation order the reference's expressions have (vec3.cuh operator forms, SURVEY.md
 // Appendix A.8); the translation unit is compiled with -ffp-contract=off, so these are the same
-// roundings the CPU oracle performs and per-ray results can be compared bit for bit.  Where FMA
-// is wanted (box tests, which only cull) it is requested explicitly with __builtin_fmaf.
+// roundings the CPU oracle performs and per-ray results can be compared bit for bit.  (The box
+// tests in rtcuda_amd.hip only cull and are free to use any conservative arithmetic.)
 #ifndef RT_DEVICE_H
 #define RT_DEVICE_H
 

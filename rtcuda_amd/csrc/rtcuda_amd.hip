@@ -13,18 +13,26 @@
 //     active fraction decays 100 % -> 2 % inside every 11-iteration generation) without changing
 //     one random number, and makes the image invariant under any partition of the slots -- which
 //     is how the work is sharded over GPUs.
-//   * One round = three kernels, no host synchronisation inside the loop (the reference does four
-//     blocking 4-byte read-backs per iteration: render.cuh:433-434,444-445):
-//       k_advance        init() + mat() + gen() fused per slot (render.cuh:84-275): emission,
-//                        Russian roulette (repeated for "killed" slots exactly as the reference
-//                        re-rolls them), BSDF sampling, NEE; writes the next path ray in place and
-//                        appends the shadow ray to a compact queue with one atomic per wave
-//                        (ballot + mbcnt) instead of flag arrays + CUB select (render.cuh:348-364)
-//       k_trace<POOL_CLOSEST>  ch() (render.cuh:297-328): persistent while-while BVH closest hit, LDS stack
-//       k_trace<QUEUE_ANY>     ah() (render.cuh:278-294): any-hit over the shadow queue, float atomics
-//                        into the raw-sum framebuffer
-//   * BVH: 64-byte pair records (both child boxes + links in one line), triangles as 48-byte
-//     {p0,e1,e2,n} records in leaf order (rt_bvh.h).
+//   * One global condition remains -- the host loop stops at the first iteration in which nothing
+//     shades (render.cuh:436) -- and it can only bite in the final generation, which is therefore
+//     run in lockstep (one init() per slot per round, host-checked).
+//
+// Kernels:
+//   k_paths      everything before the final generation, ONE persistent launch per frame.  A lane
+//                owns a slot (then its next one); init+mat+gen, the shadow ray and the path ray are
+//                PHASES of the lane; the wave issues, per iteration, the one block most of its lanes
+//                wait for.  Rays, hit records and queues never leave registers / LDS.
+//   k_advance    init() + mat() + gen() for all slots of a round (render.cuh:84-275), state in the
+//   k_trace      SoA pools; ch() + ah() of a round (render.cuh:278-328) with persistent waves, ballot +
+//                mbcnt compaction into a per-wave LDS queue instead of flag arrays + CUB select
+//                (render.cuh:348-364), while-while traversal, LDS stack.  Used for the lockstep final
+//                generation, by the stage-level test entry points, and (RT_PERSISTENT=0) for whole frames.
+//   advance_core / inner_step / tri_intersect / box_hit are the shared device functions: one copy of
+//   the estimator and of the traversal for both pipelines.
+//   * BVH: 64-byte node records -- 2-wide with exact padded boxes (default) or 4-wide with 8-bit
+//     quantised boxes -- and 48-byte {p0,e1,e2,n} triangle records in leaf order (rt_bvh.h).
+//   * There are no host read-backs inside a frame except one 16-byte poll per lockstep round (the
+//     reference does four blocking 4-byte read-backs per iteration: render.cuh:433-434,444-445).
 //
 // No MFMA anywhere: there is no dense contraction on this path.
 #include <hip/hip_runtime.h>
