@@ -113,6 +113,7 @@ struct Result {
 };
 
 constexpr int kMaxLeaf = 4;
+constexpr int kTopPrefix = 1024;  // records laid out breadth-first at the front (LDS-cacheable top of the tree)
 constexpr int kMaxBinDepth = 60;
 
 inline float pad_down(float v, int k) {
@@ -421,6 +422,74 @@ inline Result build(const float *verts, int n) {
                 if ((int)depth_of.size() < next) depth_of.resize(next, 0);
                 for (int k = before; k < next; k++) depth_of[k] = d + 1;
                 res.pairs[pi] = p;
+            }
+        }
+    }
+    // ---- breadth-first prefix: the first kTopPrefix records of each format are the TOP of the tree in
+    // level order (ancestor-closed), so a kernel can keep "the records with index < T" in LDS for any
+    // T <= kTopPrefix; the remaining records keep their depth-first order.  Children still always have a
+    // larger index than their parent.
+    {
+        {
+            auto lk = [](const Pair &p, int *out) { out[0] = p.llink; out[1] = p.rlink; return 2; };
+            const int n_rec = (int)res.pairs.size();
+            if (n_rec > 2) {
+                std::vector<int> new_of(n_rec, -1), order_new;
+                std::vector<int> queue{0};
+                new_of[0] = 0;
+                order_new.push_back(0);
+                for (size_t head = 0; head < queue.size() && (int)order_new.size() < kTopPrefix; head++) {
+                    int links[2];
+                    lk(res.pairs[queue[head]], links);
+                    for (int k = 0; k < 2 && (int)order_new.size() < kTopPrefix; k++)
+                        if (links[k] >= 0 && new_of[links[k]] < 0) {
+                            new_of[links[k]] = (int)order_new.size();
+                            order_new.push_back(links[k]);
+                            queue.push_back(links[k]);
+                        }
+                }
+                for (int i = 0; i < n_rec; i++)
+                    if (new_of[i] < 0) {
+                        new_of[i] = (int)order_new.size();
+                        order_new.push_back(i);
+                    }
+                std::vector<Pair> old = res.pairs;
+                for (int i = 0; i < n_rec; i++) {
+                    Pair p = old[i];
+                    if (p.llink >= 0) p.llink = new_of[p.llink];
+                    if (p.rlink >= 0) p.rlink = new_of[p.rlink];
+                    res.pairs[new_of[i]] = p;
+                }
+            }
+        }
+        {
+            const int n_rec = (int)res.nodes.size();
+            if (n_rec > 2) {
+                std::vector<int> new_of(n_rec, -1), order_new;
+                std::vector<int> queue{0};
+                new_of[0] = 0;
+                order_new.push_back(0);
+                for (size_t head = 0; head < queue.size() && (int)order_new.size() < kTopPrefix; head++)
+                    for (int k = 0; k < 4 && (int)order_new.size() < kTopPrefix; k++) {
+                        int l = res.nodes[queue[head]].link[k];
+                        if (l >= 0 && new_of[l] < 0) {
+                            new_of[l] = (int)order_new.size();
+                            order_new.push_back(l);
+                            queue.push_back(l);
+                        }
+                    }
+                for (int i = 0; i < n_rec; i++)
+                    if (new_of[i] < 0) {
+                        new_of[i] = (int)order_new.size();
+                        order_new.push_back(i);
+                    }
+                std::vector<Node4> old = res.nodes;
+                for (int i = 0; i < n_rec; i++) {
+                    Node4 nd = old[i];
+                    for (int k = 0; k < 4; k++)
+                        if (nd.link[k] >= 0) nd.link[k] = new_of[nd.link[k]];
+                    res.nodes[new_of[i]] = nd;
+                }
             }
         }
     }

@@ -627,20 +627,38 @@ __device__ __forceinline__ void stack_push(int *lds_col, int *over_col, int &sp,
 }
 __device__ __forceinline__ int stack_pop(int *lds_col, int *over_col, int &sp, int cap) {
     sp--;
-    return sp < cap ? lds_col[sp * kBlock] : over_col[(size_t)(sp - cap) * kOverStride];
+    // always read the LDS column (clamped) and patch from the overflow only when needed: written as a
+    // select of two pointers, the compiler merges the paths into one FLAT load, which is slower
+    int v = lds_col[min(sp, cap - 1) * kBlock];
+    if (sp >= cap) v = over_col[(size_t)(sp - cap) * kOverStride];
+    return v;
 }
 constexpr int kRefillAt = 40;                // finalise + refill once <= this many lanes still traverse
 __device__ __forceinline__ int leaf_ref(int first, int count) { return ~((first << 3) | count); }
 
 // One node step of a lane whose current entry is an inner record (cur >= 0): test the children,
 // continue with the nearest one that the ray may enter, push the others (far first).
+// `top` / `top_n`: the first top_n records (the top of the tree, breadth-first: rt_bvh.h) may be staged
+// in LDS by the caller; nullptr / 0 otherwise.
 template <bool WIDE>
 __device__ __forceinline__ void inner_step(const DScene &sc, V3 o, V3 inv, float tmax, int &cur, int &sp, int *stack,
-                                           int *over, int stack_cap) {
+                                           int *over, int stack_cap, const float4 *top = nullptr, int top_n = 0) {
+    float4 q0, q1, q2, q3;
+    if (top_n > 0 && cur < top_n) {
+        const float4 *q = top + 4 * cur;
+        q0 = q[0];
+        q1 = q[1];
+        q2 = q[2];
+        q3 = q[3];
+    } else {
+        const float4 *q = (const float4 *)((const char *)sc.nodes + ((unsigned)cur << 6));
+        q0 = q[0];
+        q1 = q[1];
+        q2 = q[2];
+        q3 = q[3];
+    }
     if (!WIDE) {
         // 2-wide record: two exact boxes, near child first, far child onto the stack
-        const float4 *q = (const float4 *)((const char *)sc.nodes + ((unsigned)cur << 6));
-        float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
         int cl = __float_as_int(q3.x), cr = __float_as_int(q3.y);
         float el, er;
         bool hl = box_hit(o, inv, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tmax, el) && cl != kEntryDone;
@@ -660,8 +678,6 @@ __device__ __forceinline__ void inner_step(const DScene &sc, V3 o, V3 inv, float
         }
     }
     if (WIDE) {
-        const float4 *q = (const float4 *)((const char *)sc.nodes + ((unsigned)cur << 6));
-        float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
         const unsigned exps = __float_as_uint(q0.w);
         const float cx = __uint_as_float((exps & 0xffu) << 23);
         const float cy = __uint_as_float(((exps >> 8) & 0xffu) << 23);
@@ -970,7 +986,7 @@ enum { PH_ADV = 0, PH_ANY = 1, PH_CLOSEST = 2, PH_IDLE = 3 };
 template <bool LDS_TABLES, bool WIDE, bool MAJORITY, int MIN_WAVES>
 __global__ void __launch_bounds__(kBlock, MIN_WAVES)
 k_paths(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__ fb, DWaveRow *__restrict__ rows,
-        int stack_cap, int *overflow, int adv_batch, int debug_no_deposit, unsigned long long *prof) {
+        int stack_cap, int *overflow, int adv_batch, int debug_no_deposit, unsigned long long *prof, int top_n) {
     extern __shared__ int s_lds[];
     int *stack = s_lds + threadIdx.x;
     float *park = (float *)(s_lds + stack_cap * kBlock) + threadIdx.x;  // element k at park[k * kBlock]
@@ -978,11 +994,16 @@ k_paths(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__ f
     int *cold = s_lds + (stack_cap + 9) * kBlock + threadIdx.x;  // element k at cold[k * kBlock]
     float *s_tab = (float *)(s_lds + (stack_cap + 21) * kBlock);
     const float *tab = sc.tables;
+    // small shards (MIN_WAVES == 2: at most 2 workgroups per CU, LDS to spare, latency-bound): the top of
+    // the BVH is staged in LDS, so the first levels of every traversal do not leave the CU
+    const float4 *s_top = (const float4 *)(s_tab + (LDS_TABLES ? kTabDwordsMax : 0));
+    if (MIN_WAVES != 2) top_n = 0;
+    for (int k = threadIdx.x; k < top_n * 4; k += kBlock) ((float4 *)s_top)[k] = sc.nodes[k];
     if (LDS_TABLES) {
         for (int k = threadIdx.x; k < sc.tab_dwords; k += kBlock) s_tab[k] = sc.tables[k];
-        __syncthreads();
         tab = s_tab;
     }
+    if (LDS_TABLES || top_n > 0) __syncthreads();
     // A lane works through the slots i, i + G, i + 2G, ... (G = lanes of the grid), each for the whole
     // frame, one after the other: with G dividing the slot count every lane gets the same number of
     // slots, so all lanes -- and all workgroups, which are all resident -- finish together.
@@ -1163,7 +1184,7 @@ k_paths(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__ f
 #ifdef RT_TRACE_PROFILE
             pf[2]++; pf[3] += n_node; pf[6] += n_adv;
 #endif
-            if (want_node) inner_step<WIDE>(sc, o, inv, tmax, cur, sp, stack, over, stack_cap);
+            if (want_node) inner_step<WIDE>(sc, o, inv, tmax, cur, sp, stack, over, stack_cap, s_top, top_n);
         }
         // ---------------- triangle tests (triangle.cuh:39-58): the leaf reference is the cursor
         if (n_tri > 0 && (!MAJORITY || n_tri > n_node)) {
@@ -1604,7 +1625,7 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
         const int paths_cap = std::min(8, std::max(1, scene->stack_bound));
         int *d_over2 = nullptr;
         if (ensure_overflow(scene->stack_bound - paths_cap, &d_over2)) return 1;
-        const size_t lds_paths = sizeof(int) * (size_t)kBlock * (size_t)(paths_cap + 21) + (lds_tables ? sizeof(float) * kTabDwordsMax : 0);
+        size_t lds_paths = sizeof(int) * (size_t)kBlock * (size_t)(paths_cap + 21) + (lds_tables ? sizeof(float) * kTabDwordsMax : 0);
         bool majority = true;
         if (const char *e = getenv("RT_MAJORITY")) majority = atoi(e) != 0;
         const int dbg = (flags & 0x100u) ? 1 : 0;
@@ -1623,6 +1644,13 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
         const dim3 grid_paths(paths_blocks);
         int dev_cus_paths = 0;
         HIP_TRY(hipDeviceGetAttribute(&dev_cus_paths, hipDeviceAttributeMultiprocessorCount, dev));
+        const bool few_blocks = paths_blocks <= 2 * dev_cus_paths;
+        int top_n = 0;
+        if (few_blocks) {
+            top_n = std::min(384, std::min(scene->n_nodes, (int)rtbvh::kTopPrefix));  // keeps the workgroup under 64 KB of LDS
+            if (const char *e = getenv("RT_TOP_NODES")) top_n = std::max(0, std::min(top_n, atoi(e)));
+            lds_paths += (size_t)top_n * 64;
+        }
         HIP_TRY(hipEventRecord(c.ev_a, st));
 // MIN_WAVES: 4 waves per SIMD (128 VGPRs, some spills) when the grid fills the chip, 2 (256 VGPRs, no
         // spills) when the shard is so small that only 2 workgroups per CU exist anyway (8-GPU runs)
@@ -1630,12 +1658,11 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
     do {                                                                                                               \
         if (few_blocks)                                                                                                \
             hipLaunchKernelGGL((k_paths<T, WD, MJ, 2>), grid_paths, block, lds_paths, st, sc, c.pools, cam, ap, d_sum,   \
-                               c.d_rows, paths_cap, d_over2, adv_batch, dbg, paths_prof);                              \
+                               c.d_rows, paths_cap, d_over2, adv_batch, dbg, paths_prof, top_n);                       \
         else                                                                                                           \
             hipLaunchKernelGGL((k_paths<T, WD, MJ, 4>), grid_paths, block, lds_paths, st, sc, c.pools, cam, ap, d_sum,   \
-                               c.d_rows, paths_cap, d_over2, adv_batch, dbg, paths_prof);                              \
+                               c.d_rows, paths_cap, d_over2, adv_batch, dbg, paths_prof, 0);                           \
     } while (0)
-        const bool few_blocks = paths_blocks <= 2 * dev_cus_paths;
         if (majority) {
             if (lds_tables && scene->wide) RT_LAUNCH_PATHS(true, true, true);
             else if (lds_tables) RT_LAUNCH_PATHS(true, false, true);
