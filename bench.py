@@ -60,6 +60,8 @@ def main():
     ap.add_argument("--cpu-spp", type=int, default=4, help="spp of the bounded CPU-baseline sample")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--save-image", default="")
+    ap.add_argument("--deterministic", action="store_true",
+                    help="accumulate in 64-bit fixed point (order-independent: the N-GPU image equals the 1-GPU image bit for bit)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--debug-flags", type=int, default=0, help="perf experiments only (results invalid)")
     args = ap.parse_args()
@@ -91,17 +93,26 @@ def main():
     scene = api.Scene(arrays)
     cam = api.make_camera(aspect=w / h)
     fb = torch.zeros(h * w * 3, dtype=torch.float32, device="cuda")
+    fb_fixed = torch.zeros(h * w * 3, dtype=torch.int64, device="cuda") if args.deterministic else None
     stream = torch.cuda.current_stream().cuda_stream
     flags = (0 if args.no_kernel_timing else api.FLAG_TIME_KERNELS) | args.debug_flags
     last_stats = {}
 
     def step():
-        fb.zero_()
-        st = scene.render_shard(cam, w, h, spp, rank, world, fb.data_ptr(), max_bounces=args.max_bounces, seed=1,
-                                flags=flags, stream=stream)
-        rtdist.reduce_raw_sums(fb, dst=0)
-        if rank == 0:
-            api.post_process(fb.data_ptr(), w * h, spp, stream=stream)
+        if args.deterministic:
+            fb_fixed.zero_()
+            st = scene.render_shard_fixed(cam, w, h, spp, rank, world, fb_fixed.data_ptr(), max_bounces=args.max_bounces,
+                                          seed=1, flags=flags, stream=stream)
+            rtdist.reduce_raw_sums(fb_fixed, dst=0)
+            if rank == 0:
+                api.post_process_fixed(fb_fixed.data_ptr(), fb.data_ptr(), w * h, spp, stream=stream)
+        else:
+            fb.zero_()
+            st = scene.render_shard(cam, w, h, spp, rank, world, fb.data_ptr(), max_bounces=args.max_bounces, seed=1,
+                                    flags=flags, stream=stream)
+            rtdist.reduce_raw_sums(fb, dst=0)
+            if rank == 0:
+                api.post_process(fb.data_ptr(), w * h, spp, stream=stream)
         last_stats.update(st)
 
     def fence():
@@ -138,7 +149,8 @@ def main():
             "config": {"workload": f"bun_zipper.ply {w}x{h} {spp} spp, {args.scene} scene, max_bounces "
                                    f"{args.max_bounces} (BASELINE configs[1] when 1920x1080x256 full_bsdf)",
                        "scene": args.scene, "width": w, "height": h, "spp": spp, "max_bounces": args.max_bounces,
-                       "parallelism": f"slot-shard x{world} + 1 RCCL reduce" if world > 1 else "1 GPU"},
+                       "parallelism": f"slot-shard x{world} + 1 RCCL reduce" if world > 1 else "1 GPU",
+                       "accumulation": "int64 fixed point (order-independent)" if args.deterministic else "fp32 atomics"},
             "ms_per_frame": round(1e3 * elapsed / max(args.steps, 1), 3),
         }
         # ---- CPU baseline (rank 0, N = 1 only): the oracle on a bounded sample of the same workload

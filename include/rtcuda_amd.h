@@ -81,7 +81,9 @@ typedef struct rt_stats {
 } rt_stats;
 
 /* Flags for rt_render / rt_render_shard */
-#define RT_FLAG_TIME_KERNELS 1u /* time the stage kernels with HIP events on the launch stream (fills seconds_*) */
+#define RT_FLAG_TIME_KERNELS 1u  /* time the stage kernels with HIP events on the launch stream (fills seconds_*) */
+#define RT_FLAG_DETERMINISTIC 2u /* rt_render: accumulate in 64-bit fixed point (2^-30) instead of float atomics
+                                    (vec3.cuh:149-153): bit-reproducible image, independent of summation order */
 
 /* ---- scene -------------------------------------------------------------------------------
  * Replaces: Triangle(p0,p1,p2) x n (triangle.cuh:6-7), cudaMalloc/Memcpy of triangles,
@@ -120,6 +122,16 @@ int rt_render(const rt_scene *scene, const rt_camera *camera, int width, int hei
 int rt_render_shard(const rt_scene *scene, const rt_camera *camera, int width, int height, int num_samples,
                     int max_bounces, uint64_t seed, int shard_index, int shard_count, uint32_t flags,
                     float *d_sum_rgb, void *stream, rt_stats *stats);
+
+/* Order-independent variant of rt_render_shard: d_sum_fixed is a DEVICE buffer of width*height*3 int64
+ * fixed-point sums (units of 2^-30), ADDED to.  Integer adds commute, so the sums of the shards of a
+ * multi-GPU render add up to EXACTLY the single-GPU sums and every run gives the same bits (the
+ * reference's float atomicAdd, vec3.cuh:149-153, does not).  rt_post_process_fixed converts to the
+ * post-processed float image: c = sqrt(float(sum * 2^-30) * (1/spp)). */
+int rt_render_shard_fixed(const rt_scene *scene, const rt_camera *camera, int width, int height, int num_samples,
+                          int max_bounces, uint64_t seed, int shard_index, int shard_count, uint32_t flags,
+                          int64_t *d_sum_fixed, void *stream, rt_stats *stats);
+int rt_post_process_fixed(const int64_t *d_sum_fixed, float *d_rgb_out, int num_pixels, int num_samples, void *stream);
 
 /* post_process_framebuffer (render.cuh:330-338) on a DEVICE buffer: c = sqrt(c * (1/spp)). */
 int rt_post_process(float *d_rgb, int num_pixels, int num_samples, void *stream);

@@ -22,10 +22,11 @@ CSRC = os.path.join(_PKG, "csrc")
 
 W = 1 << 20  # RT_NUM_WORKING_PATHS
 FLAG_TIME_KERNELS = 1
+FLAG_DETERMINISTIC = 2
 
 EXPORTS = [
     "rt_scene_create", "rt_scene_destroy", "rt_scene_info", "rt_camera_make", "rt_render",
-    "rt_render_shard", "rt_post_process", "rt_trace_closest", "rt_trace_any", "rt_xorwow_states",
+    "rt_render_shard", "rt_render_shard_fixed", "rt_post_process", "rt_post_process_fixed", "rt_trace_closest", "rt_trace_any", "rt_xorwow_states",
     "rt_measure_copy_bandwidth", "rt_last_error", "rt_version",
 ]
 
@@ -107,6 +108,8 @@ def lib():
     L.rt_render_shard.argtypes = [vp, vp, ci, ci, ci, ci, ctypes.c_uint64, ci, ci, ctypes.c_uint32, vp, vp,
                                   ctypes.POINTER(RtStats)]
     L.rt_post_process.argtypes = [vp, ci, ci, vp]
+    L.rt_render_shard_fixed.argtypes = L.rt_render_shard.argtypes
+    L.rt_post_process_fixed.argtypes = [vp, vp, ci, ci, vp]
     L.rt_trace_closest.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp, vp]
     L.rt_trace_any.argtypes = [vp, ci, vp, vp, vp, vp, vp]
     L.rt_xorwow_states.argtypes = [ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, ci, vp, vp]
@@ -188,6 +191,17 @@ class Scene:
                                      ctypes.byref(st)), "rt_render_shard")
         return st.as_dict()
 
+    def render_shard_fixed(self, camera: np.ndarray, width: int, height: int, spp: int, shard_index: int,
+                           shard_count: int, d_sum_fixed_ptr: int, max_bounces: int = 10, seed: int = 1, flags: int = 0,
+                           stream: int = 0) -> dict:
+        """Order-independent accumulation: adds int64 fixed-point sums (2^-30) into the DEVICE buffer."""
+        cam = np.ascontiguousarray(camera, np.float32)
+        st = RtStats()
+        _check(lib().rt_render_shard_fixed(self.h, _p(cam), width, height, spp, max_bounces, seed, shard_index,
+                                           shard_count, flags, ctypes.c_void_p(d_sum_fixed_ptr), ctypes.c_void_p(stream),
+                                           ctypes.byref(st)), "rt_render_shard_fixed")
+        return st.as_dict()
+
     # ---- stage-level entry points (parity tests)
     def trace_closest(self, o3, d3, tmax):
         o3 = np.ascontiguousarray(o3, np.float32)
@@ -214,6 +228,11 @@ class Scene:
 def post_process(d_ptr: int, num_pixels: int, spp: int, stream: int = 0) -> None:
     _check(lib().rt_post_process(ctypes.c_void_p(d_ptr), num_pixels, spp, ctypes.c_void_p(stream)),
            "rt_post_process")
+
+
+def post_process_fixed(d_fixed_ptr: int, d_out_ptr: int, num_pixels: int, spp: int, stream: int = 0) -> None:
+    _check(lib().rt_post_process_fixed(ctypes.c_void_p(d_fixed_ptr), ctypes.c_void_p(d_out_ptr), num_pixels, spp,
+                                       ctypes.c_void_p(stream)), "rt_post_process_fixed")
 
 
 def xorwow_states(seed: int, first: int, count: int, draws: int = 0):

@@ -69,6 +69,7 @@ int fail(const std::string &msg) {
     } while (0)
 
 constexpr int kW = RT_NUM_WORKING_PATHS;
+constexpr uint32_t kFlagFixedFb = 0x200u;  // internal: d_sum points to int64 fixed-point sums
 constexpr int kBlock = 256;       // 4 waves per workgroup
 constexpr int kLdsStack = 16;          // traversal stack entries kept in LDS per lane
 constexpr int kOverStride = 1 << 20;   // lanes of the overflow stack (>= lanes of the largest grid that traverses)
@@ -247,6 +248,7 @@ struct AdvanceParams {
     int batch_mask;      // rounds with (round & batch_mask) == batch_mask close a host-polled batch
     int last_gen;        // index of the final camera-ray generation
     int lockstep;        // 1: final generation, one init() per slot per round (literal reference schedule)
+    int fb_fixed;        // framebuffer holds 64-bit fixed-point sums (see deposit())
 };
 
 constexpr int kLdsTable = 64;                   // materials / lights staged in LDS per workgroup
@@ -313,6 +315,31 @@ __device__ __forceinline__ Light tab_light(const float *tab, int n_mats, int i) 
 // advance_core: init() + mat() + gen() for ONE slot (render.cuh:84-275), on register state.
 // Shared by k_advance (state loaded from / stored to the pools) and k_paths (state lives in
 // registers for the whole frame).
+// Framebuffer deposit.  Default: three float atomics, as the reference's Vec3::atomic_add
+// (vec3.cuh:149-153) -- the summation order, and with it the last bits of a pixel, vary from run to
+// run.  Fixed mode (RT_FLAG_DETERMINISTIC / rt_render_shard_fixed): the buffer holds 64-bit
+// fixed-point sums (scale 2^30); integer adds commute, so the image is bit-reproducible and the sum of
+// the shards of a multi-GPU render is EXACTLY the single-GPU sum.  Non-finite contributions (none
+// occur in any test scene) are dropped and magnitudes are clamped to 2^31 in that mode.
+constexpr float kFixedScale = 1073741824.f;  // 2^30
+__device__ __forceinline__ long long to_fixed(float x) {
+    if (!(fabsf(x) <= 2147483648.f)) x = (x == x) ? copysignf(2147483648.f, x) : 0.f;
+    return __float2ll_rn(x * kFixedScale);
+}
+__device__ __forceinline__ void deposit(float *__restrict__ fb, int fixed, int pixel, float r, float g, float b) {
+    const unsigned k = (unsigned)(3 * pixel);
+    if (fixed) {
+        unsigned long long *f = (unsigned long long *)fb;
+        atomicAdd(&f[k + 0], (unsigned long long)to_fixed(r));
+        atomicAdd(&f[k + 1], (unsigned long long)to_fixed(g));
+        atomicAdd(&f[k + 2], (unsigned long long)to_fixed(b));
+    } else {
+        atomicAdd(&fb[k + 0], r);
+        atomicAdd(&fb[k + 1], g);
+        atomicAdd(&fb[k + 2], b);
+    }
+}
+
 struct SlotState {
     int bounces, hit_info, pixel, gen;
     Rng rs;
@@ -342,9 +369,7 @@ __device__ __forceinline__ void advance_core(const DScene &sc, const float *tab,
     while (true) {
         if (st.bounces == 0 && hit && light_of_hit >= 0) {  // :98-103 emission only at bounce 0
             Light l = tab_light(tab, sc.num_mats, light_of_hit);
-            atomicAdd(&fb[(unsigned)(3 * st.pixel + 0)], l.lx);
-            atomicAdd(&fb[(unsigned)(3 * st.pixel + 1)], l.ly);
-            atomicAdd(&fb[(unsigned)(3 * st.pixel + 2)], l.lz);
+            deposit(fb, ap.fb_fixed, st.pixel, l.lx, l.ly, l.lz);
             out.did_emit = true;
         }
         bool cont = st.bounces < ap.max_bounces;  // :109
@@ -729,6 +754,7 @@ enum { MODE_POOL = 0, MODE_TEST_CLOSEST = 2, MODE_TEST_ANY = 3 };
 struct TraceParams {
     int total;             // number of slots (MODE_POOL) or test rays
     int debug_no_deposit;  // perf experiments only: skip the framebuffer atomics
+    int fb_fixed;          // framebuffer holds 64-bit fixed-point sums (see deposit())
     float *fb;             // MODE_POOL: raw-sum framebuffer
     DWaveRow *rows;        // MODE_POOL: counter rows
     unsigned long long *prof;  // RT_TRACE_PROFILE builds only
@@ -815,9 +841,7 @@ __global__ void __launch_bounds__(kBlock, 8) k_trace(DScene sc, DPools p, TraceP
                         p.hit_info(slot) = info;
                     } else if (hu == 0.f && !tp.debug_no_deposit) {  // unoccluded: render.cuh:291-293
                         int pixel = p.pixel(slot);
-                        atomicAdd(&tp.fb[(unsigned)(3 * pixel + 0)], p.slr(slot));
-                        atomicAdd(&tp.fb[(unsigned)(3 * pixel + 1)], p.slg(slot));
-                        atomicAdd(&tp.fb[(unsigned)(3 * pixel + 2)], p.slb(slot));
+                        deposit(tp.fb, tp.fb_fixed, pixel, p.slr(slot), p.slg(slot), p.slb(slot));
                     }
                 } else if (MODE == MODE_TEST_CLOSEST) {
                     tp.out_i[slot] = tri >= 0 ? tp.order[tri] : -1;
@@ -1225,9 +1249,7 @@ k_paths(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__ f
             if (is_any) {
                 if (hu == 0.f && !debug_no_deposit) {  // unoccluded: render.cuh:291-293
                     const int pixel = cold[1 * kBlock];
-                    atomicAdd(&fb[(unsigned)(3 * pixel + 0)], park[6 * kBlock]);
-                    atomicAdd(&fb[(unsigned)(3 * pixel + 1)], park[7 * kBlock]);
-                    atomicAdd(&fb[(unsigned)(3 * pixel + 2)], park[8 * kBlock]);
+                    deposit(fb, ap.fb_fixed, pixel, park[6 * kBlock], park[7 * kBlock], park[8 * kBlock]);
                 }
                 // now the slot's path ray
                 o = mk(park[0 * kBlock], park[1 * kBlock], park[2 * kBlock]);
@@ -1255,6 +1277,12 @@ k_paths(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__ f
 __global__ void k_post_process(float *fb, int n_values, float inv_spp) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_values) fb[i] = sqrtf(fb[i] * inv_spp);
+}
+
+// fixed-point sums -> post-processed image: c = sqrt(float(sum * 2^-30) * (1/spp))
+__global__ void k_post_process_fixed(const long long *__restrict__ sums, float *__restrict__ out, int n_values, float inv_spp) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_values) out[i] = sqrtf((float)((double)sums[i] * (1.0 / 1073741824.0)) * inv_spp);
 }
 
 // ---- stage-level test kernels
@@ -1560,6 +1588,7 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
     ap.round = 0;
     ap.batch_mask = 7;
     ap.lockstep = 0;
+    ap.fb_fixed = (flags & kFlagFixedFb) ? 1 : 0;
     const bool lds_tables = scene->n_mats <= kLdsTable && scene->n_lights <= kLdsTable;
 
     hipEvent_t ev_start, ev_stop;
@@ -1594,6 +1623,7 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
     tpp.fb = d_sum;
     tpp.rows = c.d_rows;
     tpp.debug_no_deposit = (flags & 0x100u) ? 1 : 0;
+    tpp.fb_fixed = (flags & kFlagFixedFb) ? 1 : 0;
 #ifdef RT_TRACE_PROFILE
     unsigned long long *d_prof = nullptr;
     HIP_TRY(hipMalloc((void **)&d_prof, sizeof(unsigned long long) * 16));
@@ -2038,7 +2068,24 @@ int rt_render_shard(const rt_scene *scene, const rt_camera *camera, int width, i
                     int max_bounces, uint64_t seed, int shard_index, int shard_count, uint32_t flags,
                     float *d_sum_rgb, void *stream, rt_stats *stats) {
     return render_overlapped(scene, camera, width, height, num_samples, max_bounces, seed, shard_index, shard_count,
-                             flags, d_sum_rgb, (hipStream_t)stream, stats);
+                             flags & ~kFlagFixedFb, d_sum_rgb, (hipStream_t)stream, stats);
+}
+
+int rt_render_shard_fixed(const rt_scene *scene, const rt_camera *camera, int width, int height, int num_samples,
+                          int max_bounces, uint64_t seed, int shard_index, int shard_count, uint32_t flags,
+                          int64_t *d_sum_fixed, void *stream, rt_stats *stats) {
+    return render_overlapped(scene, camera, width, height, num_samples, max_bounces, seed, shard_index, shard_count,
+                             (flags & ~kFlagFixedFb) | kFlagFixedFb, (float *)d_sum_fixed, (hipStream_t)stream, stats);
+}
+
+int rt_post_process_fixed(const int64_t *d_sum_fixed, float *d_rgb_out, int num_pixels, int num_samples, void *stream) {
+    if (!d_sum_fixed || !d_rgb_out || num_pixels <= 0 || num_samples <= 0) return fail("rt_post_process_fixed: bad argument");
+    int nv = num_pixels * 3;
+    float inv = 1.f / (float)num_samples;
+    hipLaunchKernelGGL(k_post_process_fixed, dim3((nv + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       (const long long *)d_sum_fixed, d_rgb_out, nv, inv);
+    HIP_TRY(hipGetLastError());
+    return 0;
 }
 
 int rt_post_process(float *d_rgb, int num_pixels, int num_samples, void *stream) {
@@ -2054,20 +2101,36 @@ int rt_render(const rt_scene *scene, const rt_camera *camera, int width, int hei
               int max_bounces, uint64_t seed, uint32_t flags, float *out_rgb, rt_stats *stats) {
     if (!out_rgb) return fail("rt_render: out_rgb is null");
     if (width <= 0 || height <= 0) return fail("rt_render: bad dimensions");
-    size_t bytes = sizeof(float) * 3 * (size_t)width * height;
+    const bool fixed = (flags & RT_FLAG_DETERMINISTIC) != 0;
+    const size_t n_values = 3 * (size_t)width * height;
+    const size_t bytes = sizeof(float) * n_values;
     float *d_fb = nullptr;
+    long long *d_fixed = nullptr;
     HIP_TRY(hipMalloc((void **)&d_fb, bytes));
+    if (fixed && hipMalloc((void **)&d_fixed, sizeof(long long) * n_values) != hipSuccess) {
+        (void)hipFree(d_fb);
+        return fail("rt_render: out of device memory");
+    }
     int rc = 0;
     do {
-        if (hipMemsetAsync(d_fb, 0, bytes, nullptr) != hipSuccess) { rc = fail("rt_render: memset failed"); break; }
-        rc = render_overlapped(scene, camera, width, height, num_samples, max_bounces, seed, 0, 1, flags, d_fb,
-                               nullptr, stats);
-        if (rc) break;
-        rc = rt_post_process(d_fb, width * height, num_samples, nullptr);
+        if (fixed) {
+            if (hipMemsetAsync(d_fixed, 0, sizeof(long long) * n_values, nullptr) != hipSuccess) { rc = fail("rt_render: memset failed"); break; }
+            rc = render_overlapped(scene, camera, width, height, num_samples, max_bounces, seed, 0, 1,
+                                   (flags & ~kFlagFixedFb) | kFlagFixedFb, (float *)d_fixed, nullptr, stats);
+            if (rc) break;
+            rc = rt_post_process_fixed((const int64_t *)d_fixed, d_fb, width * height, num_samples, nullptr);
+        } else {
+            if (hipMemsetAsync(d_fb, 0, bytes, nullptr) != hipSuccess) { rc = fail("rt_render: memset failed"); break; }
+            rc = render_overlapped(scene, camera, width, height, num_samples, max_bounces, seed, 0, 1, flags & ~kFlagFixedFb,
+                                   d_fb, nullptr, stats);
+            if (rc) break;
+            rc = rt_post_process(d_fb, width * height, num_samples, nullptr);
+        }
         if (rc) break;
         if (hipMemcpy(out_rgb, d_fb, bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = fail("rt_render: copy-back failed");
     } while (0);
     (void)hipFree(d_fb);
+    (void)hipFree(d_fixed);
     return rc;
 }
 
