@@ -100,6 +100,10 @@ void rt_scene_destroy(rt_scene *scene);
 
 /* out[0]=node records, out[1]=triangles, out[2]=max depth, out[3]=leaves */
 int rt_scene_info(const rt_scene *scene, int64_t out[4]);
+/* Which BVH builder made the scene (0 = host SAH, the default; 1 = device LBVH, RT_BVH_BUILDER=lbvh) and
+ * how long the build took (host wall clock / HIP events).  The reference times "Top-down constructing BVH"
+ * on stdout (bvh.cuh:106-201). */
+int rt_scene_build_info(const rt_scene *scene, int *builder, double *seconds);
 
 /* Replaces Camera::Camera(lookfrom, lookat, up, vfov_deg, aspect) (camera.cuh:15-29). Host only. */
 int rt_camera_make(const float lookfrom[3], const float lookat[3], const float up[3], float vfov_deg,

@@ -25,7 +25,7 @@ FLAG_TIME_KERNELS = 1
 FLAG_DETERMINISTIC = 2
 
 EXPORTS = [
-    "rt_scene_create", "rt_scene_destroy", "rt_scene_info", "rt_camera_make", "rt_render",
+    "rt_scene_create", "rt_scene_destroy", "rt_scene_info", "rt_scene_build_info", "rt_camera_make", "rt_render",
     "rt_render_shard", "rt_render_shard_fixed", "rt_post_process", "rt_post_process_fixed", "rt_trace_closest", "rt_trace_any", "rt_xorwow_states",
     "rt_measure_copy_bandwidth", "rt_last_error", "rt_version",
 ]
@@ -103,6 +103,7 @@ def lib():
     L.rt_scene_destroy.argtypes = [vp]
     L.rt_scene_destroy.restype = None
     L.rt_scene_info.argtypes = [vp, vp]
+    L.rt_scene_build_info.argtypes = [vp, ctypes.POINTER(ci), ctypes.POINTER(ctypes.c_double)]
     L.rt_camera_make.argtypes = [vp, vp, vp, cf, cf, vp]
     L.rt_render.argtypes = [vp, vp, ci, ci, ci, ci, ctypes.c_uint64, ctypes.c_uint32, vp, ctypes.POINTER(RtStats)]
     L.rt_render_shard.argtypes = [vp, vp, ci, ci, ci, ci, ctypes.c_uint64, ci, ci, ctypes.c_uint32, vp, vp,
@@ -167,7 +168,10 @@ class Scene:
     def info(self) -> dict:
         out = np.zeros(4, np.int64)
         _check(lib().rt_scene_info(self.h, _p(out)), "rt_scene_info")
-        return {"pairs": int(out[0]), "tris": int(out[1]), "max_depth": int(out[2]), "leaves": int(out[3])}
+        b, sec = ctypes.c_int(0), ctypes.c_double(0.0)
+        _check(lib().rt_scene_build_info(self.h, ctypes.byref(b), ctypes.byref(sec)), "rt_scene_build_info")
+        return {"pairs": int(out[0]), "tris": int(out[1]), "max_depth": int(out[2]), "leaves": int(out[3]),
+                "builder": "lbvh" if b.value else "sah", "build_seconds": sec.value}
 
     # ---- render(): the drop-in entry point
     def render(self, camera: np.ndarray, width: int, height: int, spp: int, max_bounces: int = 10,

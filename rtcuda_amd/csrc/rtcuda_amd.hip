@@ -38,6 +38,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -1304,12 +1305,166 @@ __global__ void k_copy_f4(const float4 *__restrict__ src, float4 *__restrict__ d
     for (; i < n; i += stride) dst[i] = src[i];
 }
 
+// ============================================================================ device BVH build (LBVH)
+// a BVH build on the GPU.  Optional (RT_BVH_BUILDER=lbvh): a linear BVH --
+// 30-bit Morton codes of the triangle centroids, sorted, binary radix tree by longest common prefix
+// (Karras 2012), bottom-up box fit -- emitted in the same 2-wide record format the kernels walk.  It
+// builds in about a millisecond but has no surface-area heuristic, so traversal is slower than through
+// the host SAH tree; the image is the same (closest accepted triangle does not depend on the tree).
+__device__ __forceinline__ unsigned morton_expand(unsigned v) {  // 10 bits -> every third bit
+    v = (v * 0x00010001u) & 0xFF0000FFu;
+    v = (v * 0x00000101u) & 0x0F00F00Fu;
+    v = (v * 0x00000011u) & 0xC30C30C3u;
+    v = (v * 0x00000005u) & 0x49249249u;
+    return v;
+}
+__global__ void k_lbvh_keys(const float *__restrict__ verts, int n, int n_pad, float lox, float loy, float loz, float sx,
+                            float sy, float sz, unsigned long long *__restrict__ keys) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pad) return;
+    if (i >= n) {
+        keys[i] = ~0ull;  // padding sorts last
+        return;
+    }
+    const float *v = verts + 9 * (size_t)i;
+    float cx = (fminf(v[0], fminf(v[3], v[6])) + fmaxf(v[0], fmaxf(v[3], v[6]))) * 0.5f;
+    float cy = (fminf(v[1], fminf(v[4], v[7])) + fmaxf(v[1], fmaxf(v[4], v[7]))) * 0.5f;
+    float cz = (fminf(v[2], fminf(v[5], v[8])) + fmaxf(v[2], fmaxf(v[5], v[8]))) * 0.5f;
+    unsigned qx = (unsigned)fminf(fmaxf((cx - lox) * sx, 0.f), 1023.f);
+    unsigned qy = (unsigned)fminf(fmaxf((cy - loy) * sy, 0.f), 1023.f);
+    unsigned qz = (unsigned)fminf(fmaxf((cz - loz) * sz, 0.f), 1023.f);
+    unsigned code = (morton_expand(qx) << 2) | (morton_expand(qy) << 1) | morton_expand(qz);
+    keys[i] = ((unsigned long long)code << 32) | (unsigned)i;  // the index makes every key unique
+}
+__global__ void k_bitonic_step(unsigned long long *__restrict__ keys, int n_pad, int j, int k) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pad) return;
+    int partner = i ^ j;
+    if (partner > i) {
+        unsigned long long a = keys[i], b = keys[partner];
+        bool ascending = (i & k) == 0;
+        if ((a > b) == ascending) {
+            keys[i] = b;
+            keys[partner] = a;
+        }
+    }
+}
+__device__ __forceinline__ int lbvh_delta(const unsigned long long *keys, int n, int i, int j) {
+    if (j < 0 || j >= n) return -1;
+    return __clzll((long long)(keys[i] ^ keys[j]));
+}
+// child encoding: internal node k -> k, leaf k (sorted position) -> ~k
+__global__ void k_lbvh_hierarchy(const unsigned long long *__restrict__ keys, int n, int *__restrict__ left,
+                                 int *__restrict__ right, int *__restrict__ parent_int, int *__restrict__ parent_leaf) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1) return;
+    int d = (lbvh_delta(keys, n, i, i + 1) - lbvh_delta(keys, n, i, i - 1)) >= 0 ? 1 : -1;
+    int dmin = lbvh_delta(keys, n, i, i - d);
+    int lmax = 2;
+    while (lbvh_delta(keys, n, i, i + lmax * d) > dmin) lmax *= 2;
+    int l = 0;
+    for (int t = lmax / 2; t >= 1; t /= 2)
+        if (lbvh_delta(keys, n, i, i + (l + t) * d) > dmin) l += t;
+    int j = i + l * d;
+    int dnode = lbvh_delta(keys, n, i, j);
+    int s = 0, t = l;
+    do {
+        t = (t + 1) >> 1;
+        if (lbvh_delta(keys, n, i, i + (s + t) * d) > dnode) s += t;
+    } while (t > 1);
+    int gamma = i + s * d + min(d, 0);
+    int lo = min(i, j), hi = max(i, j);
+    int lc = (lo == gamma) ? ~gamma : gamma;
+    int rc = (hi == gamma + 1) ? ~(gamma + 1) : gamma + 1;
+    left[i] = lc;
+    right[i] = rc;
+    if (lc < 0) parent_leaf[~lc] = i; else parent_int[lc] = i;
+    if (rc < 0) parent_leaf[~rc] = i; else parent_int[rc] = i;
+    if (i == 0) parent_int[0] = -1;
+}
+__device__ __forceinline__ void lbvh_leaf_box(const float *verts, const unsigned long long *keys, int pos, float *b) {
+    const float *v = verts + 9 * (size_t)(unsigned)(keys[pos] & 0xffffffffu);
+    for (int a = 0; a < 3; a++) {
+        b[a] = fminf(v[a], fminf(v[3 + a], v[6 + a]));
+        b[3 + a] = fmaxf(v[a], fmaxf(v[3 + a], v[6 + a]));
+    }
+}
+// bottom-up: the second thread to arrive at an internal node owns it (its sibling subtree is complete)
+__global__ void k_lbvh_fit(const float *__restrict__ verts, const unsigned long long *__restrict__ keys, int n,
+                           const int *__restrict__ left, const int *__restrict__ right, const int *__restrict__ parent_int,
+                           const int *__restrict__ parent_leaf, float *boxes, int *depth, int *arrivals) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int cur = parent_leaf[i];
+    for (int guard = 0; cur >= 0 && guard < 4096; guard++) {  // (a radix tree over 64-bit keys is at most 64 deep)
+        __threadfence();  // publish what this thread wrote below before announcing arrival
+        if (atomicAdd(&arrivals[cur], 1) == 0) return;
+        __threadfence();  // second arrival: the sibling's box and depth are visible from here on
+        float b[6] = {kFltMax, kFltMax, kFltMax, -kFltMax, -kFltMax, -kFltMax};
+        int dep = 0;
+        const int ch[2] = {left[cur], right[cur]};
+        for (int c = 0; c < 2; c++) {
+            float cb[6];
+            int cd = 0;
+            if (ch[c] < 0) {
+                lbvh_leaf_box(verts, keys, ~ch[c], cb);
+            } else {
+                const volatile float *vb = boxes + 6 * (size_t)ch[c];
+                for (int a = 0; a < 6; a++) cb[a] = vb[a];
+                cd = ((const volatile int *)depth)[ch[c]];
+            }
+            for (int a = 0; a < 3; a++) {
+                b[a] = fminf(b[a], cb[a]);
+                b[3 + a] = fmaxf(b[3 + a], cb[3 + a]);
+            }
+            dep = max(dep, cd);
+        }
+        for (int a = 0; a < 6; a++) boxes[6 * (size_t)cur + a] = b[a];
+        depth[cur] = dep + 1;
+        cur = parent_int[cur];
+    }
+}
+__device__ __forceinline__ float lbvh_pad(float v, int dir) {  // 2 ulps outward, as the host builder pads
+    v = nextafterf(v, dir < 0 ? -kFltMax : kFltMax);
+    return nextafterf(v, dir < 0 ? -kFltMax : kFltMax);
+}
+__global__ void k_lbvh_emit(const float *__restrict__ verts, const unsigned long long *__restrict__ keys, int n,
+                            const int *__restrict__ left, const int *__restrict__ right, const float *__restrict__ boxes,
+                            float *__restrict__ pairs, int *__restrict__ order) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) order[i] = (int)(unsigned)(keys[i] & 0xffffffffu);
+    if (i >= n - 1) return;
+    float *rec = pairs + 16 * (size_t)i;
+    const int ch[2] = {left[i], right[i]};
+    for (int c = 0; c < 2; c++) {
+        float cb[6];
+        int link;
+        if (ch[c] < 0) {
+            lbvh_leaf_box(verts, keys, ~ch[c], cb);
+            link = ~(((~ch[c]) << 3) | 1);  // leaf reference: one triangle at sorted position
+        } else {
+            for (int a = 0; a < 6; a++) cb[a] = boxes[6 * (size_t)ch[c] + a];
+            link = ch[c];
+        }
+        for (int a = 0; a < 3; a++) {
+            rec[6 * c + a] = lbvh_pad(cb[a], -1);
+            rec[6 * c + 3 + a] = lbvh_pad(cb[3 + a], +1);
+        }
+        rec[12 + c] = __int_as_float(link);
+    }
+    rec[14] = 0.f;
+    rec[15] = 0.f;
+}
+
 // ============================================================================ host side
 struct rt_scene {
     int device = 0;
     int n_tris = 0, n_nodes = 0, max_depth = 0, stack_bound = 1, n_leaves = 0, n_lights = 0, n_mats = 0;
     float4 *d_nodes = nullptr;
     bool wide = false;  // node records: 4-wide quantised (rtbvh::Node4) or 2-wide exact (rtbvh::Pair)
+    bool top_prefix = true;  // the first records are the top of the tree in level order (host builder)
+    double build_seconds = 0.0;  // BVH build time (host wall clock, or device events for the LBVH)
+    int builder = 0;             // 0 host SAH, 1 device LBVH
     float4 *d_tris = nullptr;
     int2 *d_tri_info = nullptr;
     Material *d_mats = nullptr;
@@ -1391,6 +1546,104 @@ const std::vector<uint32_t> &jump_powers() {
         }
     });
     return table;
+}
+
+// Structural check of 2-wide records before they are uploaded (a malformed tree would hang the GPU):
+// every record reachable from the root exactly once, every triangle position in exactly one leaf.
+bool validate_pairs(const std::vector<rtbvh::Pair> &pairs, int n_tris) {
+    const int np = (int)pairs.size();
+    if (np == 0) return false;
+    std::vector<char> seen_pair(np, 0), seen_tri((size_t)std::max(n_tris, 1), 0);
+    std::vector<int> todo{0};
+    seen_pair[0] = 1;
+    int visited = 0, tris = 0;
+    while (!todo.empty()) {
+        int pi = todo.back();
+        todo.pop_back();
+        visited++;
+        const int links[2] = {pairs[pi].llink, pairs[pi].rlink};
+        for (int l : links) {
+            if (l == rtbvh::kNoChild) continue;
+            if (l >= 0) {
+                if (l >= np || seen_pair[l]) return false;
+                seen_pair[l] = 1;
+                todo.push_back(l);
+            } else {
+                int ref = ~l, first = ref >> 3, count = ref & 7;
+                if (count <= 0 || first < 0 || first + count > n_tris) return false;
+                for (int k = first; k < first + count; k++) {
+                    if (seen_tri[k]) return false;
+                    seen_tri[k] = 1;
+                    tris++;
+                }
+            }
+        }
+    }
+    return visited == np && tris == n_tris;
+}
+
+// Device LBVH build: returns the pair records and the leaf order on the host (the caller uploads them
+// like the host builder's output).  n >= 2.
+int build_lbvh_device(const float *verts_host, int n, std::vector<rtbvh::Pair> &pairs, std::vector<int32_t> &order,
+                      int &depth, double &seconds) {
+    float lo[3] = {kFltMax, kFltMax, kFltMax}, hi[3] = {-kFltMax, -kFltMax, -kFltMax};
+    for (size_t i = 0; i < (size_t)n * 3; i++)
+        for (int a = 0; a < 3; a++) {
+            lo[a] = std::min(lo[a], verts_host[3 * i + a]);
+            hi[a] = std::max(hi[a], verts_host[3 * i + a]);
+        }
+    float sc3[3];
+    for (int a = 0; a < 3; a++) sc3[a] = hi[a] > lo[a] ? 1024.f / (hi[a] - lo[a]) : 0.f;
+    int n_pad = 1;
+    while (n_pad < n) n_pad <<= 1;
+    float *d_verts = nullptr, *d_boxes = nullptr, *d_pairs = nullptr;
+    unsigned long long *d_keys = nullptr;
+    int *d_left = nullptr, *d_right = nullptr, *d_pi = nullptr, *d_pl = nullptr, *d_depth = nullptr, *d_arr = nullptr, *d_order = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_verts, sizeof(float) * 9 * (size_t)n));
+    HIP_TRY(hipMalloc((void **)&d_keys, sizeof(unsigned long long) * (size_t)n_pad));
+    HIP_TRY(hipMalloc((void **)&d_left, sizeof(int) * (size_t)n));
+    HIP_TRY(hipMalloc((void **)&d_right, sizeof(int) * (size_t)n));
+    HIP_TRY(hipMalloc((void **)&d_pi, sizeof(int) * (size_t)n));
+    HIP_TRY(hipMalloc((void **)&d_pl, sizeof(int) * (size_t)n));
+    HIP_TRY(hipMalloc((void **)&d_depth, sizeof(int) * (size_t)n));
+    HIP_TRY(hipMalloc((void **)&d_arr, sizeof(int) * (size_t)n));
+    HIP_TRY(hipMalloc((void **)&d_order, sizeof(int) * (size_t)n));
+    HIP_TRY(hipMalloc((void **)&d_boxes, sizeof(float) * 6 * (size_t)n));
+    HIP_TRY(hipMalloc((void **)&d_pairs, sizeof(float) * 16 * (size_t)n));
+    HIP_TRY(hipMemcpy(d_verts, verts_host, sizeof(float) * 9 * (size_t)n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(d_arr, 0, sizeof(int) * (size_t)n));
+    HIP_TRY(hipMemset(d_depth, 0, sizeof(int) * (size_t)n));
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(hipEventRecord(e0, nullptr));
+    const dim3 blk(256);
+    hipLaunchKernelGGL(k_lbvh_keys, dim3((n_pad + 255) / 256), blk, 0, nullptr, d_verts, n, n_pad, lo[0], lo[1], lo[2], sc3[0],
+                       sc3[1], sc3[2], d_keys);
+    for (int k2 = 2; k2 <= n_pad; k2 <<= 1)
+        for (int j = k2 >> 1; j > 0; j >>= 1)
+            hipLaunchKernelGGL(k_bitonic_step, dim3((n_pad + 255) / 256), blk, 0, nullptr, d_keys, n_pad, j, k2);
+    hipLaunchKernelGGL(k_lbvh_hierarchy, dim3((n + 255) / 256), blk, 0, nullptr, d_keys, n, d_left, d_right, d_pi, d_pl);
+    hipLaunchKernelGGL(k_lbvh_fit, dim3((n + 255) / 256), blk, 0, nullptr, d_verts, d_keys, n, d_left, d_right, d_pi, d_pl,
+                       d_boxes, d_depth, d_arr);
+    hipLaunchKernelGGL(k_lbvh_emit, dim3((n + 255) / 256), blk, 0, nullptr, d_verts, d_keys, n, d_left, d_right, d_boxes,
+                       d_pairs, d_order);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(e1, nullptr));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    seconds = ms * 1e-3;
+    pairs.resize((size_t)n - 1);
+    order.resize((size_t)n);
+    HIP_TRY(hipMemcpy(pairs.data(), d_pairs, sizeof(rtbvh::Pair) * (size_t)(n - 1), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(order.data(), d_order, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&depth, d_depth, sizeof(int), hipMemcpyDeviceToHost));  // depth of the root
+    HIP_TRY(hipEventDestroy(e0));
+    HIP_TRY(hipEventDestroy(e1));
+    void *frees[] = {d_verts, d_keys, d_left, d_right, d_pi, d_pl, d_depth, d_arr, d_order, d_boxes, d_pairs};
+    for (void *f : frees) (void)hipFree(f);
+    return 0;
 }
 
 // ---- per-device render context: pools are allocated once per (device, n) and reused
@@ -1677,7 +1930,7 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
         const bool few_blocks = paths_blocks <= 2 * dev_cus_paths;
         int top_n = 0;
         if (few_blocks) {
-            top_n = std::min(384, std::min(scene->n_nodes, (int)rtbvh::kTopPrefix));  // keeps the workgroup under 64 KB of LDS
+            top_n = scene->top_prefix ? std::min(384, std::min(scene->n_nodes, (int)rtbvh::kTopPrefix)) : 0;  // < 64 KB of LDS
             if (const char *e = getenv("RT_TOP_NODES")) top_n = std::max(0, std::min(top_n, atoi(e)));
             lds_paths += (size_t)top_n * 64;
         }
@@ -1937,13 +2190,34 @@ int rt_scene_create(const float *tri_p0p1p2, int n_tris, const int32_t *tri_mate
     }
     auto sc = std::make_unique<rt_scene>();
     HIP_TRY(hipGetDevice(&sc->device));
-    rtbvh::Result bvh = rtbvh::build(tri_p0p1p2, n_tris);
+    bool use_lbvh = false;
+    if (const char *e = getenv("RT_BVH_BUILDER")) use_lbvh = std::string(e) == "lbvh";
+    rtbvh::Result bvh;
+    if (use_lbvh && n_tris >= 2) {
+        int depth = 0;
+        if (build_lbvh_device(tri_p0p1p2, n_tris, bvh.pairs, bvh.order, depth, sc->build_seconds)) return 1;
+        if (!validate_pairs(bvh.pairs, n_tris) || depth < 1) return fail("rt_scene_create: device BVH build produced a malformed tree");
+        std::vector<char> seen((size_t)n_tris, 0);
+        for (int k = 0; k < n_tris; k++) {
+            if (bvh.order[k] < 0 || bvh.order[k] >= n_tris || seen[bvh.order[k]]) return fail("rt_scene_create: device BVH build produced a bad triangle order");
+            seen[bvh.order[k]] = 1;
+        }
+        bvh.pair_depth = depth;
+        bvh.num_leaves = n_tris;
+        sc->builder = 1;
+        sc->top_prefix = false;
+    } else {
+        auto t0 = std::chrono::steady_clock::now();
+        bvh = rtbvh::build(tri_p0p1p2, n_tris);
+        sc->build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
     if (!bvh.ok) return fail("rt_scene_create: BVH build produced an unreferenceable leaf");
-    if (bvh.stack_bound > kMaxStackBound)
+    if ((sc->builder == 1 ? bvh.pair_depth + 1 : bvh.stack_bound) > kMaxStackBound)
         return fail("rt_scene_create: BVH depth " + std::to_string(bvh.max_depth) + " exceeds the traversal stack");
     sc->n_tris = n_tris;
     sc->wide = false;  // 2-wide exact records: cheaper per test, and the trace kernel is VALU-bound
     if (const char *e = getenv("RT_BVH_WIDE")) sc->wide = atoi(e) != 0;
+    if (sc->builder == 1) sc->wide = false;  // the device builder emits 2-wide records only
     sc->n_nodes = sc->wide ? (int)bvh.nodes.size() : (int)bvh.pairs.size();
     sc->max_depth = sc->wide ? bvh.max_depth : bvh.pair_depth;
     sc->stack_bound = sc->wide ? bvh.stack_bound : bvh.pair_depth + 1;
@@ -2026,6 +2300,13 @@ int rt_scene_info(const rt_scene *scene, int64_t out[4]) {
     out[1] = scene->n_tris;
     out[2] = scene->max_depth;
     out[3] = scene->n_leaves;
+    return 0;
+}
+
+int rt_scene_build_info(const rt_scene *scene, int *builder, double *seconds) {
+    if (!scene || !builder || !seconds) return fail("rt_scene_build_info: null argument");
+    *builder = scene->builder;
+    *seconds = scene->build_seconds;
     return 0;
 }
 

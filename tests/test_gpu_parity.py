@@ -363,3 +363,26 @@ def test_deterministic_accumulation_is_bit_reproducible_and_shard_exact(api, ora
     api.post_process_fixed(full.data_ptr(), out.data_ptr(), w * h, spp)
     torch.cuda.synchronize()
     assert np.array_equal(out.cpu().numpy().reshape(h, w, 3).view(np.uint32), a.view(np.uint32))
+
+
+def test_device_lbvh_builder_gives_the_same_image(api, oracle, cpu_matte, bunny_matte, monkeypatch):
+    """the optional GPU BVH build (RT_BVH_BUILDER=lbvh).  A different tree, the same hits."""
+    monkeypatch.setenv("RT_BVH_BUILDER", "lbvh")
+    sc = api.Scene(bunny_matte)
+    info = sc.info()
+    assert info["builder"] == "lbvh" and info["pairs"] == bunny_matte.n_tris - 1 and info["leaves"] == bunny_matte.n_tris
+    assert 0 < info["build_seconds"] < 0.5
+    monkeypatch.delenv("RT_BVH_BUILDER")
+    ref_info = api.Scene(bunny_matte).info()
+    assert ref_info["builder"] == "sah"
+    cam = default_camera(oracle, 16 / 9)
+    o, d = raygen.camera_rays(cam, 1920, 1080, 150_000, seed=61)
+    g, c, _ = _closest_compare(sc, cpu_matte, o, d, np.full(len(o), FLT_MAX, np.float32), 2e-5)
+    o2, d2 = raygen.bounce_rays(o, d, c[1], c[0] >= 0, seed=62)
+    _closest_compare(sc, cpu_matte, o2, d2, np.full(len(o2), FLT_MAX, np.float32), 2e-5)
+    w, h, spp = 64, 36, 8
+    img_c, _, st_c = cpu_matte.render(default_camera(oracle, w / h), w, h, spp, threads=8)
+    img_g, st_g = sc.render(api.make_camera(aspect=w / h), w, h, spp)
+    assert st_g["shade_events"] == st_c["sum_mat"] and st_g["any_rays"] == st_c["sum_ah"]
+    assert _rms(img_g, img_c).max() < 2e-6
+    print("LBVH build", info["build_seconds"], "s; host SAH build", ref_info["build_seconds"], "s")
