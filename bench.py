@@ -57,7 +57,7 @@ def main():
     ap.add_argument("--scene", default="full_bsdf",
                     choices=["matte", "full_bsdf", "four_bunnies", "sixteen_lights"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-spp", type=int, default=4, help="spp of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-spp", type=int, default=16, help="spp of the bounded CPU-baseline sample (~10-15 s of CPU work)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--save-image", default="")
     ap.add_argument("--deterministic", action="store_true",

@@ -34,6 +34,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <vector>
@@ -116,6 +117,12 @@ constexpr int kMaxLeaf = 4;
 constexpr int kTopPrefix = 1024;  // records laid out breadth-first at the front (LDS-cacheable top of the tree)
 constexpr int kMaxBinDepth = 60;
 
+// relative cost of a traversal step (tunable for experiments: RT_BVH_TRAV_COST)
+inline float trav_cost() {
+    static float c = [] { const char *e = getenv("RT_BVH_TRAV_COST"); return e ? (float)atof(e) : 1.0f; }();
+    return c;
+}
+
 inline float pad_down(float v, int k) {
     for (int i = 0; i < k; i++) v = std::nextafter(v, -FLT_MAX);
     return v;
@@ -196,7 +203,7 @@ inline void build_binary(const float *verts, int n, std::vector<BinNode> &bin, s
             if (best_axis >= 0) {
                 float area = bin[t.node].box.half_area();
                 float leaf_cost = area * (float)cnt;
-                float split_cost = area * 1.0f + best;  // one traversal step ~ one triangle test
+                float split_cost = area * trav_cost() + best;  // cost of one node step in triangle tests
                 if (cnt <= kMaxLeaf && split_cost >= leaf_cost) best_axis = -1;
             }
             if (best_axis < 0 && cnt > kMaxLeaf) {  // coincident boxes: split in the middle of axis 0
