@@ -1107,7 +1107,8 @@ k_paths(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__ f
     // wave-uniform event counters
     unsigned long long n_gen = 0, n_shade = 0, n_traced = 0, n_shadow = 0, n_emit = 0, n_deposit = 0, n_rr = 0;
 #ifdef RT_TRACE_PROFILE
-    unsigned long long pf[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long pf[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long pf_t0 = __builtin_readcyclecounter();
 #endif
 
     while (true) {
@@ -1128,6 +1129,7 @@ k_paths(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__ f
         if (run_adv) {
 #ifdef RT_TRACE_PROFILE
             pf[0]++; pf[1] += n_adv;
+            const unsigned long long pf_ta = __builtin_readcyclecounter();
 #endif
             // ---------------- ADV block
             AdvanceOut out;
@@ -1209,6 +1211,9 @@ k_paths(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__ f
                 for (int off = 32; off > 0; off >>= 1) rr += __shfl_xor(rr, off);
                 n_rr += (unsigned long long)rr;
             }
+#ifdef RT_TRACE_PROFILE
+            pf[8] += __builtin_readcyclecounter() - pf_ta;
+#endif
             continue;
         }
         const bool is_any = phase == PH_ANY;
@@ -1216,6 +1221,7 @@ k_paths(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__ f
         if (n_node > 0 && (!MAJORITY || n_node >= n_tri)) {
 #ifdef RT_TRACE_PROFILE
             pf[2]++; pf[3] += n_node; pf[6] += n_adv;
+            const unsigned long long pf_tn = __builtin_readcyclecounter();
 #endif
             if (want_node) {
                 // a bounded while-while: up to kNodePerStep consecutive node steps (2 triangle tests in the
@@ -1224,11 +1230,15 @@ k_paths(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__ f
                 for (int rep = 0; rep < kNodePerStep; rep++)
                     if (cur >= 0) inner_step<WIDE>(sc, o, inv, tmax, cur, sp, stack, over, stack_cap, s_top, top_n);
             }
+#ifdef RT_TRACE_PROFILE
+            pf[9] += __builtin_readcyclecounter() - pf_tn;
+#endif
         }
         // ---------------- triangle tests (triangle.cuh:39-58): the leaf reference is the cursor
         if (n_tri > 0 && (!MAJORITY || n_tri > n_node)) {
 #ifdef RT_TRACE_PROFILE
             pf[4]++; pf[5] += n_tri; pf[7] += n_adv;
+            const unsigned long long pf_tt = __builtin_readcyclecounter();
 #endif
             if (want_tri) {
                 bool stop = false;
@@ -1259,6 +1269,9 @@ k_paths(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__ f
                     // MAJORITY: kTriPerStep triangles per step; otherwise the whole leaf (and chained leaves) now
                 } while ((!MAJORITY || reps < kTriPerStep) && cur != kEntryDone && cur < 0 && !stop);
             }
+#ifdef RT_TRACE_PROFILE
+            pf[10] += __builtin_readcyclecounter() - pf_tt;
+#endif
         }
         // ---------------- finished rays
         const bool fin = trav && cur == kEntryDone;
@@ -1285,7 +1298,408 @@ k_paths(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__ f
     }
 #ifdef RT_TRACE_PROFILE
     if (prof && lane_id() == 0)
-        for (int k = 0; k < 8; k++) atomicAdd(&prof[k], pf[k]);
+        { pf[11] = __builtin_readcyclecounter() - pf_t0; for (int k = 0; k < 16; k++) atomicAdd(&prof[k], pf[k]); }
+#endif
+    unsigned long long v[C_COUNT] = {n_gen, n_shade, n_traced, n_shadow, n_emit, n_deposit, n_rr, 0ull};
+    row_add(rows, v);
+}
+
+// ============================================================================ k_paths_pool
+// k_paths with the ADV block served from a WORKGROUP-wide request queue.  In k_paths a wave runs the
+// ADV block (~1 500 instructions, by far the longest) for its own lanes only, typically with ~40 of
+// 64 lanes active, while the lanes already waiting for it idle through the traversal blocks.  Here a
+// lane that needs ADV posts its lane number to a ring in LDS and waits; any wave of the workgroup
+// that finds 64 requests pending (or has nothing else to do) claims up to 64 of them and executes
+// the ADV block with lane j working on the slot of the j-th requester.  That is possible because
+// everything the ADV block reads and writes is already in the requester's LDS columns: the slot
+// state (13 dwords), and a "mail" column that carries the hit record in and the next ray(s) out.
+//     lane:      CLOSEST done -> mail[0..5] = (tri, u, v, d), post, WAIT -> poll state -> next ray
+//     executor:  claim [head, head+m) by CAS -> advance_core for each -> mail, cold -> state = code
+// LDS layout: [stack: cap x 256][cold: 13 x 256][mail: 17 x 256][state: 256][head, tail][ring: 256 x u16][tables]
+// The ring has as many entries as the workgroup has lanes and a lane has at most one request
+// outstanding, so it cannot overflow.  A wave only ever waits for (a) another wave's ring entry whose
+// index that wave has already reserved, (b) an executor that is running: no circular waits.
+// All cross-wave communication is LDS -> LDS.  The LDS executes one wave's ds instructions in issue order,
+// so a consumer that sees a flag also sees everything its producer wrote before it; what has to be
+// prevented is only the COMPILER moving LDS accesses across the flag.  (A real workgroup-scope fence also
+// waits for every outstanding global load and atomic of the wave -- measured: 40 % of the kernel.)
+#define RT_LDS_ORDER() __asm__ volatile("" ::: "memory")
+enum { PW_POST = 4, PW_WAIT = 5 };                          // extra lane phases (besides PH_ANY/PH_CLOSEST/PH_IDLE)
+enum { SV_NONE = 0, SV_ANY = 2, SV_CLOSEST = 3, SV_IDLE = 4, SV_REPOST = 5 };  // executor -> lane
+constexpr int kColdRows = 13, kMailRows = 17;
+template <bool LDS_TABLES, bool WIDE, int MIN_WAVES>
+__global__ void __launch_bounds__(kBlock, MIN_WAVES)
+k_paths_pool(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__ fb, DWaveRow *__restrict__ rows,
+             int stack_cap, int *overflow, int adv_batch, int debug_no_deposit, unsigned long long *prof) {
+    extern __shared__ int s_lds[];
+    int *stack = s_lds + threadIdx.x;
+    int *cold_base = s_lds + stack_cap * kBlock;
+    float *mail_base = (float *)(cold_base + kColdRows * kBlock);
+    int *state_base = (int *)(mail_base + kMailRows * kBlock);
+    int *qctl = state_base + kBlock;  // [0] head, [1] tail (monotonic; ring index = value & 255)
+    volatile unsigned short *ring = (volatile unsigned short *)(qctl + 2);
+    float *s_tab = (float *)(qctl + 2 + kBlock / 2);
+    int *over = overflow + (blockIdx.x * kBlock + threadIdx.x) % kOverStride;
+    const float *tab = sc.tables;
+    if (LDS_TABLES) {
+        for (int k = threadIdx.x; k < sc.tab_dwords; k += kBlock) s_tab[k] = sc.tables[k];
+        tab = s_tab;
+    }
+    float *mail = mail_base + threadIdx.x;  // this lane's own columns
+    int *cold = cold_base + threadIdx.x;
+    const int lanes_in_grid = (int)(gridDim.x * blockDim.x);
+
+    int phase = PH_IDLE;
+    V3 o = mk(0, 0, 0), d = mk(0, 0, 0), inv = mk(0, 0, 0);
+    float tmax = 0.f, hu = 0.f, hv = 0.f;
+    int cur = kEntryDone, sp = 0, tri = -1;
+    {
+        if (threadIdx.x < 2) qctl[threadIdx.x] = 0;
+        ring[threadIdx.x] = 0xffffu;
+        state_base[threadIdx.x] = SV_NONE;
+        const int i = blockIdx.x * blockDim.x + threadIdx.x;
+        if (i < ap.n) {
+            const int b = p.bounces(i);
+            if (b != kDone && b != kParked) {
+                cold[0 * kBlock] = b;
+                cold[1 * kBlock] = p.pixel(i);
+                cold[2 * kBlock] = p.gen(i);
+                cold[3 * kBlock] = (int)p.rd(i);
+                cold[4 * kBlock] = (int)p.r0(i);
+                cold[5 * kBlock] = (int)p.r1(i);
+                cold[6 * kBlock] = (int)p.r2(i);
+                cold[7 * kBlock] = (int)p.r3(i);
+                cold[8 * kBlock] = (int)p.r4(i);
+                cold[9 * kBlock] = __float_as_int(p.br(i));
+                cold[10 * kBlock] = __float_as_int(p.bg(i));
+                cold[11 * kBlock] = __float_as_int(p.bb(i));
+                cold[12 * kBlock] = i;
+                mail[0] = __int_as_float(-1);  // no hit record
+                phase = PW_POST;
+            }
+        }
+        __syncthreads();
+    }
+    unsigned long long n_gen = 0, n_shade = 0, n_traced = 0, n_shadow = 0, n_emit = 0, n_deposit = 0, n_rr = 0;
+#ifdef RT_TRACE_PROFILE
+    unsigned long long pf[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long pf_t0 = __builtin_readcyclecounter();
+#endif
+
+    int polled = SV_NONE, pend_raw = 0, idle_polls = 0;
+    while (true) {
+#ifdef RT_TRACE_PROFILE
+        const unsigned long long pf_s0 = __builtin_readcyclecounter();
+#endif
+        // ---- 1. post ADV requests (one LDS atomic per wave)
+        {
+            const bool post = phase == PW_POST;
+            const unsigned long long pm = __ballot(post);
+            if (pm) {
+                int base = 0;
+                if (lane_id() == (unsigned)__ffsll((long long)pm) - 1u) base = atomicAdd(&qctl[1], __popcll(pm));
+                base = __shfl(base, __ffsll((long long)pm) - 1);
+                if (post) {
+                    const int rank = __popcll(pm & ((1ull << lane_id()) - 1ull));
+                    RT_LDS_ORDER();  // mail / cold writes first
+                    ring[(base + rank) & (kBlock - 1)] = (unsigned short)threadIdx.x;
+                    phase = PW_WAIT;
+                }
+            }
+        }
+        // ---- 2. served?  (`polled` and `pending` were read one iteration ago: their LDS latency is hidden
+        // behind the traversal blocks, and being one iteration late costs nothing)
+        if (phase == PW_WAIT) {
+            const int code = polled;
+            if (code != SV_NONE) {
+                RT_LDS_ORDER();
+                state_base[threadIdx.x] = SV_NONE;
+                if (code == SV_ANY || code == SV_CLOSEST) {
+                    o = mk(mail[9 * kBlock], mail[10 * kBlock], mail[11 * kBlock]);
+                    d = mk(mail[12 * kBlock], mail[13 * kBlock], mail[14 * kBlock]);
+                    inv = inv_dir(d);
+                    cur = 0;
+                    sp = 0;
+                    if (code == SV_ANY) {
+                        tmax = mail[15 * kBlock];
+                        tri = __float_as_int(mail[16 * kBlock]);
+                        hu = 0.f;
+                        phase = PH_ANY;
+                    } else {
+                        tmax = kFltMax;
+                        tri = -1;
+                        phase = PH_CLOSEST;
+                    }
+                } else if (code == SV_REPOST) {
+                    phase = PW_POST;  // the executor moved this lane to its next slot: needs ADV again
+                } else {
+                    phase = PH_IDLE;
+                }
+            }
+        }
+#ifdef RT_TRACE_PROFILE
+        const unsigned long long pf_s1 = __builtin_readcyclecounter();
+        pf[13] += pf_s1 - pf_s0;
+#endif
+        // ---- 3. what can this wave do now?
+        const bool trav = phase == PH_ANY || phase == PH_CLOSEST;
+        const bool want_node = trav && cur >= 0;
+        const bool want_tri = trav && cur != kEntryDone && cur < 0;
+        const int n_node = __popcll(__ballot(want_node));
+        const int n_tri = __popcll(__ballot(want_tri));
+        const int n_open = __popcll(__ballot(phase == PW_WAIT || phase == PW_POST));
+        if (n_node + n_tri + n_open == 0) break;  // every lane is out of slots
+        const int pending = __builtin_amdgcn_readfirstlane(pend_raw);
+        polled = (phase == PW_WAIT) ? __hip_atomic_load(&state_base[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : SV_NONE;
+        pend_raw = __hip_atomic_load(&qctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) -
+                   __hip_atomic_load(&qctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        // a wave with traversal work serves full batches only; a wave without serves what there is once it has
+        // found nothing else to do a few times in a row (the requests may be all that is left in the workgroup)
+        const bool no_trav = n_node + n_tri == 0;
+        idle_polls = no_trav ? idle_polls + 1 : 0;
+        const int need = (no_trav && idle_polls > 4) ? 1 : (no_trav ? min(adv_batch, 24) : adv_batch);
+        if (pending >= need) {
+            int h = 0, m = 0;
+            if (lane_id() == 0) {
+                const int hh = __hip_atomic_load(&qctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const int tt = __hip_atomic_load(&qctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const int mm = min(64, tt - hh);
+                if (mm >= need && atomicCAS(&qctl[0], hh, hh + mm) == hh) {
+                    h = hh;
+                    m = mm;
+                }
+            }
+            h = __builtin_amdgcn_readfirstlane(h);
+            m = __builtin_amdgcn_readfirstlane(m);
+            if (m > 0) {
+#ifdef RT_TRACE_PROFILE
+    pf[0]++; pf[1] += m;
+                const unsigned long long pf_ta = __builtin_readcyclecounter();
+#endif
+                // ---------------- ADV block for requesters ring[h .. h+m)
+                AdvanceOut out;
+                out.did_gen = out.did_shade = out.has_shadow = out.did_emit = out.new_ray = false;
+                out.rr_draws = 0;
+                if ((int)lane_id() < m) {
+                    const int qi = (h + (int)lane_id()) & (kBlock - 1);
+                    unsigned t;
+                    do t = ring[qi]; while (t == 0xffffu);  // reserved by its poster, arrives at once
+                    ring[qi] = 0xffffu;
+                    RT_LDS_ORDER();
+                    int *tc = cold_base + t;
+                    float *tm = mail_base + t;
+                    SlotState st;
+                    st.bounces = tc[0 * kBlock];
+                    st.pixel = tc[1 * kBlock];
+                    st.gen = tc[2 * kBlock];
+                    st.rs = Rng{(uint32_t)tc[3 * kBlock], (uint32_t)tc[4 * kBlock], (uint32_t)tc[5 * kBlock],
+                                (uint32_t)tc[6 * kBlock], (uint32_t)tc[7 * kBlock], (uint32_t)tc[8 * kBlock]};
+                    st.beta = mk(__int_as_float(tc[9 * kBlock]), __int_as_float(tc[10 * kBlock]), __int_as_float(tc[11 * kBlock]));
+                    int ti = tc[12 * kBlock];
+                    const int ttri = __float_as_int(tm[0 * kBlock]);
+                    st.wo = mk(tm[3 * kBlock], tm[4 * kBlock], tm[5 * kBlock]);
+                    st.hit_info = -1;
+                    st.isect_p = st.isect_n = mk(0, 0, 0);
+                    if (ttri >= 0) {  // hit record in the form mat() consumes (render.cuh:152-153, 311-316)
+                        Tri tr = load_tri(sc.tris, ttri);
+                        int2 ml = sc.tri_info[(unsigned)ttri];
+                        st.isect_p = tri_point(tr, tm[1 * kBlock], tm[2 * kBlock]);
+                        st.isect_n = neg(unit(tr.n));
+                        st.hit_info = (ml.x & 0xffff) | ((ml.y + 1) << 16);
+                    }
+                    advance_core(sc, tab, cam, ap, ap.slot_lo + ti, st, out, fb);
+                    int code;
+                    if (out.has_shadow) {
+                        tm[0 * kBlock] = out.ray_o.x;
+                        tm[1 * kBlock] = out.ray_o.y;
+                        tm[2 * kBlock] = out.ray_o.z;
+                        tm[3 * kBlock] = out.ray_d.x;
+                        tm[4 * kBlock] = out.ray_d.y;
+                        tm[5 * kBlock] = out.ray_d.z;
+                        tm[6 * kBlock] = out.s_L.x;
+                        tm[7 * kBlock] = out.s_L.y;
+                        tm[8 * kBlock] = out.s_L.z;
+                        tm[9 * kBlock] = out.s_o.x;
+                        tm[10 * kBlock] = out.s_o.y;
+                        tm[11 * kBlock] = out.s_o.z;
+                        tm[12 * kBlock] = out.s_d.x;
+                        tm[13 * kBlock] = out.s_d.y;
+                        tm[14 * kBlock] = out.s_d.z;
+                        tm[15 * kBlock] = out.s_tmax;
+                        tm[16 * kBlock] = __int_as_float(out.s_target);
+                        code = SV_ANY;
+                    } else if (out.new_ray) {
+                        tm[9 * kBlock] = out.ray_o.x;
+                        tm[10 * kBlock] = out.ray_o.y;
+                        tm[11 * kBlock] = out.ray_o.z;
+                        tm[12 * kBlock] = out.ray_d.x;
+                        tm[13 * kBlock] = out.ray_d.y;
+                        tm[14 * kBlock] = out.ray_d.z;
+                        code = SV_CLOSEST;
+                    } else {
+                        // the slot is out of camera rays (or parked for the lockstep final generation): hand it
+                        // back to the pools and move the requester to its next slot
+                        p.bounces(ti) = st.bounces;
+                        p.pixel(ti) = st.pixel;
+                        p.gen(ti) = st.gen;
+                        p.hit_info(ti) = -1;
+                        p.stmax(ti) = -1.f;
+                        p.br(ti) = st.beta.x;
+                        p.bg(ti) = st.beta.y;
+                        p.bb(ti) = st.beta.z;
+                        p.rd(ti) = st.rs.d;
+                        p.r0(ti) = st.rs.v0;
+                        p.r1(ti) = st.rs.v1;
+                        p.r2(ti) = st.rs.v2;
+                        p.r3(ti) = st.rs.v3;
+                        p.r4(ti) = st.rs.v4;
+                        code = SV_IDLE;
+                        ti += lanes_in_grid;
+                        if (ti < ap.n) {
+                            st.bounces = p.bounces(ti);
+                            if (st.bounces != kDone && st.bounces != kParked) {  // (untouched slots start alive)
+                                st.pixel = p.pixel(ti);
+                                st.gen = p.gen(ti);
+                                st.rs = Rng{p.rd(ti), p.r0(ti), p.r1(ti), p.r2(ti), p.r3(ti), p.r4(ti)};
+                                st.beta = mk(p.br(ti), p.bg(ti), p.bb(ti));
+                                tm[0 * kBlock] = __int_as_float(-1);
+                                code = SV_REPOST;
+                            }
+                        }
+                    }
+                    if (code != SV_IDLE) {
+                        tc[0 * kBlock] = st.bounces;
+                        tc[1 * kBlock] = st.pixel;
+                        tc[2 * kBlock] = st.gen;
+                        tc[3 * kBlock] = (int)st.rs.d;
+                        tc[4 * kBlock] = (int)st.rs.v0;
+                        tc[5 * kBlock] = (int)st.rs.v1;
+                        tc[6 * kBlock] = (int)st.rs.v2;
+                        tc[7 * kBlock] = (int)st.rs.v3;
+                        tc[8 * kBlock] = (int)st.rs.v4;
+                        tc[9 * kBlock] = __float_as_int(st.beta.x);
+                        tc[10 * kBlock] = __float_as_int(st.beta.y);
+                        tc[11 * kBlock] = __float_as_int(st.beta.z);
+                        tc[12 * kBlock] = ti;
+                    }
+                    RT_LDS_ORDER();
+                    __hip_atomic_store(&state_base[t], code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                n_gen += __popcll(__ballot(out.did_gen));
+                n_shade += __popcll(__ballot(out.did_shade));
+                n_traced += __popcll(__ballot(out.new_ray));
+                n_shadow += __popcll(__ballot(out.has_shadow));
+                n_emit += __popcll(__ballot(out.did_emit));
+                int rr = out.rr_draws;
+                if (__ballot(rr != 0)) {
+                    for (int off = 32; off > 0; off >>= 1) rr += __shfl_xor(rr, off);
+                    n_rr += (unsigned long long)rr;
+                }
+#ifdef RT_TRACE_PROFILE
+                pf[8] += __builtin_readcyclecounter() - pf_ta;
+#endif
+                continue;
+            }
+        }
+        if (no_trav) {  // only waiting lanes
+#ifdef RT_TRACE_PROFILE
+            pf[12]++;
+#endif
+            __builtin_amdgcn_s_sleep(4);
+            continue;
+        }
+#ifdef RT_TRACE_PROFILE
+        pf[14] += __builtin_readcyclecounter() - pf_s1;
+#endif
+        const bool is_any = phase == PH_ANY;
+        // ---------------- node steps
+        if (n_node > 0 && n_node >= n_tri) {
+#ifdef RT_TRACE_PROFILE
+            pf[2]++; pf[3] += n_node; pf[6] += n_open;
+            const unsigned long long pf_tn = __builtin_readcyclecounter();
+#endif
+            if (want_node) {
+#pragma unroll
+                for (int rep = 0; rep < kNodePerStep; rep++)
+                    if (cur >= 0) inner_step<WIDE>(sc, o, inv, tmax, cur, sp, stack, over, stack_cap, (const float4 *)nullptr, 0);
+            }
+#ifdef RT_TRACE_PROFILE
+            pf[9] += __builtin_readcyclecounter() - pf_tn;
+#endif
+        }
+        // ---------------- triangle tests (triangle.cuh:39-58)
+        if (n_tri > 0 && n_tri > n_node) {
+#ifdef RT_TRACE_PROFILE
+            pf[4]++; pf[5] += n_tri; pf[7] += n_open;
+            const unsigned long long pf_tt = __builtin_readcyclecounter();
+#endif
+            if (want_tri) {
+                bool stop = false;
+                int reps = 0;
+                do {
+                    int ref = ~cur;
+                    int k = ref >> 3, count = ref & 7;
+                    Tri tr = load_tri(sc.tris, k);
+                    float t, u, v;
+                    if (tri_intersect(tr, o, d, tmax, t, u, v)) {
+                        if (is_any) {
+                            if (k != tri) {  // bvh.cuh:243
+                                hu = 1.f;
+                                stop = true;
+                            }
+                        } else {  // bvh.cuh:227-231
+                            tmax = t;
+                            hu = u;
+                            hv = v;
+                            tri = k;
+                        }
+                    }
+                    if (stop) cur = kEntryDone;
+                    else if (count > 1) cur = leaf_ref(k + 1, count - 1);
+                    else if (sp > 0) cur = stack_pop(stack, over, sp, stack_cap);
+                    else cur = kEntryDone;
+                    reps++;
+                } while (reps < kTriPerStep && cur != kEntryDone && cur < 0 && !stop);
+            }
+#ifdef RT_TRACE_PROFILE
+            pf[10] += __builtin_readcyclecounter() - pf_tt;
+#endif
+        }
+        // ---------------- finished rays
+#ifdef RT_TRACE_PROFILE
+        const unsigned long long pf_s2 = __builtin_readcyclecounter();
+#endif
+        const bool fin = trav && cur == kEntryDone;
+        n_deposit += __popcll(__ballot(fin && is_any && hu == 0.f));
+        if (fin) {
+            if (is_any) {
+                if (hu == 0.f && !debug_no_deposit)  // unoccluded: render.cuh:291-293
+                    deposit(fb, ap.fb_fixed, cold[1 * kBlock], mail[6 * kBlock], mail[7 * kBlock], mail[8 * kBlock]);
+                o = mk(mail[0 * kBlock], mail[1 * kBlock], mail[2 * kBlock]);
+                d = mk(mail[3 * kBlock], mail[4 * kBlock], mail[5 * kBlock]);
+                phase = PH_CLOSEST;
+                inv = inv_dir(d);
+                tmax = kFltMax;
+                tri = -1;
+                cur = 0;
+                sp = 0;
+            } else {
+                mail[0 * kBlock] = __int_as_float(tri);
+                mail[1 * kBlock] = hu;
+                mail[2 * kBlock] = hv;
+                mail[3 * kBlock] = d.x;
+                mail[4 * kBlock] = d.y;
+                mail[5 * kBlock] = d.z;
+                phase = PW_POST;
+            }
+        }
+#ifdef RT_TRACE_PROFILE
+        pf[15] += __builtin_readcyclecounter() - pf_s2;
+#endif
+    }
+#ifdef RT_TRACE_PROFILE
+    if (prof && lane_id() == 0)
+        { pf[11] = __builtin_readcyclecounter() - pf_t0; for (int k = 0; k < 16; k++) atomicAdd(&prof[k], pf[k]); }
 #endif
     unsigned long long v[C_COUNT] = {n_gen, n_shade, n_traced, n_shadow, n_emit, n_deposit, n_rr, 0ull};
     row_add(rows, v);
@@ -1931,8 +2345,8 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
         const int dbg = (flags & 0x100u) ? 1 : 0;
         unsigned long long *paths_prof = nullptr;
 #ifdef RT_TRACE_PROFILE
-        HIP_TRY(hipMalloc((void **)&paths_prof, 64));
-        HIP_TRY(hipMemset(paths_prof, 0, 64));
+        HIP_TRY(hipMalloc((void **)&paths_prof, 128));
+        HIP_TRY(hipMemset(paths_prof, 0, 128));
 #endif
         // all workgroups resident at once (4 per CU at <= 128 VGPRs), lane count a divisor of n
         int paths_blocks = grid_for(n);
@@ -1963,7 +2377,33 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
             hipLaunchKernelGGL((k_paths<T, WD, MJ, 4>), grid_paths, block, lds_paths, st, sc, c.pools, cam, ap, d_sum,   \
                                c.d_rows, paths_cap, d_over2, adv_batch, dbg, paths_prof, 0);                           \
     } while (0)
-        if (majority) {
+        bool pooled = false;  // ADV served from a workgroup-wide request queue (k_paths_pool)
+        if (const char *e = getenv("RT_POOL")) pooled = atoi(e) != 0;
+        if (pooled) {
+            // 4 workgroups per CU: at most 40 KB each; the traversal stack gets what the fixed columns and the
+            // scene's tables leave (deeper stacks continue in the global overflow area)
+            const size_t lds_fixed = sizeof(int) * (size_t)kBlock * (size_t)(kColdRows + kMailRows + 1) + 8 + 2 * kBlock +
+                                     (lds_tables ? sizeof(float) * (size_t)scene->tab_dwords : 0);
+            int pool_cap = paths_cap;
+            if (!few_blocks) pool_cap = std::max(2, std::min(paths_cap, (int)((40960 - (long)lds_fixed) / (long)(sizeof(int) * kBlock))));
+            if (ensure_overflow(scene->stack_bound - pool_cap, &d_over2)) return 1;
+            const size_t lds_pool = lds_fixed + sizeof(int) * (size_t)kBlock * (size_t)pool_cap;
+            if (const char *e = getenv("RT_ADV_BATCH")) (void)e; else adv_batch = 64;
+#define RT_LAUNCH_POOL(T, WD)                                                                                         \
+    do {                                                                                                               \
+        if (few_blocks)                                                                                                \
+            hipLaunchKernelGGL((k_paths_pool<T, WD, 2>), grid_paths, block, lds_pool, st, sc, c.pools, cam, ap, d_sum,  \
+                               c.d_rows, pool_cap, d_over2, adv_batch, dbg, paths_prof);                               \
+        else                                                                                                           \
+            hipLaunchKernelGGL((k_paths_pool<T, WD, 4>), grid_paths, block, lds_pool, st, sc, c.pools, cam, ap, d_sum,  \
+                               c.d_rows, pool_cap, d_over2, adv_batch, dbg, paths_prof);                               \
+    } while (0)
+            if (lds_tables && scene->wide) RT_LAUNCH_POOL(true, true);
+            else if (lds_tables) RT_LAUNCH_POOL(true, false);
+            else if (scene->wide) RT_LAUNCH_POOL(false, true);
+            else RT_LAUNCH_POOL(false, false);
+#undef RT_LAUNCH_POOL
+        } else if (majority) {
             if (lds_tables && scene->wide) RT_LAUNCH_PATHS(true, true, true);
             else if (lds_tables) RT_LAUNCH_PATHS(true, false, true);
             else if (scene->wide) RT_LAUNCH_PATHS(false, true, true);
@@ -1981,8 +2421,12 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
         HIP_TRY(hipEventElapsedTime(&ms_paths, c.ev_a, c.ev_b));
 #ifdef RT_TRACE_PROFILE
         {
-            unsigned long long h[8];
-            HIP_TRY(hipMemcpy(h, paths_prof, 64, hipMemcpyDeviceToHost));
+            unsigned long long h[16];
+            HIP_TRY(hipMemcpy(h, paths_prof, 128, hipMemcpyDeviceToHost));
+            fprintf(stderr, "k_paths cycles: ADV %.1f%% (%.0f / block) node %.1f%% (%.0f) tri %.1f%% (%.0f) rest %.1f%% | idle iterations %llu\n",
+                    100.0 * h[8] / h[11], h[0] ? (double)h[8] / h[0] : 0.0, 100.0 * h[9] / h[11], h[2] ? (double)h[9] / h[2] : 0.0,
+                    100.0 * h[10] / h[11], h[4] ? (double)h[10] / h[4] : 0.0, 100.0 * (double)(h[11] - h[8] - h[9] - h[10]) / h[11], h[12]);
+            fprintf(stderr, "k_paths_pool rest: post+poll %.1f%% decide+claim %.1f%% finish %.1f%%\n", 100.0 * h[13] / h[11], 100.0 * h[14] / h[11], 100.0 * h[15] / h[11]);
             fprintf(stderr, "k_paths profile: ADV blocks %llu avg lanes %.1f | node steps %llu avg lanes %.1f (ADV-waiting %.1f) | tri steps %llu avg lanes %.1f (ADV-waiting %.1f)\n",
                     h[0], h[0] ? (double)h[1] / h[0] : 0.0, h[2], h[2] ? (double)h[3] / h[2] : 0.0, h[2] ? (double)h[6] / h[2] : 0.0, h[4],
                     h[4] ? (double)h[5] / h[4] : 0.0, h[4] ? (double)h[7] / h[4] : 0.0);
