@@ -676,6 +676,9 @@ __device__ __forceinline__ void inner_step(const DScene &sc, V3 o, V3 inv, float
         q1 = q[1];
         q2 = q[2];
         q3 = q[3];
+        // keeps the two branches apart: merged into a select of pointers they become FLAT loads, which go
+        // through the texture addresser like any global load and make the LDS copy pointless
+        __asm__ volatile("" ::: "memory");
     } else {
         const float4 *q = (const float4 *)((const char *)sc.nodes + ((unsigned)cur << 6));
         q0 = q[0];
@@ -1019,7 +1022,8 @@ constexpr int kNodePerStep = RT_NODE_PER_STEP;  // node steps a lane makes per s
 template <bool LDS_TABLES, bool WIDE, bool MAJORITY, int MIN_WAVES>
 __global__ void __launch_bounds__(kBlock, MIN_WAVES)
 k_paths(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__ fb, DWaveRow *__restrict__ rows,
-        int stack_cap, int *overflow, int adv_batch, int debug_no_deposit, unsigned long long *prof, int top_n) {
+        int stack_cap, int *overflow, int adv_batch, int debug_no_deposit, unsigned long long *prof, int top_n,
+        int prio_period) {
     extern __shared__ int s_lds[];
     int *stack = s_lds + threadIdx.x;
     float *park = (float *)(s_lds + stack_cap * kBlock) + threadIdx.x;  // element k at park[k * kBlock]
@@ -1029,7 +1033,7 @@ k_paths(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__ f
     const float *tab = sc.tables;
     // small shards (MIN_WAVES == 2: at most 2 workgroups per CU, LDS to spare, latency-bound): the top of
     // the BVH is staged in LDS, so the first levels of every traversal do not leave the CU
-    const float4 *s_top = (const float4 *)(s_tab + (LDS_TABLES ? kTabDwordsMax : 0));
+    const float4 *s_top = (const float4 *)(s_tab + (LDS_TABLES ? ((sc.tab_dwords + 3) & ~3) : 0));  // (tables: what the scene needs)
     if (MIN_WAVES != 2) top_n = 0;
     for (int k = threadIdx.x; k < top_n * 4; k += kBlock) ((float4 *)s_top)[k] = sc.nodes[k];
     if (LDS_TABLES) {
@@ -1111,7 +1115,24 @@ k_paths(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__ f
     const unsigned long long pf_t0 = __builtin_readcyclecounter();
 #endif
 
+    // The SIMD's issue arbiter prefers the OLDEST of its waves.  Left alone, the four waves of a SIMD (one from
+    // each of the CU's four resident workgroups) finish in dispatch order at 0.63 / 0.73 / 0.81 / 0.92 of the
+    // kernel's duration although they carry the same work, and the SIMD spends the last third of the frame with
+    // three, two, one wave -- too few to hide anything.  Rotating the waves' priorities makes them progress
+    // together (0.87 .. 0.92; +7 % throughput): every 2^prio_period scheduling decisions a wave takes the next of
+    // the four levels, starting from its workgroup's residency rank.  (Steering the priority by measured
+    // progress against the grid's average was tried and is worse than the plain rotation.)
+    unsigned prio_tick = 0;
+    const unsigned prio_rank = (4u * blockIdx.x) / gridDim.x;
     while (true) {
+        if (prio_period && (prio_tick++ & ((1u << prio_period) - 1u)) == 0u) {
+            switch (((prio_tick >> prio_period) + prio_rank) & 3u) {
+                case 0: __builtin_amdgcn_s_setprio(0); break;
+                case 1: __builtin_amdgcn_s_setprio(1); break;
+                case 2: __builtin_amdgcn_s_setprio(2); break;
+                default: __builtin_amdgcn_s_setprio(3); break;
+            }
+        }
         // ---- what each lane wants next: the ADV block, a node step, or triangle tests
         const bool trav = phase == PH_ANY || phase == PH_CLOSEST;
         const bool want_node = trav && cur >= 0;
@@ -1298,408 +1319,307 @@ k_paths(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__ f
     }
 #ifdef RT_TRACE_PROFILE
     if (prof && lane_id() == 0)
-        { pf[11] = __builtin_readcyclecounter() - pf_t0; for (int k = 0; k < 16; k++) atomicAdd(&prof[k], pf[k]); }
+        { pf[11] = __builtin_readcyclecounter() - pf_t0; for (int k = 0; k < 16; k++) atomicAdd(&prof[k], pf[k]); atomicMax(&prof[13], pf[11]); atomicAdd(&prof[14], 1ull);
+          // per-wave record: where it ran and for how long
+          unsigned long long *rec = prof + 16 + 4 * (size_t)((blockIdx.x * kBlock + threadIdx.x) >> 6);
+          rec[0] = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_ID
+          rec[1] = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // XCC_ID
+          rec[2] = pf[11];
+          rec[3] = pf[0] + pf[2] + pf[4]; }
 #endif
     unsigned long long v[C_COUNT] = {n_gen, n_shade, n_traced, n_shadow, n_emit, n_deposit, n_rr, 0ull};
     row_add(rows, v);
 }
 
-// ============================================================================ k_paths_pool
-// k_paths with the ADV block served from a WORKGROUP-wide request queue.  In k_paths a wave runs the
-// ADV block (~1 500 instructions, by far the longest) for its own lanes only, typically with ~40 of
-// 64 lanes active, while the lanes already waiting for it idle through the traversal blocks.  Here a
-// lane that needs ADV posts its lane number to a ring in LDS and waits; any wave of the workgroup
-// that finds 64 requests pending (or has nothing else to do) claims up to 64 of them and executes
-// the ADV block with lane j working on the slot of the j-th requester.  That is possible because
-// everything the ADV block reads and writes is already in the requester's LDS columns: the slot
-// state (13 dwords), and a "mail" column that carries the hit record in and the next ray(s) out.
-//     lane:      CLOSEST done -> mail[0..5] = (tri, u, v, d), post, WAIT -> poll state -> next ray
-//     executor:  claim [head, head+m) by CAS -> advance_core for each -> mail, cold -> state = code
-// LDS layout: [stack: cap x 256][cold: 13 x 256][mail: 17 x 256][state: 256][head, tail][ring: 256 x u16][tables]
-// The ring has as many entries as the workgroup has lanes and a lane has at most one request
-// outstanding, so it cannot overflow.  A wave only ever waits for (a) another wave's ring entry whose
-// index that wave has already reserved, (b) an executor that is running: no circular waits.
-// All cross-wave communication is LDS -> LDS.  The LDS executes one wave's ds instructions in issue order,
-// so a consumer that sees a flag also sees everything its producer wrote before it; what has to be
-// prevented is only the COMPILER moving LDS accesses across the flag.  (A real workgroup-scope fence also
-// waits for every outstanding global load and atomic of the wave -- measured: 40 % of the kernel.)
-#define RT_LDS_ORDER() __asm__ volatile("" ::: "memory")
-enum { PW_POST = 4, PW_WAIT = 5 };                          // extra lane phases (besides PH_ANY/PH_CLOSEST/PH_IDLE)
-enum { SV_NONE = 0, SV_ANY = 2, SV_CLOSEST = 3, SV_IDLE = 4, SV_REPOST = 5 };  // executor -> lane
-constexpr int kColdRows = 13, kMailRows = 17;
-template <bool LDS_TABLES, bool WIDE, int MIN_WAVES>
-__global__ void __launch_bounds__(kBlock, MIN_WAVES)
-k_paths_pool(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__ fb, DWaveRow *__restrict__ rows,
-             int stack_cap, int *overflow, int adv_batch, int debug_no_deposit, unsigned long long *prof) {
+// ============================================================================ k_paths_dual
+// k_paths for SMALL SHARDS (at most 2 workgroups per CU: the 1/8 shard of an 8-GPU render has one slot
+// per lane of half the machine).  There the chip is not short of issue slots but of independent work:
+// with 2 waves per SIMD a node step costs what its memory round trip costs.  A slot that has just been
+// shaded has TWO rays -- the shadow ray of its next-event estimate and its continuation ray -- and they
+// do not depend on each other: the shadow ray's outcome only decides a deposit.  k_paths traces them one
+// after the other; this kernel gives a lane two traversal contexts and traces them TOGETHER:
+//     A  the slot's path ray   (closest hit -> hit record for the next ADV)
+//     B  the slot's shadow ray (any hit; deposits when unoccluded, then the context is free)
+// Both contexts' node (triangle) records are fetched before either is evaluated, so a lane has two
+// memory round trips in flight and a slot-round takes max(A, B) instead of A + B.  The next ADV of a
+// slot waits for both.  Same estimator, same RNG streams, same sums: which lane-context traces a ray
+// does not enter the arithmetic.  2-wide records only; no register pressure (2 waves/SIMD: 256 VGPRs).
+// LDS layout: [stack A: cap x 256][stack B: cap x 256][slot state: 12 x 256][tables]
+struct TravCtx {
+    V3 o, d, inv;
+    float tmax, hu, hv;
+    int cur, sp, tri;
+};
+__device__ __forceinline__ void node_fetch_global(const DScene &sc, int cur, float4 (&q)[4]) {
+    const float4 *g = (const float4 *)((const char *)sc.nodes + ((unsigned)cur << 6));
+    q[0] = g[0]; q[1] = g[1]; q[2] = g[2]; q[3] = g[3];
+}
+// the 2-wide branch of inner_step on an already fetched record; the whole stack is in LDS (no overflow
+// area: a global access inside the evaluation would make it wait for the other context's fetch)
+__device__ __forceinline__ void node_eval(const float4 (&q)[4], TravCtx &c, int *stack) {
+    int cl = __float_as_int(q[3].x), cr = __float_as_int(q[3].y);
+    float el, er;
+    bool hl = box_hit(c.o, c.inv, q[0].x, q[0].y, q[0].z, q[0].w, q[1].x, q[1].y, c.tmax, el) && cl != kEntryDone;
+    bool hr = box_hit(c.o, c.inv, q[1].z, q[1].w, q[2].x, q[2].y, q[2].z, q[2].w, c.tmax, er) && cr != kEntryDone;
+    if (hl && hr) {
+        bool left_first = !(el > er);
+        stack[c.sp++ * kBlock] = left_first ? cr : cl;
+        c.cur = left_first ? cl : cr;
+    } else if (hl) {
+        c.cur = cl;
+    } else if (hr) {
+        c.cur = cr;
+    } else if (c.sp > 0) {
+        c.cur = stack[--c.sp * kBlock];
+    } else {
+        c.cur = kEntryDone;
+    }
+}
+// one triangle of the leaf the cursor points at, then advance the cursor (triangle.cuh:39-58; bvh.cuh:222-248)
+template <bool ANY>
+__device__ __forceinline__ void leaf_eval(const Tri &tr, int k, int count, TravCtx &c, int *stack) {
+    float t, u, v;
+    bool stop = false;
+    if (tri_intersect(tr, c.o, c.d, c.tmax, t, u, v)) {
+        if (ANY) {
+            if (k != c.tri) {  // bvh.cuh:243: first accepted hit that is not the excluded triangle
+                c.hu = 1.f;
+                stop = true;
+            }
+        } else {  // bvh.cuh:227-231: later equal-t hit wins (t <= tmax)
+            c.tmax = t;
+            c.hu = u;
+            c.hv = v;
+            c.tri = k;
+        }
+    }
+    if (stop) c.cur = kEntryDone;
+    else if (count > 1) c.cur = leaf_ref(k + 1, count - 1);
+    else if (c.sp > 0) c.cur = stack[--c.sp * kBlock];
+    else c.cur = kEntryDone;
+}
+
+template <bool LDS_TABLES>
+__global__ void __launch_bounds__(kBlock, 2)
+k_paths_dual(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__ fb, DWaveRow *__restrict__ rows,
+             int stack_cap, int adv_batch, int debug_no_deposit, unsigned long long *prof) {
     extern __shared__ int s_lds[];
-    int *stack = s_lds + threadIdx.x;
-    int *cold_base = s_lds + stack_cap * kBlock;
-    float *mail_base = (float *)(cold_base + kColdRows * kBlock);
-    int *state_base = (int *)(mail_base + kMailRows * kBlock);
-    int *qctl = state_base + kBlock;  // [0] head, [1] tail (monotonic; ring index = value & 255)
-    volatile unsigned short *ring = (volatile unsigned short *)(qctl + 2);
-    float *s_tab = (float *)(qctl + 2 + kBlock / 2);
-    int *over = overflow + (blockIdx.x * kBlock + threadIdx.x) % kOverStride;
+    int *stack_a = s_lds + threadIdx.x;
+    int *stack_b = s_lds + stack_cap * kBlock + threadIdx.x;
+    int *cold = s_lds + 2 * stack_cap * kBlock + threadIdx.x;  // element k at cold[k * kBlock]
+    float *s_tab = (float *)(s_lds + (2 * stack_cap + 12) * kBlock);
     const float *tab = sc.tables;
     if (LDS_TABLES) {
         for (int k = threadIdx.x; k < sc.tab_dwords; k += kBlock) s_tab[k] = sc.tables[k];
         tab = s_tab;
-    }
-    float *mail = mail_base + threadIdx.x;  // this lane's own columns
-    int *cold = cold_base + threadIdx.x;
-    const int lanes_in_grid = (int)(gridDim.x * blockDim.x);
-
-    int phase = PH_IDLE;
-    V3 o = mk(0, 0, 0), d = mk(0, 0, 0), inv = mk(0, 0, 0);
-    float tmax = 0.f, hu = 0.f, hv = 0.f;
-    int cur = kEntryDone, sp = 0, tri = -1;
-    {
-        if (threadIdx.x < 2) qctl[threadIdx.x] = 0;
-        ring[threadIdx.x] = 0xffffu;
-        state_base[threadIdx.x] = SV_NONE;
-        const int i = blockIdx.x * blockDim.x + threadIdx.x;
-        if (i < ap.n) {
-            const int b = p.bounces(i);
-            if (b != kDone && b != kParked) {
-                cold[0 * kBlock] = b;
-                cold[1 * kBlock] = p.pixel(i);
-                cold[2 * kBlock] = p.gen(i);
-                cold[3 * kBlock] = (int)p.rd(i);
-                cold[4 * kBlock] = (int)p.r0(i);
-                cold[5 * kBlock] = (int)p.r1(i);
-                cold[6 * kBlock] = (int)p.r2(i);
-                cold[7 * kBlock] = (int)p.r3(i);
-                cold[8 * kBlock] = (int)p.r4(i);
-                cold[9 * kBlock] = __float_as_int(p.br(i));
-                cold[10 * kBlock] = __float_as_int(p.bg(i));
-                cold[11 * kBlock] = __float_as_int(p.bb(i));
-                cold[12 * kBlock] = i;
-                mail[0] = __int_as_float(-1);  // no hit record
-                phase = PW_POST;
-            }
-        }
         __syncthreads();
+    }
+    const int lanes_in_grid = (int)(gridDim.x * blockDim.x);
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int bounces = kDone, pixel = 0, gen = 0;
+    Rng rs{0, 0, 0, 0, 0, 0};
+    V3 beta = mk(0, 0, 0);
+    auto load_slot = [&](int k) {
+        bounces = p.bounces(k);
+        pixel = p.pixel(k);
+        gen = p.gen(k);
+        rs = Rng{p.rd(k), p.r0(k), p.r1(k), p.r2(k), p.r3(k), p.r4(k)};
+        beta = mk(p.br(k), p.bg(k), p.bb(k));
+    };
+    auto store_slot = [&](int k) {
+        p.bounces(k) = bounces;
+        p.pixel(k) = pixel;
+        p.gen(k) = gen;
+        p.hit_info(k) = -1;
+        p.stmax(k) = -1.f;
+        p.br(k) = beta.x;
+        p.bg(k) = beta.y;
+        p.bb(k) = beta.z;
+        p.rd(k) = rs.d;
+        p.r0(k) = rs.v0;
+        p.r1(k) = rs.v1;
+        p.r2(k) = rs.v2;
+        p.r3(k) = rs.v3;
+        p.r4(k) = rs.v4;
+    };
+    auto cold_save = [&]() {
+        cold[0 * kBlock] = bounces;
+        cold[1 * kBlock] = pixel;
+        cold[2 * kBlock] = gen;
+        cold[3 * kBlock] = (int)rs.d;
+        cold[4 * kBlock] = (int)rs.v0;
+        cold[5 * kBlock] = (int)rs.v1;
+        cold[6 * kBlock] = (int)rs.v2;
+        cold[7 * kBlock] = (int)rs.v3;
+        cold[8 * kBlock] = (int)rs.v4;
+        cold[9 * kBlock] = __float_as_int(beta.x);
+        cold[10 * kBlock] = __float_as_int(beta.y);
+        cold[11 * kBlock] = __float_as_int(beta.z);
+    };
+    auto cold_load = [&]() {
+        bounces = cold[0 * kBlock];
+        pixel = cold[1 * kBlock];
+        gen = cold[2 * kBlock];
+        rs = Rng{(uint32_t)cold[3 * kBlock], (uint32_t)cold[4 * kBlock], (uint32_t)cold[5 * kBlock],
+                 (uint32_t)cold[6 * kBlock], (uint32_t)cold[7 * kBlock], (uint32_t)cold[8 * kBlock]};
+        beta = mk(__int_as_float(cold[9 * kBlock]), __int_as_float(cold[10 * kBlock]), __int_as_float(cold[11 * kBlock]));
+    };
+    // A: PH_CLOSEST while tracing, PH_ADV when its hit record waits for the ADV block, PH_IDLE when out of slots.
+    // B: active while b_on.  (A.tri, A.hu, A.hv, A.d) are the hit record between the end of A's trace and ADV.
+    int phase = PH_IDLE;
+    TravCtx A{mk(0, 0, 0), mk(0, 0, 0), mk(0, 0, 0), 0.f, 0.f, 0.f, kEntryDone, 0, -1};
+    TravCtx B = A;
+    bool b_on = false;
+    V3 b_L = mk(0, 0, 0);  // radiance the shadow ray deposits if unoccluded, and where
+    int b_pixel = 0;
+    if (i < ap.n) {
+        load_slot(i);
+        phase = (bounces != kDone && bounces != kParked) ? PH_ADV : PH_IDLE;
+        cold_save();
     }
     unsigned long long n_gen = 0, n_shade = 0, n_traced = 0, n_shadow = 0, n_emit = 0, n_deposit = 0, n_rr = 0;
 #ifdef RT_TRACE_PROFILE
     unsigned long long pf[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    const unsigned long long pf_t0 = __builtin_readcyclecounter();
 #endif
 
-    int polled = SV_NONE, pend_raw = 0, idle_polls = 0;
     while (true) {
+        const bool a_trav = phase == PH_CLOSEST;
+        const bool a_node = a_trav && A.cur >= 0;
+        const bool a_tri = a_trav && A.cur != kEntryDone && A.cur < 0;
+        const bool b_node = b_on && B.cur >= 0;
+        const bool b_tri = b_on && B.cur != kEntryDone && B.cur < 0;
+        const bool adv_ready = phase == PH_ADV && !b_on;
+        const int n_adv = __popcll(__ballot(adv_ready));
+        const int n_node = __popcll(__ballot(a_node || b_node));
+        const int n_tri = __popcll(__ballot(a_tri || b_tri));
+        if (n_adv + n_node + n_tri == 0) break;
+        const bool run_adv = n_adv > 0 && ((n_adv >= adv_batch && n_adv >= n_node && n_adv >= n_tri) || n_node + n_tri == 0);
+        if (run_adv) {
 #ifdef RT_TRACE_PROFILE
-        const unsigned long long pf_s0 = __builtin_readcyclecounter();
+            pf[0]++; pf[1] += n_adv;
 #endif
-        // ---- 1. post ADV requests (one LDS atomic per wave)
-        {
-            const bool post = phase == PW_POST;
-            const unsigned long long pm = __ballot(post);
-            if (pm) {
-                int base = 0;
-                if (lane_id() == (unsigned)__ffsll((long long)pm) - 1u) base = atomicAdd(&qctl[1], __popcll(pm));
-                base = __shfl(base, __ffsll((long long)pm) - 1);
-                if (post) {
-                    const int rank = __popcll(pm & ((1ull << lane_id()) - 1ull));
-                    RT_LDS_ORDER();  // mail / cold writes first
-                    ring[(base + rank) & (kBlock - 1)] = (unsigned short)threadIdx.x;
-                    phase = PW_WAIT;
+            AdvanceOut out;
+            out.did_gen = out.did_shade = out.has_shadow = out.did_emit = out.new_ray = false;
+            out.rr_draws = 0;
+            if (adv_ready) {
+                cold_load();
+                SlotState st;
+                st.bounces = bounces;
+                st.pixel = pixel;
+                st.gen = gen;
+                st.rs = rs;
+                st.beta = beta;
+                st.wo = A.d;
+                st.hit_info = -1;
+                st.isect_p = st.isect_n = mk(0, 0, 0);
+                if (A.tri >= 0) {  // hit record in the form mat() consumes (render.cuh:152-153, 311-316)
+                    Tri tr = load_tri(sc.tris, A.tri);
+                    int2 ml = sc.tri_info[(unsigned)A.tri];
+                    st.isect_p = tri_point(tr, A.hu, A.hv);
+                    st.isect_n = neg(unit(tr.n));
+                    st.hit_info = (ml.x & 0xffff) | ((ml.y + 1) << 16);
                 }
-            }
-        }
-        // ---- 2. served?  (`polled` and `pending` were read one iteration ago: their LDS latency is hidden
-        // behind the traversal blocks, and being one iteration late costs nothing)
-        if (phase == PW_WAIT) {
-            const int code = polled;
-            if (code != SV_NONE) {
-                RT_LDS_ORDER();
-                state_base[threadIdx.x] = SV_NONE;
-                if (code == SV_ANY || code == SV_CLOSEST) {
-                    o = mk(mail[9 * kBlock], mail[10 * kBlock], mail[11 * kBlock]);
-                    d = mk(mail[12 * kBlock], mail[13 * kBlock], mail[14 * kBlock]);
-                    inv = inv_dir(d);
-                    cur = 0;
-                    sp = 0;
-                    if (code == SV_ANY) {
-                        tmax = mail[15 * kBlock];
-                        tri = __float_as_int(mail[16 * kBlock]);
-                        hu = 0.f;
-                        phase = PH_ANY;
-                    } else {
-                        tmax = kFltMax;
-                        tri = -1;
-                        phase = PH_CLOSEST;
-                    }
-                } else if (code == SV_REPOST) {
-                    phase = PW_POST;  // the executor moved this lane to its next slot: needs ADV again
+                advance_core(sc, tab, cam, ap, ap.slot_lo + i, st, out, fb);
+                bounces = st.bounces;
+                pixel = st.pixel;
+                gen = st.gen;
+                rs = st.rs;
+                beta = st.beta;
+                if (out.has_shadow) {
+                    B.o = out.s_o;
+                    B.d = out.s_d;
+                    B.inv = inv_dir(out.s_d);
+                    B.tmax = out.s_tmax;
+                    B.tri = out.s_target;
+                    B.hu = 0.f;
+                    B.cur = 0;
+                    B.sp = 0;
+                    b_L = out.s_L;
+                    b_pixel = pixel;
+                    b_on = true;
+                }
+                if (out.new_ray) {
+                    A.o = out.ray_o;
+                    A.d = out.ray_d;
+                    A.inv = inv_dir(out.ray_d);
+                    A.tmax = kFltMax;
+                    A.tri = -1;
+                    A.cur = 0;
+                    A.sp = 0;
+                    phase = PH_CLOSEST;
                 } else {
+                    // out of camera rays (or parked for the lockstep final generation): next slot of this lane
+                    store_slot(i);
                     phase = PH_IDLE;
-                }
-            }
-        }
-#ifdef RT_TRACE_PROFILE
-        const unsigned long long pf_s1 = __builtin_readcyclecounter();
-        pf[13] += pf_s1 - pf_s0;
-#endif
-        // ---- 3. what can this wave do now?
-        const bool trav = phase == PH_ANY || phase == PH_CLOSEST;
-        const bool want_node = trav && cur >= 0;
-        const bool want_tri = trav && cur != kEntryDone && cur < 0;
-        const int n_node = __popcll(__ballot(want_node));
-        const int n_tri = __popcll(__ballot(want_tri));
-        const int n_open = __popcll(__ballot(phase == PW_WAIT || phase == PW_POST));
-        if (n_node + n_tri + n_open == 0) break;  // every lane is out of slots
-        const int pending = __builtin_amdgcn_readfirstlane(pend_raw);
-        polled = (phase == PW_WAIT) ? __hip_atomic_load(&state_base[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : SV_NONE;
-        pend_raw = __hip_atomic_load(&qctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) -
-                   __hip_atomic_load(&qctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        // a wave with traversal work serves full batches only; a wave without serves what there is once it has
-        // found nothing else to do a few times in a row (the requests may be all that is left in the workgroup)
-        const bool no_trav = n_node + n_tri == 0;
-        idle_polls = no_trav ? idle_polls + 1 : 0;
-        const int need = (no_trav && idle_polls > 4) ? 1 : (no_trav ? min(adv_batch, 24) : adv_batch);
-        if (pending >= need) {
-            int h = 0, m = 0;
-            if (lane_id() == 0) {
-                const int hh = __hip_atomic_load(&qctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                const int tt = __hip_atomic_load(&qctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                const int mm = min(64, tt - hh);
-                if (mm >= need && atomicCAS(&qctl[0], hh, hh + mm) == hh) {
-                    h = hh;
-                    m = mm;
-                }
-            }
-            h = __builtin_amdgcn_readfirstlane(h);
-            m = __builtin_amdgcn_readfirstlane(m);
-            if (m > 0) {
-#ifdef RT_TRACE_PROFILE
-    pf[0]++; pf[1] += m;
-                const unsigned long long pf_ta = __builtin_readcyclecounter();
-#endif
-                // ---------------- ADV block for requesters ring[h .. h+m)
-                AdvanceOut out;
-                out.did_gen = out.did_shade = out.has_shadow = out.did_emit = out.new_ray = false;
-                out.rr_draws = 0;
-                if ((int)lane_id() < m) {
-                    const int qi = (h + (int)lane_id()) & (kBlock - 1);
-                    unsigned t;
-                    do t = ring[qi]; while (t == 0xffffu);  // reserved by its poster, arrives at once
-                    ring[qi] = 0xffffu;
-                    RT_LDS_ORDER();
-                    int *tc = cold_base + t;
-                    float *tm = mail_base + t;
-                    SlotState st;
-                    st.bounces = tc[0 * kBlock];
-                    st.pixel = tc[1 * kBlock];
-                    st.gen = tc[2 * kBlock];
-                    st.rs = Rng{(uint32_t)tc[3 * kBlock], (uint32_t)tc[4 * kBlock], (uint32_t)tc[5 * kBlock],
-                                (uint32_t)tc[6 * kBlock], (uint32_t)tc[7 * kBlock], (uint32_t)tc[8 * kBlock]};
-                    st.beta = mk(__int_as_float(tc[9 * kBlock]), __int_as_float(tc[10 * kBlock]), __int_as_float(tc[11 * kBlock]));
-                    int ti = tc[12 * kBlock];
-                    const int ttri = __float_as_int(tm[0 * kBlock]);
-                    st.wo = mk(tm[3 * kBlock], tm[4 * kBlock], tm[5 * kBlock]);
-                    st.hit_info = -1;
-                    st.isect_p = st.isect_n = mk(0, 0, 0);
-                    if (ttri >= 0) {  // hit record in the form mat() consumes (render.cuh:152-153, 311-316)
-                        Tri tr = load_tri(sc.tris, ttri);
-                        int2 ml = sc.tri_info[(unsigned)ttri];
-                        st.isect_p = tri_point(tr, tm[1 * kBlock], tm[2 * kBlock]);
-                        st.isect_n = neg(unit(tr.n));
-                        st.hit_info = (ml.x & 0xffff) | ((ml.y + 1) << 16);
+                    A.tri = -1;
+                    i += lanes_in_grid;
+                    if (i < ap.n) {
+                        load_slot(i);
+                        if (bounces != kDone && bounces != kParked) phase = PH_ADV;
+                        else i = ap.n;
                     }
-                    advance_core(sc, tab, cam, ap, ap.slot_lo + ti, st, out, fb);
-                    int code;
-                    if (out.has_shadow) {
-                        tm[0 * kBlock] = out.ray_o.x;
-                        tm[1 * kBlock] = out.ray_o.y;
-                        tm[2 * kBlock] = out.ray_o.z;
-                        tm[3 * kBlock] = out.ray_d.x;
-                        tm[4 * kBlock] = out.ray_d.y;
-                        tm[5 * kBlock] = out.ray_d.z;
-                        tm[6 * kBlock] = out.s_L.x;
-                        tm[7 * kBlock] = out.s_L.y;
-                        tm[8 * kBlock] = out.s_L.z;
-                        tm[9 * kBlock] = out.s_o.x;
-                        tm[10 * kBlock] = out.s_o.y;
-                        tm[11 * kBlock] = out.s_o.z;
-                        tm[12 * kBlock] = out.s_d.x;
-                        tm[13 * kBlock] = out.s_d.y;
-                        tm[14 * kBlock] = out.s_d.z;
-                        tm[15 * kBlock] = out.s_tmax;
-                        tm[16 * kBlock] = __int_as_float(out.s_target);
-                        code = SV_ANY;
-                    } else if (out.new_ray) {
-                        tm[9 * kBlock] = out.ray_o.x;
-                        tm[10 * kBlock] = out.ray_o.y;
-                        tm[11 * kBlock] = out.ray_o.z;
-                        tm[12 * kBlock] = out.ray_d.x;
-                        tm[13 * kBlock] = out.ray_d.y;
-                        tm[14 * kBlock] = out.ray_d.z;
-                        code = SV_CLOSEST;
-                    } else {
-                        // the slot is out of camera rays (or parked for the lockstep final generation): hand it
-                        // back to the pools and move the requester to its next slot
-                        p.bounces(ti) = st.bounces;
-                        p.pixel(ti) = st.pixel;
-                        p.gen(ti) = st.gen;
-                        p.hit_info(ti) = -1;
-                        p.stmax(ti) = -1.f;
-                        p.br(ti) = st.beta.x;
-                        p.bg(ti) = st.beta.y;
-                        p.bb(ti) = st.beta.z;
-                        p.rd(ti) = st.rs.d;
-                        p.r0(ti) = st.rs.v0;
-                        p.r1(ti) = st.rs.v1;
-                        p.r2(ti) = st.rs.v2;
-                        p.r3(ti) = st.rs.v3;
-                        p.r4(ti) = st.rs.v4;
-                        code = SV_IDLE;
-                        ti += lanes_in_grid;
-                        if (ti < ap.n) {
-                            st.bounces = p.bounces(ti);
-                            if (st.bounces != kDone && st.bounces != kParked) {  // (untouched slots start alive)
-                                st.pixel = p.pixel(ti);
-                                st.gen = p.gen(ti);
-                                st.rs = Rng{p.rd(ti), p.r0(ti), p.r1(ti), p.r2(ti), p.r3(ti), p.r4(ti)};
-                                st.beta = mk(p.br(ti), p.bg(ti), p.bb(ti));
-                                tm[0 * kBlock] = __int_as_float(-1);
-                                code = SV_REPOST;
-                            }
-                        }
-                    }
-                    if (code != SV_IDLE) {
-                        tc[0 * kBlock] = st.bounces;
-                        tc[1 * kBlock] = st.pixel;
-                        tc[2 * kBlock] = st.gen;
-                        tc[3 * kBlock] = (int)st.rs.d;
-                        tc[4 * kBlock] = (int)st.rs.v0;
-                        tc[5 * kBlock] = (int)st.rs.v1;
-                        tc[6 * kBlock] = (int)st.rs.v2;
-                        tc[7 * kBlock] = (int)st.rs.v3;
-                        tc[8 * kBlock] = (int)st.rs.v4;
-                        tc[9 * kBlock] = __float_as_int(st.beta.x);
-                        tc[10 * kBlock] = __float_as_int(st.beta.y);
-                        tc[11 * kBlock] = __float_as_int(st.beta.z);
-                        tc[12 * kBlock] = ti;
-                    }
-                    RT_LDS_ORDER();
-                    __hip_atomic_store(&state_base[t], code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
-                n_gen += __popcll(__ballot(out.did_gen));
-                n_shade += __popcll(__ballot(out.did_shade));
-                n_traced += __popcll(__ballot(out.new_ray));
-                n_shadow += __popcll(__ballot(out.has_shadow));
-                n_emit += __popcll(__ballot(out.did_emit));
-                int rr = out.rr_draws;
-                if (__ballot(rr != 0)) {
-                    for (int off = 32; off > 0; off >>= 1) rr += __shfl_xor(rr, off);
-                    n_rr += (unsigned long long)rr;
-                }
-#ifdef RT_TRACE_PROFILE
-                pf[8] += __builtin_readcyclecounter() - pf_ta;
-#endif
-                continue;
+                if (phase != PH_IDLE) cold_save();
             }
-        }
-        if (no_trav) {  // only waiting lanes
-#ifdef RT_TRACE_PROFILE
-            pf[12]++;
-#endif
-            __builtin_amdgcn_s_sleep(4);
+            n_gen += __popcll(__ballot(out.did_gen));
+            n_shade += __popcll(__ballot(out.did_shade));
+            n_traced += __popcll(__ballot(out.new_ray));
+            n_shadow += __popcll(__ballot(out.has_shadow));
+            n_emit += __popcll(__ballot(out.did_emit));
+            int rr = out.rr_draws;
+            if (__ballot(rr != 0)) {
+                for (int off = 32; off > 0; off >>= 1) rr += __shfl_xor(rr, off);
+                n_rr += (unsigned long long)rr;
+            }
             continue;
         }
-#ifdef RT_TRACE_PROFILE
-        pf[14] += __builtin_readcyclecounter() - pf_s1;
-#endif
-        const bool is_any = phase == PH_ANY;
-        // ---------------- node steps
+        // ---------------- node steps: both contexts' records are in flight before either is evaluated
         if (n_node > 0 && n_node >= n_tri) {
 #ifdef RT_TRACE_PROFILE
-            pf[2]++; pf[3] += n_node; pf[6] += n_open;
-            const unsigned long long pf_tn = __builtin_readcyclecounter();
+            pf[2]++; pf[3] += __popcll(__ballot(a_node)); pf[6] += __popcll(__ballot(b_node));
 #endif
-            if (want_node) {
+            // Software pipeline over the two contexts, straight-line (every lane fetches, from record 0 when it
+            // has nothing to visit, so that the waits the compiler inserts are exact): while A's record is
+            // evaluated B's is in flight, and A's next record is requested before B's evaluation starts.
+            float4 qa[4], qb[4];
+            node_fetch_global(sc, max(A.cur, 0), qa);
+            node_fetch_global(sc, max(B.cur, 0), qb);
 #pragma unroll
-                for (int rep = 0; rep < kNodePerStep; rep++)
-                    if (cur >= 0) inner_step<WIDE>(sc, o, inv, tmax, cur, sp, stack, over, stack_cap, (const float4 *)nullptr, 0);
+            for (int rep = 0; rep < kNodePerStep; rep++) {
+                if (a_node && A.cur >= 0) node_eval(qa, A, stack_a);
+                if (rep + 1 < kNodePerStep) node_fetch_global(sc, max(A.cur, 0), qa);
+                if (b_node && B.cur >= 0) node_eval(qb, B, stack_b);
+                if (rep + 1 < kNodePerStep) node_fetch_global(sc, max(B.cur, 0), qb);
             }
-#ifdef RT_TRACE_PROFILE
-            pf[9] += __builtin_readcyclecounter() - pf_tn;
-#endif
         }
-        // ---------------- triangle tests (triangle.cuh:39-58)
+        // ---------------- triangle tests
         if (n_tri > 0 && n_tri > n_node) {
 #ifdef RT_TRACE_PROFILE
-            pf[4]++; pf[5] += n_tri; pf[7] += n_open;
-            const unsigned long long pf_tt = __builtin_readcyclecounter();
+            pf[4]++; pf[5] += __popcll(__ballot(a_tri)); pf[7] += __popcll(__ballot(b_tri));
 #endif
-            if (want_tri) {
-                bool stop = false;
-                int reps = 0;
-                do {
-                    int ref = ~cur;
-                    int k = ref >> 3, count = ref & 7;
-                    Tri tr = load_tri(sc.tris, k);
-                    float t, u, v;
-                    if (tri_intersect(tr, o, d, tmax, t, u, v)) {
-                        if (is_any) {
-                            if (k != tri) {  // bvh.cuh:243
-                                hu = 1.f;
-                                stop = true;
-                            }
-                        } else {  // bvh.cuh:227-231
-                            tmax = t;
-                            hu = u;
-                            hv = v;
-                            tri = k;
-                        }
-                    }
-                    if (stop) cur = kEntryDone;
-                    else if (count > 1) cur = leaf_ref(k + 1, count - 1);
-                    else if (sp > 0) cur = stack_pop(stack, over, sp, stack_cap);
-                    else cur = kEntryDone;
-                    reps++;
-                } while (reps < kTriPerStep && cur != kEntryDone && cur < 0 && !stop);
+            auto leaf_tri = [](int cur) { return (cur != kEntryDone && cur < 0) ? (~cur) >> 3 : 0; };
+            Tri ta = load_tri(sc.tris, leaf_tri(A.cur));
+            Tri tb = load_tri(sc.tris, leaf_tri(B.cur));
+#pragma unroll
+            for (int rep = 0; rep < kTriPerStep; rep++) {
+                if (a_tri && A.cur != kEntryDone && A.cur < 0) leaf_eval<false>(ta, (~A.cur) >> 3, (~A.cur) & 7, A, stack_a);
+                if (rep + 1 < kTriPerStep) ta = load_tri(sc.tris, leaf_tri(A.cur));
+                if (b_tri && B.cur != kEntryDone && B.cur < 0) leaf_eval<true>(tb, (~B.cur) >> 3, (~B.cur) & 7, B, stack_b);
+                if (rep + 1 < kTriPerStep) tb = load_tri(sc.tris, leaf_tri(B.cur));
             }
-#ifdef RT_TRACE_PROFILE
-            pf[10] += __builtin_readcyclecounter() - pf_tt;
-#endif
         }
         // ---------------- finished rays
-#ifdef RT_TRACE_PROFILE
-        const unsigned long long pf_s2 = __builtin_readcyclecounter();
-#endif
-        const bool fin = trav && cur == kEntryDone;
-        n_deposit += __popcll(__ballot(fin && is_any && hu == 0.f));
-        if (fin) {
-            if (is_any) {
-                if (hu == 0.f && !debug_no_deposit)  // unoccluded: render.cuh:291-293
-                    deposit(fb, ap.fb_fixed, cold[1 * kBlock], mail[6 * kBlock], mail[7 * kBlock], mail[8 * kBlock]);
-                o = mk(mail[0 * kBlock], mail[1 * kBlock], mail[2 * kBlock]);
-                d = mk(mail[3 * kBlock], mail[4 * kBlock], mail[5 * kBlock]);
-                phase = PH_CLOSEST;
-                inv = inv_dir(d);
-                tmax = kFltMax;
-                tri = -1;
-                cur = 0;
-                sp = 0;
-            } else {
-                mail[0 * kBlock] = __int_as_float(tri);
-                mail[1 * kBlock] = hu;
-                mail[2 * kBlock] = hv;
-                mail[3 * kBlock] = d.x;
-                mail[4 * kBlock] = d.y;
-                mail[5 * kBlock] = d.z;
-                phase = PW_POST;
-            }
+        const bool b_fin = b_on && B.cur == kEntryDone;
+        n_deposit += __popcll(__ballot(b_fin && B.hu == 0.f));
+        if (b_fin) {
+            if (B.hu == 0.f && !debug_no_deposit) deposit(fb, ap.fb_fixed, b_pixel, b_L.x, b_L.y, b_L.z);  // render.cuh:291-293
+            b_on = false;
         }
-#ifdef RT_TRACE_PROFILE
-        pf[15] += __builtin_readcyclecounter() - pf_s2;
-#endif
+        if (a_trav && A.cur == kEntryDone) phase = PH_ADV;  // (A.tri, A.hu, A.hv, A.d) carry the hit to the ADV block
     }
 #ifdef RT_TRACE_PROFILE
     if (prof && lane_id() == 0)
-        { pf[11] = __builtin_readcyclecounter() - pf_t0; for (int k = 0; k < 16; k++) atomicAdd(&prof[k], pf[k]); }
+        for (int k = 0; k < 16; k++) atomicAdd(&prof[k], pf[k]);
 #endif
     unsigned long long v[C_COUNT] = {n_gen, n_shade, n_traced, n_shadow, n_emit, n_deposit, n_rr, 0ull};
     row_add(rows, v);
@@ -2339,14 +2259,15 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
         const int paths_cap = std::min(8, std::max(1, scene->stack_bound));
         int *d_over2 = nullptr;
         if (ensure_overflow(scene->stack_bound - paths_cap, &d_over2)) return 1;
-        size_t lds_paths = sizeof(int) * (size_t)kBlock * (size_t)(paths_cap + 21) + (lds_tables ? sizeof(float) * kTabDwordsMax : 0);
+        size_t lds_paths = sizeof(int) * (size_t)kBlock * (size_t)(paths_cap + 21) + (lds_tables ? sizeof(float) * (size_t)((scene->tab_dwords + 3) & ~3) : 0);
         bool majority = true;
         if (const char *e = getenv("RT_MAJORITY")) majority = atoi(e) != 0;
         const int dbg = (flags & 0x100u) ? 1 : 0;
         unsigned long long *paths_prof = nullptr;
 #ifdef RT_TRACE_PROFILE
-        HIP_TRY(hipMalloc((void **)&paths_prof, 128));
-        HIP_TRY(hipMemset(paths_prof, 0, 128));
+        const size_t prof_bytes = 128 + 32 * (size_t)(grid_for(n) * (kBlock / 64));
+        HIP_TRY(hipMalloc((void **)&paths_prof, prof_bytes));
+        HIP_TRY(hipMemset(paths_prof, 0, prof_bytes));
 #endif
         // all workgroups resident at once (4 per CU at <= 128 VGPRs), lane count a divisor of n
         int paths_blocks = grid_for(n);
@@ -2362,9 +2283,12 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
         int top_n = 0;
         if (few_blocks) {
             top_n = scene->top_prefix ? std::min(384, std::min(scene->n_nodes, (int)rtbvh::kTopPrefix)) : 0;  // < 64 KB of LDS
-            if (const char *e = getenv("RT_TOP_NODES")) top_n = std::max(0, std::min(top_n, atoi(e)));
+            if (const char *e = getenv("RT_TOP_NODES"))
+                top_n = scene->top_prefix ? std::max(0, std::min(std::min(768, atoi(e)), std::min(scene->n_nodes, (int)rtbvh::kTopPrefix))) : 0;
             lds_paths += (size_t)top_n * 64;
         }
+        int prio_rotate = 8;  // log2 of the priority-rotation period in scheduling decisions; 0 = off
+        if (const char *e = getenv("RT_PRIO_ROTATE")) prio_rotate = atoi(e);
         HIP_TRY(hipEventRecord(c.ev_a, st));
 // MIN_WAVES: 4 waves per SIMD (128 VGPRs, some spills) when the grid fills the chip, 2 (256 VGPRs, no
         // spills) when the shard is so small that only 2 workgroups per CU exist anyway (8-GPU runs)
@@ -2372,37 +2296,25 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
     do {                                                                                                               \
         if (few_blocks)                                                                                                \
             hipLaunchKernelGGL((k_paths<T, WD, MJ, 2>), grid_paths, block, lds_paths, st, sc, c.pools, cam, ap, d_sum,   \
-                               c.d_rows, paths_cap, d_over2, adv_batch, dbg, paths_prof, top_n);                       \
+                               c.d_rows, paths_cap, d_over2, adv_batch, dbg, paths_prof, top_n, prio_rotate);           \
         else                                                                                                           \
             hipLaunchKernelGGL((k_paths<T, WD, MJ, 4>), grid_paths, block, lds_paths, st, sc, c.pools, cam, ap, d_sum,   \
-                               c.d_rows, paths_cap, d_over2, adv_batch, dbg, paths_prof, 0);                           \
+                               c.d_rows, paths_cap, d_over2, adv_batch, dbg, paths_prof, 0, prio_rotate);               \
     } while (0)
-        bool pooled = false;  // ADV served from a workgroup-wide request queue (k_paths_pool)
-        if (const char *e = getenv("RT_POOL")) pooled = atoi(e) != 0;
-        if (pooled) {
-            // 4 workgroups per CU: at most 40 KB each; the traversal stack gets what the fixed columns and the
-            // scene's tables leave (deeper stacks continue in the global overflow area)
-            const size_t lds_fixed = sizeof(int) * (size_t)kBlock * (size_t)(kColdRows + kMailRows + 1) + 8 + 2 * kBlock +
-                                     (lds_tables ? sizeof(float) * (size_t)scene->tab_dwords : 0);
-            int pool_cap = paths_cap;
-            if (!few_blocks) pool_cap = std::max(2, std::min(paths_cap, (int)((40960 - (long)lds_fixed) / (long)(sizeof(int) * kBlock))));
-            if (ensure_overflow(scene->stack_bound - pool_cap, &d_over2)) return 1;
-            const size_t lds_pool = lds_fixed + sizeof(int) * (size_t)kBlock * (size_t)pool_cap;
-            if (const char *e = getenv("RT_ADV_BATCH")) (void)e; else adv_batch = 64;
-#define RT_LAUNCH_POOL(T, WD)                                                                                         \
-    do {                                                                                                               \
-        if (few_blocks)                                                                                                \
-            hipLaunchKernelGGL((k_paths_pool<T, WD, 2>), grid_paths, block, lds_pool, st, sc, c.pools, cam, ap, d_sum,  \
-                               c.d_rows, pool_cap, d_over2, adv_batch, dbg, paths_prof);                               \
-        else                                                                                                           \
-            hipLaunchKernelGGL((k_paths_pool<T, WD, 4>), grid_paths, block, lds_pool, st, sc, c.pools, cam, ap, d_sum,  \
-                               c.d_rows, pool_cap, d_over2, adv_batch, dbg, paths_prof);                               \
-    } while (0)
-            if (lds_tables && scene->wide) RT_LAUNCH_POOL(true, true);
-            else if (lds_tables) RT_LAUNCH_POOL(true, false);
-            else if (scene->wide) RT_LAUNCH_POOL(false, true);
-            else RT_LAUNCH_POOL(false, false);
-#undef RT_LAUNCH_POOL
+        // small shards (<= 2 workgroups per CU): shadow ray and path ray of a slot traced together (k_paths_dual)
+        const int dual_cap = std::max(1, scene->stack_bound);  // both stacks entirely in LDS
+        const size_t lds_dual = sizeof(int) * (size_t)kBlock * (size_t)(2 * dual_cap + 12) +
+                                (lds_tables ? sizeof(float) * (size_t)((scene->tab_dwords + 3) & ~3) : 0);
+        bool dual = few_blocks && !scene->wide && majority && lds_dual <= 80 * 1024;
+        if (const char *e = getenv("RT_DUAL")) dual = dual && atoi(e) != 0;
+        else dual = false;  // measured: 3 % slower than k_paths on the 1/8 shard
+        if (dual) {
+            if (lds_tables)
+                hipLaunchKernelGGL((k_paths_dual<true>), grid_paths, block, lds_dual, st, sc, c.pools, cam, ap, d_sum, c.d_rows,
+                                   dual_cap, adv_batch, dbg, paths_prof);
+            else
+                hipLaunchKernelGGL((k_paths_dual<false>), grid_paths, block, lds_dual, st, sc, c.pools, cam, ap, d_sum, c.d_rows,
+                                   dual_cap, adv_batch, dbg, paths_prof);
         } else if (majority) {
             if (lds_tables && scene->wide) RT_LAUNCH_PATHS(true, true, true);
             else if (lds_tables) RT_LAUNCH_PATHS(true, false, true);
@@ -2423,13 +2335,23 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
         {
             unsigned long long h[16];
             HIP_TRY(hipMemcpy(h, paths_prof, 128, hipMemcpyDeviceToHost));
-            fprintf(stderr, "k_paths cycles: ADV %.1f%% (%.0f / block) node %.1f%% (%.0f) tri %.1f%% (%.0f) rest %.1f%% | idle iterations %llu\n",
+            fprintf(stderr, "k_paths cycles: ADV %.1f%% (%.0f / block) node %.1f%% (%.0f) tri %.1f%% (%.0f) rest %.1f%%\n",
                     100.0 * h[8] / h[11], h[0] ? (double)h[8] / h[0] : 0.0, 100.0 * h[9] / h[11], h[2] ? (double)h[9] / h[2] : 0.0,
-                    100.0 * h[10] / h[11], h[4] ? (double)h[10] / h[4] : 0.0, 100.0 * (double)(h[11] - h[8] - h[9] - h[10]) / h[11], h[12]);
-            fprintf(stderr, "k_paths_pool rest: post+poll %.1f%% decide+claim %.1f%% finish %.1f%%\n", 100.0 * h[13] / h[11], 100.0 * h[14] / h[11], 100.0 * h[15] / h[11]);
+                    100.0 * h[10] / h[11], h[4] ? (double)h[10] / h[4] : 0.0, 100.0 * (double)(h[11] - h[8] - h[9] - h[10]) / h[11]);
+            fprintf(stderr, "k_paths waves: %llu, mean lifetime %.0f cycles, longest %.0f cycles (x%.3f)\n", h[14], (double)h[11] / h[14], (double)h[13],
+                    (double)h[13] * h[14] / h[11]);
             fprintf(stderr, "k_paths profile: ADV blocks %llu avg lanes %.1f | node steps %llu avg lanes %.1f (ADV-waiting %.1f) | tri steps %llu avg lanes %.1f (ADV-waiting %.1f)\n",
                     h[0], h[0] ? (double)h[1] / h[0] : 0.0, h[2], h[2] ? (double)h[3] / h[2] : 0.0, h[2] ? (double)h[6] / h[2] : 0.0, h[4],
                     h[4] ? (double)h[5] / h[4] : 0.0, h[4] ? (double)h[7] / h[4] : 0.0);
+            if (const char *dump = getenv("RT_PROF_DUMP")) {  // per-wave records: hw_id xcc_id cycles blocks
+                std::vector<unsigned long long> recs(4 * (size_t)paths_blocks * (kBlock / 64));
+                HIP_TRY(hipMemcpy(recs.data(), paths_prof + 16, recs.size() * 8, hipMemcpyDeviceToHost));
+                if (FILE *f = fopen(dump, "w")) {
+                    for (size_t k = 0; k < recs.size(); k += 4)
+                        fprintf(f, "%zu %llu %llu %llu %llu\n", k / 4, recs[k], recs[k + 1], recs[k + 2], recs[k + 3]);
+                    fclose(f);
+                }
+            }
             (void)hipFree(paths_prof);
         }
 #endif
