@@ -1023,7 +1023,7 @@ template <bool LDS_TABLES, bool WIDE, bool MAJORITY, int MIN_WAVES>
 __global__ void __launch_bounds__(kBlock, MIN_WAVES)
 k_paths(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__ fb, DWaveRow *__restrict__ rows,
         int stack_cap, int *overflow, int adv_batch, int debug_no_deposit, unsigned long long *prof, int top_n,
-        int prio_period) {
+        int prio_period, int rot_wave, int rot_set) {
     extern __shared__ int s_lds[];
     int *stack = s_lds + threadIdx.x;
     float *park = (float *)(s_lds + stack_cap * kBlock) + threadIdx.x;  // element k at park[k * kBlock]
@@ -1045,7 +1045,24 @@ k_paths(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__ f
     // frame, one after the other: with G dividing the slot count every lane gets the same number of
     // slots, so all lanes -- and all workgroups, which are all resident -- finish together.
     const int lanes_in_grid = (int)(gridDim.x * blockDim.x);
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    // Which slots.  Slot s works through the pixels (s + g W) / spp, g = 0, 1, ...: a lattice of a few image
+    // columns (every 128th at 1920 x 1080 x 256 spp), the same lattice for slots s and s + 64 * lattice_blocks.
+    // A wave always owns 64 CONSECUTIVE slots (samples of one pixel: coherent primary rays; splitting waves
+    // into quarters was measured and loses more than it balances), but with plain striding the four waves of a
+    // workgroup, the four workgroups of a CU and all successive slot sets of a lane fall on ONE lattice, and
+    // whole CUs differ by +-5 % in work (bunny or no bunny in their columns) -- which the slowest one turns
+    // into frame time.  So the j-th wave of a workgroup is shifted by j quarter periods and the k-th slot set
+    // by k * 5/16 of a period.  A bijection between (set, 64-slot block) and (set, wave).  +6 % at 1 GPU.
+    auto slot_of = [&](int set) {  // (everything recomputed here: nothing of this lives across the main loop)
+        const unsigned lane_in_grid = blockIdx.x * blockDim.x + threadIdx.x;
+        const unsigned wave_in_grid = lane_in_grid >> 6, lane_in_wave = lane_in_grid & 63u;
+        // (the grid is a power of two: W is, shard counts divide it, and the host halves from there)
+        const unsigned b = (wave_in_grid + (wave_in_grid & 3u) * (unsigned)rot_wave + (unsigned)set * (unsigned)rot_set) &
+                           (((unsigned)lanes_in_grid >> 6) - 1u);
+        return set * lanes_in_grid + (int)(b * 64u + lane_in_wave);
+    };
+    int slot_set = 0;
+    int i = slot_of(0);
     // persistent slot state
     int bounces = kDone, pixel = 0, gen = 0;
     Rng rs{0, 0, 0, 0, 0, 0};
@@ -1208,7 +1225,8 @@ k_paths(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__ f
                     store_slot(i);
                     phase = PH_IDLE;
                     tri = -1;
-                    i += lanes_in_grid;
+                    slot_set++;
+                    i = slot_of(slot_set);
                     if (i < ap.n) {
                         load_slot(i);
                         if (bounces != kDone && bounces != kParked) phase = PH_ADV;
@@ -1326,300 +1344,6 @@ k_paths(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__ f
           rec[1] = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // XCC_ID
           rec[2] = pf[11];
           rec[3] = pf[0] + pf[2] + pf[4]; }
-#endif
-    unsigned long long v[C_COUNT] = {n_gen, n_shade, n_traced, n_shadow, n_emit, n_deposit, n_rr, 0ull};
-    row_add(rows, v);
-}
-
-// ============================================================================ k_paths_dual
-// k_paths for SMALL SHARDS (at most 2 workgroups per CU: the 1/8 shard of an 8-GPU render has one slot
-// per lane of half the machine).  There the chip is not short of issue slots but of independent work:
-// with 2 waves per SIMD a node step costs what its memory round trip costs.  A slot that has just been
-// shaded has TWO rays -- the shadow ray of its next-event estimate and its continuation ray -- and they
-// do not depend on each other: the shadow ray's outcome only decides a deposit.  k_paths traces them one
-// after the other; this kernel gives a lane two traversal contexts and traces them TOGETHER:
-//     A  the slot's path ray   (closest hit -> hit record for the next ADV)
-//     B  the slot's shadow ray (any hit; deposits when unoccluded, then the context is free)
-// Both contexts' node (triangle) records are fetched before either is evaluated, so a lane has two
-// memory round trips in flight and a slot-round takes max(A, B) instead of A + B.  The next ADV of a
-// slot waits for both.  Same estimator, same RNG streams, same sums: which lane-context traces a ray
-// does not enter the arithmetic.  2-wide records only; no register pressure (2 waves/SIMD: 256 VGPRs).
-// LDS layout: [stack A: cap x 256][stack B: cap x 256][slot state: 12 x 256][tables]
-struct TravCtx {
-    V3 o, d, inv;
-    float tmax, hu, hv;
-    int cur, sp, tri;
-};
-__device__ __forceinline__ void node_fetch_global(const DScene &sc, int cur, float4 (&q)[4]) {
-    const float4 *g = (const float4 *)((const char *)sc.nodes + ((unsigned)cur << 6));
-    q[0] = g[0]; q[1] = g[1]; q[2] = g[2]; q[3] = g[3];
-}
-// the 2-wide branch of inner_step on an already fetched record; the whole stack is in LDS (no overflow
-// area: a global access inside the evaluation would make it wait for the other context's fetch)
-__device__ __forceinline__ void node_eval(const float4 (&q)[4], TravCtx &c, int *stack) {
-    int cl = __float_as_int(q[3].x), cr = __float_as_int(q[3].y);
-    float el, er;
-    bool hl = box_hit(c.o, c.inv, q[0].x, q[0].y, q[0].z, q[0].w, q[1].x, q[1].y, c.tmax, el) && cl != kEntryDone;
-    bool hr = box_hit(c.o, c.inv, q[1].z, q[1].w, q[2].x, q[2].y, q[2].z, q[2].w, c.tmax, er) && cr != kEntryDone;
-    if (hl && hr) {
-        bool left_first = !(el > er);
-        stack[c.sp++ * kBlock] = left_first ? cr : cl;
-        c.cur = left_first ? cl : cr;
-    } else if (hl) {
-        c.cur = cl;
-    } else if (hr) {
-        c.cur = cr;
-    } else if (c.sp > 0) {
-        c.cur = stack[--c.sp * kBlock];
-    } else {
-        c.cur = kEntryDone;
-    }
-}
-// one triangle of the leaf the cursor points at, then advance the cursor (triangle.cuh:39-58; bvh.cuh:222-248)
-template <bool ANY>
-__device__ __forceinline__ void leaf_eval(const Tri &tr, int k, int count, TravCtx &c, int *stack) {
-    float t, u, v;
-    bool stop = false;
-    if (tri_intersect(tr, c.o, c.d, c.tmax, t, u, v)) {
-        if (ANY) {
-            if (k != c.tri) {  // bvh.cuh:243: first accepted hit that is not the excluded triangle
-                c.hu = 1.f;
-                stop = true;
-            }
-        } else {  // bvh.cuh:227-231: later equal-t hit wins (t <= tmax)
-            c.tmax = t;
-            c.hu = u;
-            c.hv = v;
-            c.tri = k;
-        }
-    }
-    if (stop) c.cur = kEntryDone;
-    else if (count > 1) c.cur = leaf_ref(k + 1, count - 1);
-    else if (c.sp > 0) c.cur = stack[--c.sp * kBlock];
-    else c.cur = kEntryDone;
-}
-
-template <bool LDS_TABLES>
-__global__ void __launch_bounds__(kBlock, 2)
-k_paths_dual(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__ fb, DWaveRow *__restrict__ rows,
-             int stack_cap, int adv_batch, int debug_no_deposit, unsigned long long *prof) {
-    extern __shared__ int s_lds[];
-    int *stack_a = s_lds + threadIdx.x;
-    int *stack_b = s_lds + stack_cap * kBlock + threadIdx.x;
-    int *cold = s_lds + 2 * stack_cap * kBlock + threadIdx.x;  // element k at cold[k * kBlock]
-    float *s_tab = (float *)(s_lds + (2 * stack_cap + 12) * kBlock);
-    const float *tab = sc.tables;
-    if (LDS_TABLES) {
-        for (int k = threadIdx.x; k < sc.tab_dwords; k += kBlock) s_tab[k] = sc.tables[k];
-        tab = s_tab;
-        __syncthreads();
-    }
-    const int lanes_in_grid = (int)(gridDim.x * blockDim.x);
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    int bounces = kDone, pixel = 0, gen = 0;
-    Rng rs{0, 0, 0, 0, 0, 0};
-    V3 beta = mk(0, 0, 0);
-    auto load_slot = [&](int k) {
-        bounces = p.bounces(k);
-        pixel = p.pixel(k);
-        gen = p.gen(k);
-        rs = Rng{p.rd(k), p.r0(k), p.r1(k), p.r2(k), p.r3(k), p.r4(k)};
-        beta = mk(p.br(k), p.bg(k), p.bb(k));
-    };
-    auto store_slot = [&](int k) {
-        p.bounces(k) = bounces;
-        p.pixel(k) = pixel;
-        p.gen(k) = gen;
-        p.hit_info(k) = -1;
-        p.stmax(k) = -1.f;
-        p.br(k) = beta.x;
-        p.bg(k) = beta.y;
-        p.bb(k) = beta.z;
-        p.rd(k) = rs.d;
-        p.r0(k) = rs.v0;
-        p.r1(k) = rs.v1;
-        p.r2(k) = rs.v2;
-        p.r3(k) = rs.v3;
-        p.r4(k) = rs.v4;
-    };
-    auto cold_save = [&]() {
-        cold[0 * kBlock] = bounces;
-        cold[1 * kBlock] = pixel;
-        cold[2 * kBlock] = gen;
-        cold[3 * kBlock] = (int)rs.d;
-        cold[4 * kBlock] = (int)rs.v0;
-        cold[5 * kBlock] = (int)rs.v1;
-        cold[6 * kBlock] = (int)rs.v2;
-        cold[7 * kBlock] = (int)rs.v3;
-        cold[8 * kBlock] = (int)rs.v4;
-        cold[9 * kBlock] = __float_as_int(beta.x);
-        cold[10 * kBlock] = __float_as_int(beta.y);
-        cold[11 * kBlock] = __float_as_int(beta.z);
-    };
-    auto cold_load = [&]() {
-        bounces = cold[0 * kBlock];
-        pixel = cold[1 * kBlock];
-        gen = cold[2 * kBlock];
-        rs = Rng{(uint32_t)cold[3 * kBlock], (uint32_t)cold[4 * kBlock], (uint32_t)cold[5 * kBlock],
-                 (uint32_t)cold[6 * kBlock], (uint32_t)cold[7 * kBlock], (uint32_t)cold[8 * kBlock]};
-        beta = mk(__int_as_float(cold[9 * kBlock]), __int_as_float(cold[10 * kBlock]), __int_as_float(cold[11 * kBlock]));
-    };
-    // A: PH_CLOSEST while tracing, PH_ADV when its hit record waits for the ADV block, PH_IDLE when out of slots.
-    // B: active while b_on.  (A.tri, A.hu, A.hv, A.d) are the hit record between the end of A's trace and ADV.
-    int phase = PH_IDLE;
-    TravCtx A{mk(0, 0, 0), mk(0, 0, 0), mk(0, 0, 0), 0.f, 0.f, 0.f, kEntryDone, 0, -1};
-    TravCtx B = A;
-    bool b_on = false;
-    V3 b_L = mk(0, 0, 0);  // radiance the shadow ray deposits if unoccluded, and where
-    int b_pixel = 0;
-    if (i < ap.n) {
-        load_slot(i);
-        phase = (bounces != kDone && bounces != kParked) ? PH_ADV : PH_IDLE;
-        cold_save();
-    }
-    unsigned long long n_gen = 0, n_shade = 0, n_traced = 0, n_shadow = 0, n_emit = 0, n_deposit = 0, n_rr = 0;
-#ifdef RT_TRACE_PROFILE
-    unsigned long long pf[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#endif
-
-    while (true) {
-        const bool a_trav = phase == PH_CLOSEST;
-        const bool a_node = a_trav && A.cur >= 0;
-        const bool a_tri = a_trav && A.cur != kEntryDone && A.cur < 0;
-        const bool b_node = b_on && B.cur >= 0;
-        const bool b_tri = b_on && B.cur != kEntryDone && B.cur < 0;
-        const bool adv_ready = phase == PH_ADV && !b_on;
-        const int n_adv = __popcll(__ballot(adv_ready));
-        const int n_node = __popcll(__ballot(a_node || b_node));
-        const int n_tri = __popcll(__ballot(a_tri || b_tri));
-        if (n_adv + n_node + n_tri == 0) break;
-        const bool run_adv = n_adv > 0 && ((n_adv >= adv_batch && n_adv >= n_node && n_adv >= n_tri) || n_node + n_tri == 0);
-        if (run_adv) {
-#ifdef RT_TRACE_PROFILE
-            pf[0]++; pf[1] += n_adv;
-#endif
-            AdvanceOut out;
-            out.did_gen = out.did_shade = out.has_shadow = out.did_emit = out.new_ray = false;
-            out.rr_draws = 0;
-            if (adv_ready) {
-                cold_load();
-                SlotState st;
-                st.bounces = bounces;
-                st.pixel = pixel;
-                st.gen = gen;
-                st.rs = rs;
-                st.beta = beta;
-                st.wo = A.d;
-                st.hit_info = -1;
-                st.isect_p = st.isect_n = mk(0, 0, 0);
-                if (A.tri >= 0) {  // hit record in the form mat() consumes (render.cuh:152-153, 311-316)
-                    Tri tr = load_tri(sc.tris, A.tri);
-                    int2 ml = sc.tri_info[(unsigned)A.tri];
-                    st.isect_p = tri_point(tr, A.hu, A.hv);
-                    st.isect_n = neg(unit(tr.n));
-                    st.hit_info = (ml.x & 0xffff) | ((ml.y + 1) << 16);
-                }
-                advance_core(sc, tab, cam, ap, ap.slot_lo + i, st, out, fb);
-                bounces = st.bounces;
-                pixel = st.pixel;
-                gen = st.gen;
-                rs = st.rs;
-                beta = st.beta;
-                if (out.has_shadow) {
-                    B.o = out.s_o;
-                    B.d = out.s_d;
-                    B.inv = inv_dir(out.s_d);
-                    B.tmax = out.s_tmax;
-                    B.tri = out.s_target;
-                    B.hu = 0.f;
-                    B.cur = 0;
-                    B.sp = 0;
-                    b_L = out.s_L;
-                    b_pixel = pixel;
-                    b_on = true;
-                }
-                if (out.new_ray) {
-                    A.o = out.ray_o;
-                    A.d = out.ray_d;
-                    A.inv = inv_dir(out.ray_d);
-                    A.tmax = kFltMax;
-                    A.tri = -1;
-                    A.cur = 0;
-                    A.sp = 0;
-                    phase = PH_CLOSEST;
-                } else {
-                    // out of camera rays (or parked for the lockstep final generation): next slot of this lane
-                    store_slot(i);
-                    phase = PH_IDLE;
-                    A.tri = -1;
-                    i += lanes_in_grid;
-                    if (i < ap.n) {
-                        load_slot(i);
-                        if (bounces != kDone && bounces != kParked) phase = PH_ADV;
-                        else i = ap.n;
-                    }
-                }
-                if (phase != PH_IDLE) cold_save();
-            }
-            n_gen += __popcll(__ballot(out.did_gen));
-            n_shade += __popcll(__ballot(out.did_shade));
-            n_traced += __popcll(__ballot(out.new_ray));
-            n_shadow += __popcll(__ballot(out.has_shadow));
-            n_emit += __popcll(__ballot(out.did_emit));
-            int rr = out.rr_draws;
-            if (__ballot(rr != 0)) {
-                for (int off = 32; off > 0; off >>= 1) rr += __shfl_xor(rr, off);
-                n_rr += (unsigned long long)rr;
-            }
-            continue;
-        }
-        // ---------------- node steps: both contexts' records are in flight before either is evaluated
-        if (n_node > 0 && n_node >= n_tri) {
-#ifdef RT_TRACE_PROFILE
-            pf[2]++; pf[3] += __popcll(__ballot(a_node)); pf[6] += __popcll(__ballot(b_node));
-#endif
-            // Software pipeline over the two contexts, straight-line (every lane fetches, from record 0 when it
-            // has nothing to visit, so that the waits the compiler inserts are exact): while A's record is
-            // evaluated B's is in flight, and A's next record is requested before B's evaluation starts.
-            float4 qa[4], qb[4];
-            node_fetch_global(sc, max(A.cur, 0), qa);
-            node_fetch_global(sc, max(B.cur, 0), qb);
-#pragma unroll
-            for (int rep = 0; rep < kNodePerStep; rep++) {
-                if (a_node && A.cur >= 0) node_eval(qa, A, stack_a);
-                if (rep + 1 < kNodePerStep) node_fetch_global(sc, max(A.cur, 0), qa);
-                if (b_node && B.cur >= 0) node_eval(qb, B, stack_b);
-                if (rep + 1 < kNodePerStep) node_fetch_global(sc, max(B.cur, 0), qb);
-            }
-        }
-        // ---------------- triangle tests
-        if (n_tri > 0 && n_tri > n_node) {
-#ifdef RT_TRACE_PROFILE
-            pf[4]++; pf[5] += __popcll(__ballot(a_tri)); pf[7] += __popcll(__ballot(b_tri));
-#endif
-            auto leaf_tri = [](int cur) { return (cur != kEntryDone && cur < 0) ? (~cur) >> 3 : 0; };
-            Tri ta = load_tri(sc.tris, leaf_tri(A.cur));
-            Tri tb = load_tri(sc.tris, leaf_tri(B.cur));
-#pragma unroll
-            for (int rep = 0; rep < kTriPerStep; rep++) {
-                if (a_tri && A.cur != kEntryDone && A.cur < 0) leaf_eval<false>(ta, (~A.cur) >> 3, (~A.cur) & 7, A, stack_a);
-                if (rep + 1 < kTriPerStep) ta = load_tri(sc.tris, leaf_tri(A.cur));
-                if (b_tri && B.cur != kEntryDone && B.cur < 0) leaf_eval<true>(tb, (~B.cur) >> 3, (~B.cur) & 7, B, stack_b);
-                if (rep + 1 < kTriPerStep) tb = load_tri(sc.tris, leaf_tri(B.cur));
-            }
-        }
-        // ---------------- finished rays
-        const bool b_fin = b_on && B.cur == kEntryDone;
-        n_deposit += __popcll(__ballot(b_fin && B.hu == 0.f));
-        if (b_fin) {
-            if (B.hu == 0.f && !debug_no_deposit) deposit(fb, ap.fb_fixed, b_pixel, b_L.x, b_L.y, b_L.z);  // render.cuh:291-293
-            b_on = false;
-        }
-        if (a_trav && A.cur == kEntryDone) phase = PH_ADV;  // (A.tri, A.hu, A.hv, A.d) carry the hit to the ADV block
-    }
-#ifdef RT_TRACE_PROFILE
-    if (prof && lane_id() == 0)
-        for (int k = 0; k < 16; k++) atomicAdd(&prof[k], pf[k]);
 #endif
     unsigned long long v[C_COUNT] = {n_gen, n_shade, n_traced, n_shadow, n_emit, n_deposit, n_rr, 0ull};
     row_add(rows, v);
@@ -2288,6 +2012,24 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
             lds_paths += (size_t)top_n * 64;
         }
         int prio_rotate = 8;  // log2 of the priority-rotation period in scheduling decisions; 0 = off
+        // period, in 64-slot blocks, after which slots repeat the same pixel-column lattice (see k_paths)
+        int rot_wave = 0, rot_set = 0;
+        {
+            long long period = 0;
+            if (spp % 64 == 0 && kW % spp == 0) {
+                const long long step = (kW / spp) % width;  // columns a slot moves per generation
+                long long a = step, b = width;
+                while (b) { long long t = a % b; a = b; b = t; }
+                period = a * (spp / 64);  // gcd(step, width) columns x blocks per pixel
+            }
+            const int waves = paths_blocks * (kBlock / 64);
+            if (period < 16 || period > waves) period = std::max(16, waves / 8);
+            rot_wave = (int)(period / 4);                // measured best on the bunny scenes: 128 / 160 blocks
+            rot_set = (int)(period / 4 + period / 16);
+            if (const char *e = getenv("RT_ROT_WAVE")) rot_wave = atoi(e);
+            if (const char *e = getenv("RT_ROT_SET")) rot_set = atoi(e);
+            rot_wave &= ~3;  // keeps wave j of a workgroup on blocks = j (mod 4): the map stays a bijection
+        }
         if (const char *e = getenv("RT_PRIO_ROTATE")) prio_rotate = atoi(e);
         HIP_TRY(hipEventRecord(c.ev_a, st));
 // MIN_WAVES: 4 waves per SIMD (128 VGPRs, some spills) when the grid fills the chip, 2 (256 VGPRs, no
@@ -2296,26 +2038,12 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
     do {                                                                                                               \
         if (few_blocks)                                                                                                \
             hipLaunchKernelGGL((k_paths<T, WD, MJ, 2>), grid_paths, block, lds_paths, st, sc, c.pools, cam, ap, d_sum,   \
-                               c.d_rows, paths_cap, d_over2, adv_batch, dbg, paths_prof, top_n, prio_rotate);           \
+                               c.d_rows, paths_cap, d_over2, adv_batch, dbg, paths_prof, top_n, prio_rotate, rot_wave, rot_set); \
         else                                                                                                           \
             hipLaunchKernelGGL((k_paths<T, WD, MJ, 4>), grid_paths, block, lds_paths, st, sc, c.pools, cam, ap, d_sum,   \
-                               c.d_rows, paths_cap, d_over2, adv_batch, dbg, paths_prof, 0, prio_rotate);               \
+                               c.d_rows, paths_cap, d_over2, adv_batch, dbg, paths_prof, 0, prio_rotate, rot_wave, rot_set);     \
     } while (0)
-        // small shards (<= 2 workgroups per CU): shadow ray and path ray of a slot traced together (k_paths_dual)
-        const int dual_cap = std::max(1, scene->stack_bound);  // both stacks entirely in LDS
-        const size_t lds_dual = sizeof(int) * (size_t)kBlock * (size_t)(2 * dual_cap + 12) +
-                                (lds_tables ? sizeof(float) * (size_t)((scene->tab_dwords + 3) & ~3) : 0);
-        bool dual = few_blocks && !scene->wide && majority && lds_dual <= 80 * 1024;
-        if (const char *e = getenv("RT_DUAL")) dual = dual && atoi(e) != 0;
-        else dual = false;  // measured: 3 % slower than k_paths on the 1/8 shard
-        if (dual) {
-            if (lds_tables)
-                hipLaunchKernelGGL((k_paths_dual<true>), grid_paths, block, lds_dual, st, sc, c.pools, cam, ap, d_sum, c.d_rows,
-                                   dual_cap, adv_batch, dbg, paths_prof);
-            else
-                hipLaunchKernelGGL((k_paths_dual<false>), grid_paths, block, lds_dual, st, sc, c.pools, cam, ap, d_sum, c.d_rows,
-                                   dual_cap, adv_batch, dbg, paths_prof);
-        } else if (majority) {
+        if (majority) {
             if (lds_tables && scene->wide) RT_LAUNCH_PATHS(true, true, true);
             else if (lds_tables) RT_LAUNCH_PATHS(true, false, true);
             else if (scene->wide) RT_LAUNCH_PATHS(false, true, true);
