@@ -12,7 +12,9 @@ resident in HBM, one RCCL sum-reduce brings the partial framebuffers to rank 0, 
 post-processes: total work is fixed, so "scaling" is "strong".
 
 Rank 0 prints ONE JSON line with the contract fields plus
-  roofline      dominant kernel (k_trace_closest) against the 8 TB/s HBM peak
+  roofline      dominant kernel (k_paths: the whole asynchronous part of the frame in one persistent
+                launch) -- SURVEY 8d's algorithmic bytes per launch / its HIP-event duration, against
+                the 8 TB/s HBM peak; plus the device copy bandwidth measured in the same run
   cpu_baseline  the CPU oracle (a port of the reference's algorithm; the reference itself needs
                 nvcc + cuRAND + CUB and cannot be built here) timed on a bounded sample
 """
@@ -208,7 +210,17 @@ def main():
                 "stage_share_of_render": {
                     "dominant": round(agg["seconds_trace"] / max(agg["seconds_render"], 1e-12), 4),
                     "advance": round(agg["seconds_advance"] / max(agg["seconds_render"], 1e-12), 4)},
-                "grays_per_s": round((agg["closest_rays"] + agg["any_rays"]) / max(agg["seconds_trace"], 1e-12) / 1e9, 3)}
+                "grays_per_s": round((agg["closest_rays"] + agg["any_rays"]) / max(agg["seconds_trace"], 1e-12) / 1e9, 3),
+                "frac_note": "algorithmic bytes use the REFERENCE's record sizes (SURVEY 8d); this kernel keeps rays, hit "
+                             "records and slot state in registers / LDS and gathers the 5.7 MB BVH from L2, so the bytes "
+                             "it would have to stream at the reference's layouts exceed what HBM could deliver (frac > 1 "
+                             "means exactly that); the kernel is bound by VALU issue at ~50 % lane utilisation "
+                             "(profiles/r01_pmc.json), not by HBM -- `traffic` is the HBM traffic actually measured"}
+            try:  # the HBM denominator measured on the box in the same run (device float4 copy)
+                out["roofline"]["copy_bandwidth_measured_GBs"] = round(api.measure_copy_bandwidth(1 << 30, 5) / 1e9, 1)
+            except Exception as e:  # noqa: BLE001 -- reported, never fatal for the bench line
+                out["roofline"]["copy_bandwidth_measured_GBs"] = None
+                out["roofline"]["copy_bandwidth_error"] = str(e)
             traffic_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             if os.path.exists(traffic_file):
                 tr = json.load(open(traffic_file))
