@@ -642,6 +642,7 @@ __device__ __forceinline__ bool box_hit(V3 o, V3 inv, float lox, float loy, floa
     return t_in <= t_out && t_out >= 0.f && t_in <= tmax;
 }
 
+typedef float v2f __attribute__((ext_vector_type(2)));  // packed fp32 (v_pk_*_f32 on gfx950)
 constexpr int kEntryDone = (int)0x80000000;  // "nothing left to visit" marker for a lane (== rtbvh::kNoChild)
 // Traversal stack: the first `cap` entries of a lane live in its LDS column, deeper ones (rare: the
 // bound is 3 per tree level, the typical depth under 10) in a per-lane column of a global overflow
@@ -687,11 +688,23 @@ __device__ __forceinline__ void inner_step(const DScene &sc, V3 o, V3 inv, float
         q3 = q[3];
     }
     if (!WIDE) {
-        // 2-wide record: two exact boxes, near child first, far child onto the stack
+        // 2-wide record: two exact boxes, near child first, far child onto the stack.  The bounds of the two
+        // children are interleaved (rt_scene_create), so the 12 subtractions and 12 multiplications of the
+        // slab test are 6 + 6 packed operations; each component is rounded exactly as in box_hit.
         int cl = __float_as_int(q3.x), cr = __float_as_int(q3.y);
-        float el, er;
-        bool hl = box_hit(o, inv, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tmax, el) && cl != kEntryDone;
-        bool hr = box_hit(o, inv, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tmax, er) && cr != kEntryDone;
+        const v2f ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z};
+        const v2f ix = {inv.x, inv.x}, iy = {inv.y, inv.y}, iz = {inv.z, inv.z};
+        v2f ax = v2f{q0.x, q0.y} - ox, ay = v2f{q0.z, q0.w} - oy, az = v2f{q1.x, q1.y} - oz;
+        v2f bx = v2f{q1.z, q1.w} - ox, by = v2f{q2.x, q2.y} - oy, bz = v2f{q2.z, q2.w} - oz;
+        ax = ax * ix; ay = ay * iy; az = az * iz;
+        bx = bx * ix; by = by * iy; bz = bz * iz;
+        const float el = fmaxf(fmaxf(fminf(ax.x, bx.x), fminf(ay.x, by.x)), fminf(az.x, bz.x));
+        const float er = fmaxf(fmaxf(fminf(ax.y, bx.y), fminf(ay.y, by.y)), fminf(az.y, bz.y));
+        v2f t_out = {fminf(fminf(fmaxf(ax.x, bx.x), fmaxf(ay.x, by.x)), fmaxf(az.x, bz.x)),
+                     fminf(fminf(fmaxf(ax.y, bx.y), fmaxf(ay.y, by.y)), fmaxf(az.y, bz.y))};
+        t_out = t_out * v2f{1.0000004f, 1.0000004f};
+        bool hl = el <= t_out.x && t_out.x >= 0.f && el <= tmax && cl != kEntryDone;
+        bool hr = er <= t_out.y && t_out.y >= 0.f && er <= tmax && cr != kEntryDone;
         if (hl && hr) {
             bool left_first = !(el > er);
             stack_push(stack, over, sp, stack_cap, left_first ? cr : cl);
@@ -2365,7 +2378,27 @@ int rt_scene_create(const float *tri_p0p1p2, int n_tris, const int32_t *tri_mate
     static_assert(sizeof(Material) == sizeof(rt_material), "material layout");
     static_assert(sizeof(Camera) == sizeof(rt_camera), "camera layout");
     {
-        const void *src = sc->wide ? (const void *)bvh.nodes.data() : (const void *)bvh.pairs.data();
+        // device layout of a 2-wide record: the two children's bounds INTERLEAVED --
+        //   (l.lo.x, r.lo.x, l.lo.y, r.lo.y | l.lo.z, r.lo.z, l.hi.x, r.hi.x | l.hi.y, r.hi.y, l.hi.z, r.hi.z | llink, rlink, 0, 0)
+        // -- so that every (left, right) pair of bounds arrives in an aligned register pair and the slab
+        // arithmetic of both children runs as packed fp32 (v_pk_add_f32 / v_pk_mul_f32), see inner_step
+        std::vector<float> inter;
+        const void *src = (const void *)bvh.nodes.data();
+        if (!sc->wide) {
+            inter.resize(16 * bvh.pairs.size());
+            for (size_t k = 0; k < bvh.pairs.size(); k++) {
+                const rtbvh::Pair &pr = bvh.pairs[k];
+                float *r = &inter[16 * k];
+                for (int a = 0; a < 6; a++) {
+                    r[2 * a] = pr.lbox[a];
+                    r[2 * a + 1] = pr.rbox[a];
+                }
+                memcpy(&r[12], &pr.llink, 4);
+                memcpy(&r[13], &pr.rlink, 4);
+                r[14] = r[15] = 0.f;
+            }
+            src = inter.data();
+        }
         HIP_TRY(hipMalloc((void **)&sc->d_nodes, 64 * (size_t)sc->n_nodes));
         HIP_TRY(hipMemcpy(sc->d_nodes, src, 64 * (size_t)sc->n_nodes, hipMemcpyHostToDevice));
     }
