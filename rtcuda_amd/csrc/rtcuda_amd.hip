@@ -250,6 +250,7 @@ struct AdvanceParams {
     int last_gen;        // index of the final camera-ray generation
     int lockstep;        // 1: final generation, one init() per slot per round (literal reference schedule)
     int fb_fixed;        // framebuffer holds 64-bit fixed-point sums (see deposit())
+    int w_over_spp;      // W / spp when spp divides W (then pixel = gen * w_over_spp + slot / spp: no 64-bit divide), else 0
 };
 
 constexpr int kLdsTable = 64;                   // materials / lights staged in LDS per workgroup
@@ -405,9 +406,12 @@ __device__ __forceinline__ void advance_core(const DScene &sc, const float *tab,
             break;
         }
         st.gen = st.gen + 1;
-        st.pixel = (int)(cid / ap.spp);
-        int px = st.pixel % ap.width;
-        int py = st.pixel / ap.width;
+        // pixel = camera_ray_id / spp (render.cuh:254-256).  cid = gen * W + slot, so when spp divides W the quotient
+        // splits exactly into two 32-bit terms; the general case keeps the 64-bit division.
+        if (ap.w_over_spp) st.pixel = (st.gen - 1) * ap.w_over_spp + (int)((unsigned)slot_global / (unsigned)ap.spp);  // (gen already counts this ray)
+        else st.pixel = (int)(cid / ap.spp);
+        int py = (int)((unsigned)st.pixel / (unsigned)ap.width);  // (both non-negative: the unsigned divide is the cheaper one)
+        int px = st.pixel - py * ap.width;
         float jx = rng_uniform(st.rs);  // x first, then y (Appendix A.7)
         float jy = rng_uniform(st.rs);
         camera_get_ray(cam, (px + jx) / ap.width, (py + jy) / ap.height, out.ray_o, out.ray_d);
@@ -1930,6 +1934,7 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
     ap.batch_mask = 7;
     ap.lockstep = 0;
     ap.fb_fixed = (flags & kFlagFixedFb) ? 1 : 0;
+    ap.w_over_spp = (kW % spp == 0) ? kW / spp : 0;
     const bool lds_tables = scene->n_mats <= kLdsTable && scene->n_lights <= kLdsTable;
 
     hipEvent_t ev_start, ev_stop;
