@@ -349,6 +349,7 @@ struct SlotState {
 };
 struct AdvanceOut {
     bool did_gen, did_shade, has_shadow, did_emit, new_ray;
+    bool wants_gen;             // advance_core<DEFER_GEN = true> only: the slot's next step is gen()
     int rr_draws;
     V3 ray_o, ray_d;            // next path ray (valid when new_ray)
     V3 s_o, s_d, s_L;           // shadow ray + radiance to deposit if unoccluded (valid when has_shadow)
@@ -356,12 +357,42 @@ struct AdvanceOut {
     int s_target;
 };
 
+// gen() (render.cuh:250-275) for one slot.  Camera ray id = generation * W + slot (see file header).  Leaves
+// st.bounces = kDone (no camera ray left) / kParked (the final generation runs in lockstep) or a new path.
+__device__ __forceinline__ void gen_core(const Camera &cam, const AdvanceParams &ap, int slot_global, SlotState &st,
+                                         AdvanceOut &out) {
+    long long cid = (long long)st.gen * kW + slot_global;
+    if (cid >= ap.cam_end) {
+        st.bounces = kDone;
+        return;
+    }
+    if (!ap.lockstep && st.gen == ap.last_gen) {
+        st.bounces = kParked;
+        return;
+    }
+    st.gen = st.gen + 1;
+    // pixel = camera_ray_id / spp (render.cuh:254-256).  cid = gen * W + slot, so when spp divides W the quotient
+    // splits exactly into two 32-bit terms; the general case keeps the 64-bit division.
+    if (ap.w_over_spp) st.pixel = (st.gen - 1) * ap.w_over_spp + (int)((unsigned)slot_global / (unsigned)ap.spp);  // (gen already counts this ray)
+    else st.pixel = (int)(cid / ap.spp);
+    int py = (int)((unsigned)st.pixel / (unsigned)ap.width);  // (both non-negative: the unsigned divide is the cheaper one)
+    int px = st.pixel - py * ap.width;
+    float jx = rng_uniform(st.rs);  // x first, then y (Appendix A.7)
+    float jy = rng_uniform(st.rs);
+    camera_get_ray(cam, (px + jx) / ap.width, (py + jy) / ap.height, out.ray_o, out.ray_d);
+    out.new_ray = true;
+    st.bounces = 0;
+    st.beta = mk(1.f, 1.f, 1.f);
+    out.did_gen = true;
+}
+
+template <bool DEFER_GEN>
 __device__ __forceinline__ void advance_core(const DScene &sc, const float *tab, const Camera &cam,
                                              const AdvanceParams &ap, int slot_global, SlotState &st, AdvanceOut &out,
                                              float *__restrict__ fb) {
     const int off_ltri = tab_off_ltri(sc.num_mats, sc.num_lights);
     const int off_lpre = tab_off_lpre(sc.num_mats, sc.num_lights);
-    out.did_gen = out.did_shade = out.has_shadow = out.did_emit = out.new_ray = false;
+    out.did_gen = out.did_shade = out.has_shadow = out.did_emit = out.new_ray = out.wants_gen = false;
     out.rr_draws = 0;
     const bool hit = st.hit_info >= 0;
     const int light_of_hit = hit ? ((st.hit_info >> 16) & 0xffff) - 1 : -1;
@@ -395,30 +426,12 @@ __device__ __forceinline__ void advance_core(const DScene &sc, const float *tab,
             if (!hit) st.bounces = ap.max_bounces;     // idle iterations consume nothing: skip them
             continue;
         }
-        // ---- gen() :250-275.  Camera ray id = generation * W + slot (see file header).
-        long long cid = (long long)st.gen * kW + slot_global;
-        if (cid >= ap.cam_end) {
-            st.bounces = kDone;
-            break;
+        // ---- gen() :250-275
+        if (DEFER_GEN) {  // k_paths: camera rays are generated by the (much shorter) GEN block
+            out.wants_gen = true;
+            return;
         }
-        if (!ap.lockstep && st.gen == ap.last_gen) {
-            st.bounces = kParked;
-            break;
-        }
-        st.gen = st.gen + 1;
-        // pixel = camera_ray_id / spp (render.cuh:254-256).  cid = gen * W + slot, so when spp divides W the quotient
-        // splits exactly into two 32-bit terms; the general case keeps the 64-bit division.
-        if (ap.w_over_spp) st.pixel = (st.gen - 1) * ap.w_over_spp + (int)((unsigned)slot_global / (unsigned)ap.spp);  // (gen already counts this ray)
-        else st.pixel = (int)(cid / ap.spp);
-        int py = (int)((unsigned)st.pixel / (unsigned)ap.width);  // (both non-negative: the unsigned divide is the cheaper one)
-        int px = st.pixel - py * ap.width;
-        float jx = rng_uniform(st.rs);  // x first, then y (Appendix A.7)
-        float jy = rng_uniform(st.rs);
-        camera_get_ray(cam, (px + jx) / ap.width, (py + jy) / ap.height, out.ray_o, out.ray_d);
-        out.new_ray = true;
-        st.bounces = 0;
-        st.beta = mk(1.f, 1.f, 1.f);
-        out.did_gen = true;
+        gen_core(cam, ap, slot_global, st, out);
         break;
     }
     if (!out.did_shade) return;
@@ -541,7 +554,7 @@ k_advance(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__
     out.rr_draws = 0;
     if (alive) {
         const int gen_before = st.gen;
-        advance_core(sc, tab, cam, ap, ap.slot_lo + i, st, out, fb);
+        advance_core<false>(sc, tab, cam, ap, ap.slot_lo + i, st, out, fb);
         if (out.new_ray) {
             p.ox(i) = out.ray_o.x;
             p.oy(i) = out.ray_o.y;
@@ -1008,7 +1021,8 @@ __global__ void __launch_bounds__(kBlock, 8) k_trace(DScene sc, DPools p, TraceP
 // ============================================================================ k_paths
 // The whole asynchronous part of a frame in ONE launch.  A lane owns one path slot for the entire
 // render and keeps its state in registers; the reference's stage kernels become PHASES of the lane:
-//     ADV      init() + mat() + gen()        (advance_core)
+//     ADV      init() + mat()                (advance_core; + gen() on small shards)
+//     GEN      gen()                         (gen_core)
 //     ANY      ah():  the slot's shadow ray  (any hit, deposit if unoccluded)
 //     CLOSEST  ch():  the slot's path ray    (closest hit -> hit record for the next ADV)
 // Because a slot never depends on another slot (see the file header) there is no barrier of any
@@ -1017,10 +1031,12 @@ __global__ void __launch_bounds__(kBlock, 8) k_trace(DScene sc, DPools p, TraceP
 // per-round design -- every k_trace launch ended in a drain where a wave waited for its longest
 // ray with ~10 of 64 lanes active, 1 700 times per frame -- together with the per-round state
 // traffic (rays, hit records and shadow rays never leave registers) and 3 400 kernel launches.
-// Divergence between phases is handled by wave-level scheduling: the expensive ADV block runs when
-// at least `adv_batch` lanes wait for it (or nothing else can run), otherwise the wave takes one
-// node step and one leaf step for the lanes that need them.
-enum { PH_ADV = 0, PH_ANY = 1, PH_CLOSEST = 2, PH_IDLE = 3 };
+// Divergence between phases is handled by wave-level scheduling: each iteration the wave issues ONE
+// block for all its lanes -- the expensive ADV block when at least `adv_batch` lanes wait for it (or
+// nothing else can run), the short GEN block (gen() alone, for paths that certainly ended) when
+// `gen_batch` lanes wait for it, otherwise the more popular of a node block (up to 8 node steps) and a
+// triangle block (up to 2 tests).
+enum { PH_ADV = 0, PH_ANY = 1, PH_CLOSEST = 2, PH_IDLE = 3, PH_GEN = 4 };
 #ifndef RT_TRI_PER_STEP
 #define RT_TRI_PER_STEP 2
 #endif
@@ -1040,7 +1056,11 @@ template <bool LDS_TABLES, bool WIDE, bool MAJORITY, int MIN_WAVES>
 __global__ void __launch_bounds__(kBlock, MIN_WAVES)
 k_paths(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__ fb, DWaveRow *__restrict__ rows,
         int stack_cap, int *overflow, int adv_batch, int debug_no_deposit, unsigned long long *prof, int top_n,
-        int prio_period, int rot_wave, int rot_set) {
+        int prio_period, int rot_wave, int rot_set, int gen_batch) {
+    // The GEN block exists where the chip is short of issue slots (4 waves per SIMD): there it takes a third of the
+    // lanes out of the long ADV block (+3 %, and the ADV block no longer spills).  On small shards (2 waves per
+    // SIMD) a slot-round is a latency chain and one more block in it costs 5 %: gen() stays inside ADV there.
+    constexpr bool SPLIT_GEN = MIN_WAVES != 2;
     extern __shared__ int s_lds[];
     int *stack = s_lds + threadIdx.x;
     float *park = (float *)(s_lds + stack_cap * kBlock) + threadIdx.x;  // element k at park[k * kBlock]
@@ -1139,7 +1159,7 @@ k_paths(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__ f
     int cur = kEntryDone, sp = 0, tri = -1;
     if (i < ap.n) {
         load_slot(i);
-        phase = (bounces != kDone && bounces != kParked) ? PH_ADV : PH_IDLE;
+        phase = (bounces != kDone && bounces != kParked) ? (SPLIT_GEN ? PH_GEN : PH_ADV) : PH_IDLE;  // (untouched slots: bounces = INT_MAX)
         cold_save();
     }
     // wave-uniform event counters
@@ -1172,15 +1192,77 @@ k_paths(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__ f
         const bool want_node = trav && cur >= 0;
         const bool want_tri = trav && cur != kEntryDone && cur < 0;
         const int n_adv = __popcll(__ballot(phase == PH_ADV));
+        const int n_genw = __popcll(__ballot(phase == PH_GEN));
         const int n_node = __popcll(__ballot(want_node));
         const int n_tri = __popcll(__ballot(want_tri));
-        if (n_adv + n_node + n_tri == 0) break;
+        if (n_adv + n_genw + n_node + n_tri == 0) break;
         // Every block is issued for the whole wave whatever the number of lanes that need it.  The ADV
         // block is ~15x longer than a node step or a triangle test, so it waits for `adv_batch` lanes
         // unless nothing else can run.  MAJORITY additionally runs only the more popular of the two
         // traversal blocks per iteration (one triangle per lane per iteration).
         bool run_adv = n_adv > 0 && (n_adv >= adv_batch || n_node + n_tri == 0);
         if (MAJORITY) run_adv = n_adv > 0 && ((n_adv >= adv_batch && n_adv >= n_node && n_adv >= n_tri) || n_node + n_tri == 0);
+        // ---------------- GEN block: gen() (render.cuh:250-275) for the lanes whose path certainly ended -- it missed
+        // or ran out of bounces (a third of all ADV work), or the ADV block found it Russian-roulette-killed to the
+        // last bounce.  A tenth of the ADV block's length, so it runs for far fewer waiting lanes.
+        if (SPLIT_GEN && !run_adv && n_genw > 0 && (n_genw >= gen_batch || n_node + n_tri == 0)) {
+#ifdef RT_TRACE_PROFILE
+            pf[12]++; pf[15] += n_genw;
+#endif
+            AdvanceOut out;
+            out.did_gen = out.new_ray = false;
+            if (phase == PH_GEN) {
+                SlotState st;
+                st.gen = cold[2 * kBlock];
+                st.rs = Rng{(uint32_t)cold[3 * kBlock], (uint32_t)cold[4 * kBlock], (uint32_t)cold[5 * kBlock],
+                            (uint32_t)cold[6 * kBlock], (uint32_t)cold[7 * kBlock], (uint32_t)cold[8 * kBlock]};
+                st.bounces = 0;
+                st.pixel = 0;
+                st.beta = mk(0, 0, 0);
+                gen_core(cam, ap, ap.slot_lo + i, st, out);
+                if (out.new_ray) {
+                    o = out.ray_o;
+                    d = out.ray_d;
+                    inv = inv_dir(d);
+                    phase = PH_CLOSEST;
+                    tmax = kFltMax;
+                    tri = -1;
+                    cur = 0;
+                    sp = 0;
+                    bounces = st.bounces;
+                    pixel = st.pixel;
+                    gen = st.gen;
+                    rs = st.rs;
+                    beta = st.beta;
+                    cold_save();
+                } else {
+                    // this slot is out of camera rays (or parked for the lockstep final generation): hand it back
+                    // (beta and pixel are dead there, bounces is the sentinel) and take the lane's next slot
+                    bounces = st.bounces;
+                    pixel = cold[1 * kBlock];
+                    gen = st.gen;
+                    rs = st.rs;
+                    beta = mk(__int_as_float(cold[9 * kBlock]), __int_as_float(cold[10 * kBlock]), __int_as_float(cold[11 * kBlock]));
+                    store_slot(i);
+                    phase = PH_IDLE;
+                    tri = -1;
+                    slot_set++;
+                    i = slot_of(slot_set);
+                    if (i < ap.n) {
+                        load_slot(i);
+                        if (bounces != kDone && bounces != kParked) {
+                            phase = PH_GEN;  // untouched slots start with bounces = INT_MAX: their first step is gen()
+                            cold_save();
+                        } else {
+                            i = ap.n;  // (cannot happen: untouched slots start alive)
+                        }
+                    }
+                }
+            }
+            n_gen += __popcll(__ballot(out.did_gen));
+            n_traced += __popcll(__ballot(out.new_ray));
+            continue;
+        }
         if (run_adv) {
 #ifdef RT_TRACE_PROFILE
             pf[0]++; pf[1] += n_adv;
@@ -1208,7 +1290,7 @@ k_paths(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__ f
                     st.isect_n = neg(unit(tr.n));
                     st.hit_info = (ml.x & 0xffff) | ((ml.y + 1) << 16);
                 }
-                advance_core(sc, tab, cam, ap, ap.slot_lo + i, st, out, fb);
+                advance_core<SPLIT_GEN>(sc, tab, cam, ap, ap.slot_lo + i, st, out, fb);
                 bounces = st.bounces;
                 pixel = st.pixel;
                 gen = st.gen;
@@ -1236,6 +1318,9 @@ k_paths(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__ f
                     phase = PH_CLOSEST;
                     tmax = kFltMax;
                     tri = -1;
+                } else if (SPLIT_GEN) {
+                    phase = PH_GEN;  // out.wants_gen: Russian roulette ended the path (its draws are in rs)
+                    tri = -1;
                 } else {
                     // this slot is out of camera rays (or parked for the lockstep final generation):
                     // hand it back and take the lane's next slot
@@ -1257,7 +1342,7 @@ k_paths(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__ f
                 }
                 if (phase != PH_IDLE) cold_save();
             }
-            n_gen += __popcll(__ballot(out.did_gen));
+            if (!SPLIT_GEN) n_gen += __popcll(__ballot(out.did_gen));
             n_shade += __popcll(__ballot(out.did_shade));
             n_traced += __popcll(__ballot(out.new_ray));
             n_shadow += __popcll(__ballot(out.has_shadow));
@@ -1348,7 +1433,10 @@ k_paths(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__ f
                 cur = 0;
                 sp = 0;
             } else {
-                phase = PH_ADV;  // (tri, hu, hv, d) carry the hit to the ADV block
+                // (tri, hu, hv, d) carry the hit to the ADV block; a path that missed, or has no bounce left (and is not
+                // at bounce 0, where a hit light still emits: render.cuh:98-109), can only generate
+                const int b = cold[0 * kBlock];
+                phase = (SPLIT_GEN && (tri < 0 || (b >= ap.max_bounces && b > 0))) ? PH_GEN : PH_ADV;
             }
         }
     }
@@ -1996,7 +2084,7 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
     if (const char *e = getenv("RT_PERSISTENT")) persistent = atoi(e) != 0;
     float ms_paths = 0.f;
     if (persistent) {
-        int adv_batch = 40;
+        int adv_batch = 30;  // lanes waiting for the ADV block before it runs (measured: flat 28..36)
         if (const char *e = getenv("RT_ADV_BATCH")) adv_batch = std::max(1, std::min(64, atoi(e)));
         const int paths_cap = std::min(8, std::max(1, scene->stack_bound));
         int *d_over2 = nullptr;
@@ -2029,6 +2117,8 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
                 top_n = scene->top_prefix ? std::max(0, std::min(std::min(768, atoi(e)), std::min(scene->n_nodes, (int)rtbvh::kTopPrefix))) : 0;
             lds_paths += (size_t)top_n * 64;
         }
+        int gen_batch = 6;  // lanes waiting for the GEN block before it runs (unless nothing else can); flat 5..8
+        if (const char *e = getenv("RT_GEN_BATCH")) gen_batch = std::max(1, std::min(64, atoi(e)));
         int prio_rotate = 8;  // log2 of the priority-rotation period in scheduling decisions; 0 = off
         // period, in 64-slot blocks, after which slots repeat the same pixel-column lattice (see k_paths)
         int rot_wave = 0, rot_set = 0;
@@ -2056,10 +2146,10 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
     do {                                                                                                               \
         if (few_blocks)                                                                                                \
             hipLaunchKernelGGL((k_paths<T, WD, MJ, 2>), grid_paths, block, lds_paths, st, sc, c.pools, cam, ap, d_sum,   \
-                               c.d_rows, paths_cap, d_over2, adv_batch, dbg, paths_prof, top_n, prio_rotate, rot_wave, rot_set); \
+                               c.d_rows, paths_cap, d_over2, adv_batch, dbg, paths_prof, top_n, prio_rotate, rot_wave, rot_set, gen_batch); \
         else                                                                                                           \
             hipLaunchKernelGGL((k_paths<T, WD, MJ, 4>), grid_paths, block, lds_paths, st, sc, c.pools, cam, ap, d_sum,   \
-                               c.d_rows, paths_cap, d_over2, adv_batch, dbg, paths_prof, 0, prio_rotate, rot_wave, rot_set);     \
+                               c.d_rows, paths_cap, d_over2, adv_batch, dbg, paths_prof, 0, prio_rotate, rot_wave, rot_set, gen_batch);     \
     } while (0)
         if (majority) {
             if (lds_tables && scene->wide) RT_LAUNCH_PATHS(true, true, true);
@@ -2084,6 +2174,7 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
             fprintf(stderr, "k_paths cycles: ADV %.1f%% (%.0f / block) node %.1f%% (%.0f) tri %.1f%% (%.0f) rest %.1f%%\n",
                     100.0 * h[8] / h[11], h[0] ? (double)h[8] / h[0] : 0.0, 100.0 * h[9] / h[11], h[2] ? (double)h[9] / h[2] : 0.0,
                     100.0 * h[10] / h[11], h[4] ? (double)h[10] / h[4] : 0.0, 100.0 * (double)(h[11] - h[8] - h[9] - h[10]) / h[11]);
+            fprintf(stderr, "k_paths GEN blocks: %llu avg lanes %.1f\n", h[12], h[12] ? (double)h[15] / h[12] : 0.0);
             fprintf(stderr, "k_paths waves: %llu, mean lifetime %.0f cycles, longest %.0f cycles (x%.3f)\n", h[14], (double)h[11] / h[14], (double)h[13],
                     (double)h[13] * h[14] / h[11]);
             fprintf(stderr, "k_paths profile: ADV blocks %llu avg lanes %.1f | node steps %llu avg lanes %.1f (ADV-waiting %.1f) | tri steps %llu avg lanes %.1f (ADV-waiting %.1f)\n",
