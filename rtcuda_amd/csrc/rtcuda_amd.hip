@@ -1166,6 +1166,7 @@ k_paths(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__ f
     unsigned long long n_gen = 0, n_shade = 0, n_traced = 0, n_shadow = 0, n_emit = 0, n_deposit = 0, n_rr = 0;
 #ifdef RT_TRACE_PROFILE
     unsigned long long pf[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long pf_gen_cycles = 0;
     const unsigned long long pf_t0 = __builtin_readcyclecounter();
 #endif
 
@@ -1208,6 +1209,7 @@ k_paths(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__ f
         if (SPLIT_GEN && !run_adv && n_genw > 0 && (n_genw >= gen_batch || n_node + n_tri == 0)) {
 #ifdef RT_TRACE_PROFILE
             pf[12]++; pf[15] += n_genw;
+            const unsigned long long pf_tg = __builtin_readcyclecounter();
 #endif
             AdvanceOut out;
             out.did_gen = out.new_ray = false;
@@ -1261,6 +1263,9 @@ k_paths(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__ f
             }
             n_gen += __popcll(__ballot(out.did_gen));
             n_traced += __popcll(__ballot(out.new_ray));
+#ifdef RT_TRACE_PROFILE
+            pf_gen_cycles += __builtin_readcyclecounter() - pf_tg;
+#endif
             continue;
         }
         if (run_adv) {
@@ -1442,9 +1447,9 @@ k_paths(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__ f
     }
 #ifdef RT_TRACE_PROFILE
     if (prof && lane_id() == 0)
-        { pf[11] = __builtin_readcyclecounter() - pf_t0; for (int k = 0; k < 16; k++) atomicAdd(&prof[k], pf[k]); atomicMax(&prof[13], pf[11]); atomicAdd(&prof[14], 1ull);
+        { pf[11] = __builtin_readcyclecounter() - pf_t0; for (int k = 0; k < 16; k++) atomicAdd(&prof[k], pf[k]); atomicMax(&prof[13], pf[11]); atomicAdd(&prof[14], 1ull); atomicAdd(&prof[16], pf_gen_cycles);
           // per-wave record: where it ran and for how long
-          unsigned long long *rec = prof + 16 + 4 * (size_t)((blockIdx.x * kBlock + threadIdx.x) >> 6);
+          unsigned long long *rec = prof + 24 + 4 * (size_t)((blockIdx.x * kBlock + threadIdx.x) >> 6);
           rec[0] = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_ID
           rec[1] = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // XCC_ID
           rec[2] = pf[11];
@@ -2095,7 +2100,7 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
         const int dbg = (flags & 0x100u) ? 1 : 0;
         unsigned long long *paths_prof = nullptr;
 #ifdef RT_TRACE_PROFILE
-        const size_t prof_bytes = 128 + 32 * (size_t)(grid_for(n) * (kBlock / 64));
+        const size_t prof_bytes = 192 + 32 * (size_t)(grid_for(n) * (kBlock / 64));
         HIP_TRY(hipMalloc((void **)&paths_prof, prof_bytes));
         HIP_TRY(hipMemset(paths_prof, 0, prof_bytes));
 #endif
@@ -2169,12 +2174,13 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
         HIP_TRY(hipEventElapsedTime(&ms_paths, c.ev_a, c.ev_b));
 #ifdef RT_TRACE_PROFILE
         {
-            unsigned long long h[16];
-            HIP_TRY(hipMemcpy(h, paths_prof, 128, hipMemcpyDeviceToHost));
+            unsigned long long h[24];
+            HIP_TRY(hipMemcpy(h, paths_prof, 192, hipMemcpyDeviceToHost));
             fprintf(stderr, "k_paths cycles: ADV %.1f%% (%.0f / block) node %.1f%% (%.0f) tri %.1f%% (%.0f) rest %.1f%%\n",
                     100.0 * h[8] / h[11], h[0] ? (double)h[8] / h[0] : 0.0, 100.0 * h[9] / h[11], h[2] ? (double)h[9] / h[2] : 0.0,
                     100.0 * h[10] / h[11], h[4] ? (double)h[10] / h[4] : 0.0, 100.0 * (double)(h[11] - h[8] - h[9] - h[10]) / h[11]);
-            fprintf(stderr, "k_paths GEN blocks: %llu avg lanes %.1f\n", h[12], h[12] ? (double)h[15] / h[12] : 0.0);
+            fprintf(stderr, "k_paths GEN blocks: %llu avg lanes %.1f, %.1f %% of wave time (%.0f cycles / block; inside `rest` above)\n", h[12],
+                    h[12] ? (double)h[15] / h[12] : 0.0, 100.0 * h[16] / h[11], h[12] ? (double)h[16] / h[12] : 0.0);
             fprintf(stderr, "k_paths waves: %llu, mean lifetime %.0f cycles, longest %.0f cycles (x%.3f)\n", h[14], (double)h[11] / h[14], (double)h[13],
                     (double)h[13] * h[14] / h[11]);
             fprintf(stderr, "k_paths profile: ADV blocks %llu avg lanes %.1f | node steps %llu avg lanes %.1f (ADV-waiting %.1f) | tri steps %llu avg lanes %.1f (ADV-waiting %.1f)\n",
@@ -2182,7 +2188,7 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
                     h[4] ? (double)h[5] / h[4] : 0.0, h[4] ? (double)h[7] / h[4] : 0.0);
             if (const char *dump = getenv("RT_PROF_DUMP")) {  // per-wave records: hw_id xcc_id cycles blocks
                 std::vector<unsigned long long> recs(4 * (size_t)paths_blocks * (kBlock / 64));
-                HIP_TRY(hipMemcpy(recs.data(), paths_prof + 16, recs.size() * 8, hipMemcpyDeviceToHost));
+                HIP_TRY(hipMemcpy(recs.data(), paths_prof + 24, recs.size() * 8, hipMemcpyDeviceToHost));
                 if (FILE *f = fopen(dump, "w")) {
                     for (size_t k = 0; k < recs.size(); k += 4)
                         fprintf(f, "%zu %llu %llu %llu %llu\n", k / 4, recs[k], recs[k + 1], recs[k + 2], recs[k + 3]);
