@@ -1459,327 +1459,6 @@ k_paths(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__ f
     row_add(rows, v);
 }
 
-// ============================================================================ k_paths_pair
-// k_paths for SMALL SHARDS (at most 131 072 slots on this GPU: the 1/8 shard of an 8-GPU render).  With one slot
-// per lane such a shard fills only two waves per SIMD, and PMC shows the SIMDs idle half of the time: both
-// waves wait for memory.  Here a slot is served by a PAIR of lanes of one wave, l and l + 32:
-//     lane l       (A)  the slot itself: ADV / GEN, and the path ray   (closest hit)
-//     lane l + 32  (B)  the slot's shadow ray                          (any hit, deposit, idle again)
-// so a wave carries 32 slots, the shard fills FOUR waves per SIMD (twice the latency hiding), and a slot's
-// shadow ray and continuation ray -- which do not depend on each other -- are traced AT THE SAME TIME by the
-// same node / triangle blocks (a lane's ray kind is per-lane state there anyway).  The shadow ray travels from A
-// to B through twelve wave shuffles at the end of the ADV block; A's next ADV waits until B is idle again.
-// Issue slots are what this regime has to spare: the ADV block now runs for at most 32 lanes.
-// Same estimator, same RNG streams, same sums as k_paths; 2-wide records only.
-// LDS layout (dynamic): [stack: stack_cap x kBlock][slot state: 12 x kBlock (A lanes)][tables]
-template <bool LDS_TABLES>
-__global__ void __launch_bounds__(kBlock, 4)
-k_paths_pair(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__ fb, DWaveRow *__restrict__ rows,
-             int stack_cap, int *overflow, int adv_batch, int gen_batch, int debug_no_deposit, int prio_period,
-             int rot_wave, int rot_set) {
-    extern __shared__ int s_lds[];
-    int *stack = s_lds + threadIdx.x;
-    int *over = overflow + (blockIdx.x * kBlock + threadIdx.x) % kOverStride;
-    int *cold = s_lds + stack_cap * kBlock + threadIdx.x;  // element k at cold[k * kBlock]
-    float *s_tab = (float *)(s_lds + (stack_cap + 12) * kBlock);
-    const float *tab = sc.tables;
-    if (LDS_TABLES) {
-        for (int k = threadIdx.x; k < sc.tab_dwords; k += kBlock) s_tab[k] = sc.tables[k];
-        tab = s_tab;
-        __syncthreads();
-    }
-    const unsigned lane = lane_id();
-    const bool is_b = lane >= 32u;
-    const int slots_in_grid = (int)(gridDim.x * blockDim.x) >> 1;  // 32 per wave
-    // the wave's 32 consecutive slots (half of one pixel's samples), spread over the pixel-column lattices as in
-    // k_paths; rot_wave / rot_set are in 32-slot blocks here
-    auto slot_of = [&](int set) {
-        const unsigned wave_in_grid = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-        const unsigned b = (wave_in_grid + (wave_in_grid & 3u) * (unsigned)rot_wave + (unsigned)set * (unsigned)rot_set) &
-                           (((unsigned)slots_in_grid >> 5) - 1u);
-        return set * slots_in_grid + (int)(b * 32u + (lane & 31u));
-    };
-    int slot_set = 0;
-    int i = is_b ? ap.n : slot_of(0);
-    int bounces = kDone, pixel = 0, gen = 0;
-    Rng rs{0, 0, 0, 0, 0, 0};
-    V3 beta = mk(0, 0, 0);
-    auto load_slot = [&](int k) {
-        bounces = p.bounces(k);
-        pixel = p.pixel(k);
-        gen = p.gen(k);
-        rs = Rng{p.rd(k), p.r0(k), p.r1(k), p.r2(k), p.r3(k), p.r4(k)};
-        beta = mk(p.br(k), p.bg(k), p.bb(k));
-    };
-    auto store_slot = [&](int k) {
-        p.bounces(k) = bounces;
-        p.pixel(k) = pixel;
-        p.gen(k) = gen;
-        p.hit_info(k) = -1;
-        p.stmax(k) = -1.f;
-        p.br(k) = beta.x;
-        p.bg(k) = beta.y;
-        p.bb(k) = beta.z;
-        p.rd(k) = rs.d;
-        p.r0(k) = rs.v0;
-        p.r1(k) = rs.v1;
-        p.r2(k) = rs.v2;
-        p.r3(k) = rs.v3;
-        p.r4(k) = rs.v4;
-    };
-    auto cold_save = [&]() {
-        cold[0 * kBlock] = bounces;
-        cold[1 * kBlock] = pixel;
-        cold[2 * kBlock] = gen;
-        cold[3 * kBlock] = (int)rs.d;
-        cold[4 * kBlock] = (int)rs.v0;
-        cold[5 * kBlock] = (int)rs.v1;
-        cold[6 * kBlock] = (int)rs.v2;
-        cold[7 * kBlock] = (int)rs.v3;
-        cold[8 * kBlock] = (int)rs.v4;
-        cold[9 * kBlock] = __float_as_int(beta.x);
-        cold[10 * kBlock] = __float_as_int(beta.y);
-        cold[11 * kBlock] = __float_as_int(beta.z);
-    };
-    auto cold_load = [&]() {
-        bounces = cold[0 * kBlock];
-        pixel = cold[1 * kBlock];
-        gen = cold[2 * kBlock];
-        rs = Rng{(uint32_t)cold[3 * kBlock], (uint32_t)cold[4 * kBlock], (uint32_t)cold[5 * kBlock],
-                 (uint32_t)cold[6 * kBlock], (uint32_t)cold[7 * kBlock], (uint32_t)cold[8 * kBlock]};
-        beta = mk(__int_as_float(cold[9 * kBlock]), __int_as_float(cold[10 * kBlock]), __int_as_float(cold[11 * kBlock]));
-    };
-    // A lanes: PH_GEN / PH_ADV / PH_CLOSEST / PH_IDLE (out of slots).  B lanes: PH_ANY while tracing, else PH_IDLE.
-    int phase = PH_IDLE;
-    V3 o = mk(0, 0, 0), d = mk(0, 0, 0), inv = mk(0, 0, 0);
-    float tmax = 0.f, hu = 0.f, hv = 0.f;
-    int cur = kEntryDone, sp = 0, tri = -1;
-    V3 b_L = mk(0, 0, 0);  // B lanes: what the shadow ray deposits if unoccluded, and where
-    int b_pixel = 0;
-    if (i < ap.n) {
-        load_slot(i);
-        phase = (bounces != kDone && bounces != kParked) ? PH_GEN : PH_IDLE;  // (untouched slots: bounces = INT_MAX)
-        cold_save();
-    }
-    unsigned long long n_gen = 0, n_shade = 0, n_traced = 0, n_shadow = 0, n_emit = 0, n_deposit = 0, n_rr = 0;
-    unsigned prio_tick = 0;
-    const unsigned prio_rank = (4u * blockIdx.x) / gridDim.x;
-
-    while (true) {
-        if (prio_period && (prio_tick++ & ((1u << prio_period) - 1u)) == 0u) {  // see k_paths
-            switch (((prio_tick >> prio_period) + prio_rank) & 3u) {
-                case 0: __builtin_amdgcn_s_setprio(0); break;
-                case 1: __builtin_amdgcn_s_setprio(1); break;
-                case 2: __builtin_amdgcn_s_setprio(2); break;
-                default: __builtin_amdgcn_s_setprio(3); break;
-            }
-        }
-        const bool trav = phase == PH_ANY || phase == PH_CLOSEST;
-        const bool want_node = trav && cur >= 0;
-        const bool want_tri = trav && cur != kEntryDone && cur < 0;
-        // A's ADV may hand a shadow ray to B: it waits until B is idle
-        const unsigned long long b_busy = __ballot(phase == PH_ANY);
-        const bool partner_busy = ((unsigned)(b_busy >> 32) >> (lane & 31u)) & 1u;
-        const bool adv_ready = phase == PH_ADV && !partner_busy;
-        const int n_adv = __popcll(__ballot(adv_ready));
-        const int n_genw = __popcll(__ballot(phase == PH_GEN));
-        const int n_node = __popcll(__ballot(want_node));
-        const int n_tri = __popcll(__ballot(want_tri));
-        if (n_adv + n_genw + n_node + n_tri == 0) break;  // (an ADV lane with a busy partner implies n_node + n_tri > 0)
-        const bool run_adv = n_adv > 0 && ((n_adv >= adv_batch && 2 * n_adv >= n_node && 2 * n_adv >= n_tri) || n_node + n_tri == 0);
-        // ---------------- GEN block (A lanes): gen() for paths that certainly ended
-        if (!run_adv && n_genw > 0 && (n_genw >= gen_batch || n_node + n_tri == 0)) {
-            AdvanceOut out;
-            out.did_gen = out.new_ray = false;
-            if (phase == PH_GEN) {
-                SlotState st;
-                st.gen = cold[2 * kBlock];
-                st.rs = Rng{(uint32_t)cold[3 * kBlock], (uint32_t)cold[4 * kBlock], (uint32_t)cold[5 * kBlock],
-                            (uint32_t)cold[6 * kBlock], (uint32_t)cold[7 * kBlock], (uint32_t)cold[8 * kBlock]};
-                st.bounces = 0;
-                st.pixel = 0;
-                st.beta = mk(0, 0, 0);
-                gen_core(cam, ap, ap.slot_lo + i, st, out);
-                if (out.new_ray) {
-                    o = out.ray_o;
-                    d = out.ray_d;
-                    inv = inv_dir(d);
-                    phase = PH_CLOSEST;
-                    tmax = kFltMax;
-                    tri = -1;
-                    cur = 0;
-                    sp = 0;
-                    bounces = st.bounces;
-                    pixel = st.pixel;
-                    gen = st.gen;
-                    rs = st.rs;
-                    beta = st.beta;
-                    cold_save();
-                } else {
-                    // out of camera rays (or parked for the lockstep final generation): hand the slot back, take the next
-                    bounces = st.bounces;
-                    pixel = cold[1 * kBlock];
-                    gen = st.gen;
-                    rs = st.rs;
-                    beta = mk(__int_as_float(cold[9 * kBlock]), __int_as_float(cold[10 * kBlock]), __int_as_float(cold[11 * kBlock]));
-                    store_slot(i);
-                    phase = PH_IDLE;
-                    tri = -1;
-                    slot_set++;
-                    i = slot_of(slot_set);
-                    if (i < ap.n) {
-                        load_slot(i);
-                        if (bounces != kDone && bounces != kParked) {
-                            phase = PH_GEN;
-                            cold_save();
-                        } else {
-                            i = ap.n;
-                        }
-                    }
-                }
-            }
-            n_gen += __popcll(__ballot(out.did_gen));
-            n_traced += __popcll(__ballot(out.new_ray));
-            continue;
-        }
-        if (run_adv) {
-            // ---------------- ADV block (A lanes), then the shadow rays go over to the B lanes
-            AdvanceOut out;
-            out.did_gen = out.did_shade = out.has_shadow = out.did_emit = out.new_ray = out.wants_gen = false;
-            out.rr_draws = 0;
-            out.s_o = out.s_d = out.s_L = mk(0, 0, 0);
-            out.s_tmax = 0.f;
-            out.s_target = -1;
-            int send_pixel = 0;
-            if (adv_ready) {
-                cold_load();
-                SlotState st;
-                st.bounces = bounces;
-                st.pixel = pixel;
-                st.gen = gen;
-                st.rs = rs;
-                st.beta = beta;
-                st.wo = d;
-                st.hit_info = -1;
-                st.isect_p = st.isect_n = mk(0, 0, 0);
-                if (tri >= 0) {  // hit record in the form mat() consumes (render.cuh:152-153, 311-316)
-                    Tri tr = load_tri(sc.tris, tri);
-                    int2 ml = sc.tri_info[(unsigned)tri];
-                    st.isect_p = tri_point(tr, hu, hv);
-                    st.isect_n = neg(unit(tr.n));
-                    st.hit_info = (ml.x & 0xffff) | ((ml.y + 1) << 16);
-                }
-                advance_core<true>(sc, tab, cam, ap, ap.slot_lo + i, st, out, fb);
-                bounces = st.bounces;
-                pixel = st.pixel;
-                gen = st.gen;
-                rs = st.rs;
-                beta = st.beta;
-                send_pixel = pixel;
-                if (out.new_ray) {
-                    o = out.ray_o;
-                    d = out.ray_d;
-                    phase = PH_CLOSEST;
-                    tmax = kFltMax;
-                    tri = -1;
-                } else {
-                    phase = PH_GEN;  // out.wants_gen: Russian roulette ended the path
-                    tri = -1;
-                }
-                cold_save();
-            }
-            // A (lane l) -> B (lane l + 32)
-            const int src_lane = (int)(lane ^ 32u);
-            const int r_flag = __shfl(out.has_shadow ? 1 : 0, src_lane);
-            const float r_ox = __shfl(out.s_o.x, src_lane), r_oy = __shfl(out.s_o.y, src_lane), r_oz = __shfl(out.s_o.z, src_lane);
-            const float r_dx = __shfl(out.s_d.x, src_lane), r_dy = __shfl(out.s_d.y, src_lane), r_dz = __shfl(out.s_d.z, src_lane);
-            const float r_lx = __shfl(out.s_L.x, src_lane), r_ly = __shfl(out.s_L.y, src_lane), r_lz = __shfl(out.s_L.z, src_lane);
-            const float r_tmax = __shfl(out.s_tmax, src_lane);
-            const int r_target = __shfl(out.s_target, src_lane);
-            const int r_pixel = __shfl(send_pixel, src_lane);
-            if (is_b && r_flag) {
-                o = mk(r_ox, r_oy, r_oz);
-                d = mk(r_dx, r_dy, r_dz);
-                b_L = mk(r_lx, r_ly, r_lz);
-                b_pixel = r_pixel;
-                tmax = r_tmax;
-                tri = r_target;
-                hu = 0.f;
-                phase = PH_ANY;
-            }
-            if ((adv_ready && out.new_ray) || (is_b && r_flag)) {  // every lane that got a new ray
-                inv = inv_dir(d);
-                cur = 0;
-                sp = 0;
-            }
-            n_shade += __popcll(__ballot(out.did_shade));
-            n_traced += __popcll(__ballot(out.new_ray));
-            n_shadow += __popcll(__ballot(out.has_shadow));
-            n_emit += __popcll(__ballot(out.did_emit));
-            int rr = out.rr_draws;
-            if (__ballot(rr != 0)) {
-                for (int off = 32; off > 0; off >>= 1) rr += __shfl_xor(rr, off);
-                n_rr += (unsigned long long)rr;
-            }
-            continue;
-        }
-        const bool is_any = phase == PH_ANY;
-        // ---------------- node steps (both ray kinds)
-        if (n_node > 0 && n_node >= n_tri) {
-            if (want_node) {
-#pragma unroll
-                for (int rep = 0; rep < kNodePerStep; rep++)
-                    if (cur >= 0) inner_step<false>(sc, o, inv, tmax, cur, sp, stack, over, stack_cap);
-            }
-        }
-        // ---------------- triangle tests (triangle.cuh:39-58)
-        if (n_tri > 0 && n_tri > n_node) {
-            if (want_tri) {
-                bool stop = false;
-                int reps = 0;
-                do {
-                    int ref = ~cur;
-                    int k = ref >> 3, count = ref & 7;
-                    Tri tr = load_tri(sc.tris, k);
-                    float t, u, v;
-                    if (tri_intersect(tr, o, d, tmax, t, u, v)) {
-                        if (is_any) {
-                            if (k != tri) {  // bvh.cuh:243
-                                hu = 1.f;
-                                stop = true;
-                            }
-                        } else {  // bvh.cuh:227-231
-                            tmax = t;
-                            hu = u;
-                            hv = v;
-                            tri = k;
-                        }
-                    }
-                    if (stop) cur = kEntryDone;
-                    else if (count > 1) cur = leaf_ref(k + 1, count - 1);
-                    else if (sp > 0) cur = stack_pop(stack, over, sp, stack_cap);
-                    else cur = kEntryDone;
-                    reps++;
-                } while (reps < kTriPerStep && cur != kEntryDone && cur < 0 && !stop);
-            }
-        }
-        // ---------------- finished rays
-        const bool fin = trav && cur == kEntryDone;
-        n_deposit += __popcll(__ballot(fin && is_any && hu == 0.f));
-        if (fin) {
-            if (is_any) {
-                if (hu == 0.f && !debug_no_deposit) deposit(fb, ap.fb_fixed, b_pixel, b_L.x, b_L.y, b_L.z);  // render.cuh:291-293
-                phase = PH_IDLE;
-            } else {
-                const int b = cold[0 * kBlock];
-                phase = (tri < 0 || (b >= ap.max_bounces && b > 0)) ? PH_GEN : PH_ADV;
-            }
-        }
-    }
-    unsigned long long v[C_COUNT] = {n_gen, n_shade, n_traced, n_shadow, n_emit, n_deposit, n_rr, 0ull};
-    row_add(rows, v);
-}
-
 // post_process_framebuffer (render.cuh:330-338): c = sqrt(c * (1/spp))
 __global__ void k_post_process(float *fb, int n_values, float inv_spp) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2204,7 +1883,7 @@ int get_context(int n, int lane, Context **out) {
     if (dev_alloc(*c, p.base, (size_t)A_COUNT * n)) return 1;
     if (dev_alloc(*c, c->rng_backup, (size_t)6 * n)) return 1;
     if (dev_alloc(*c, c->d_ctr, 1)) return 1;
-    c->n_rows = 2 * ((n + kBlock - 1) / kBlock) * (kBlock / 64);  // (k_paths_pair runs 32 slots per wave)
+    c->n_rows = ((n + kBlock - 1) / kBlock) * (kBlock / 64);
     if (dev_alloc(*c, c->d_rows, (size_t)c->n_rows)) return 1;
     if (dev_alloc(*c, c->d_jump, (size_t)20 * 800)) return 1;
     HIP_TRY(hipMemcpy(c->d_jump, jump_powers().data(), sizeof(uint32_t) * 20 * 800, hipMemcpyHostToDevice));
@@ -2477,24 +2156,7 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
             hipLaunchKernelGGL((k_paths<T, WD, MJ, 4>), grid_paths, block, lds_paths, st, sc, c.pools, cam, ap, d_sum,   \
                                c.d_rows, paths_cap, d_over2, adv_batch, dbg, paths_prof, 0, prio_rotate, rot_wave, rot_set, gen_batch);     \
     } while (0)
-        // small shards: a slot is served by a pair of lanes (path ray | shadow ray): 4 waves per SIMD again
-        bool pair = few_blocks && !scene->wide && majority && n >= 4096;
-        if (const char *e = getenv("RT_PAIR")) pair = pair && atoi(e) != 0;
-        else pair = false;  // measured: 1/8 shard -4 %, 1/16 shard +9 %
-        if (pair) {
-            const dim3 grid_pair(2 * paths_blocks);
-            const size_t lds_pair = sizeof(int) * (size_t)kBlock * (size_t)(paths_cap + 12) +
-                                    (lds_tables ? sizeof(float) * (size_t)((scene->tab_dwords + 3) & ~3) : 0);
-            int pair_adv = 16;
-            if (const char *e = getenv("RT_PAIR_ADV_BATCH")) pair_adv = std::max(1, std::min(32, atoi(e)));
-            // lattice shifts in 32-slot blocks
-            if (lds_tables)
-                hipLaunchKernelGGL((k_paths_pair<true>), grid_pair, block, lds_pair, st, sc, c.pools, cam, ap, d_sum, c.d_rows,
-                                   paths_cap, d_over2, pair_adv, gen_batch, dbg, prio_rotate, 2 * rot_wave, 2 * rot_set);
-            else
-                hipLaunchKernelGGL((k_paths_pair<false>), grid_pair, block, lds_pair, st, sc, c.pools, cam, ap, d_sum, c.d_rows,
-                                   paths_cap, d_over2, pair_adv, gen_batch, dbg, prio_rotate, 2 * rot_wave, 2 * rot_set);
-        } else if (majority) {
+        if (majority) {
             if (lds_tables && scene->wide) RT_LAUNCH_PATHS(true, true, true);
             else if (lds_tables) RT_LAUNCH_PATHS(true, false, true);
             else if (scene->wide) RT_LAUNCH_PATHS(false, true, true);
