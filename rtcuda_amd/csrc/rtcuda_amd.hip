@@ -1181,7 +1181,11 @@ k_paths(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__ f
     const unsigned prio_rank = (4u * blockIdx.x) / gridDim.x;
     while (true) {
         if (prio_period && (prio_tick++ & ((1u << prio_period) - 1u)) == 0u) {
-            switch (((prio_tick >> prio_period) + prio_rank) & 3u) {
+            unsigned lvl = ((prio_tick >> prio_period) + prio_rank) & 3u;
+            // ties go to the older wave, which left the two younger waves of a SIMD 5 % behind the two older ones;
+            // never dropping them to the lowest level evens that out (ranks finish at 0.95 .. 0.97 of the frame)
+            lvl = max(lvl, prio_rank >> 1);
+            switch (lvl) {
                 case 0: __builtin_amdgcn_s_setprio(0); break;
                 case 1: __builtin_amdgcn_s_setprio(1); break;
                 case 2: __builtin_amdgcn_s_setprio(2); break;
