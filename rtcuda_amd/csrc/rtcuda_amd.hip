@@ -396,45 +396,52 @@ __device__ __forceinline__ void advance_core(const DScene &sc, const float *tab,
     out.rr_draws = 0;
     const bool hit = st.hit_info >= 0;
     const int light_of_hit = hit ? ((st.hit_info >> 16) & 0xffff) - 1 : -1;
-    // Emulate consecutive init() calls (render.cuh:84-137) until one of them ends in mat() or
-    // gen(): a slot whose path missed idles (no RNG use) until bounces reaches max_bounces,
-    // a slot that Russian roulette "killed" is re-rolled every iteration (Appendix A.1).
-    while (true) {
-        if (st.bounces == 0 && hit && light_of_hit >= 0) {  // :98-103 emission only at bounce 0
-            Light l = tab_light(tab, sc.num_mats, light_of_hit);
-            deposit(fb, ap.fb_fixed, st.pixel, l.lx, l.ly, l.lz);
-            out.did_emit = true;
-        }
-        bool cont = st.bounces < ap.max_bounces;  // :109
-        bool local_hit = hit;
-        if (cont && hit && st.bounces > kRrStart) {  // :112-124
-            float bm = max3(st.beta);
-            if (bm < kRrThreshold) {
-                float pt = fmaxf(0.05f, 1 - bm);
+    // Emulate consecutive init() calls (render.cuh:84-137) until one of them ends in mat() or gen(): a slot whose
+    // path missed idles (no RNG use) until bounces reaches max_bounces; a slot that Russian roulette "killed" is
+    // re-rolled by every following init() (Appendix A.1) -- beta, and with it the kill probability, does not change
+    // along such a chain, so the chain is a tight loop of draws.  `lockstep`: exactly one init() per call.
+    if (st.bounces == 0 && hit && light_of_hit >= 0) {  // :98-103 emission only at bounce 0
+        Light l = tab_light(tab, sc.num_mats, light_of_hit);
+        deposit(fb, ap.fb_fixed, st.pixel, l.lx, l.ly, l.lz);
+        out.did_emit = true;
+    }
+    const bool cont = st.bounces < ap.max_bounces;  // :109
+    if (cont && hit) {
+        bool shade = true;
+        if (st.bounces > kRrStart && max3(st.beta) < kRrThreshold) {  // :112-124
+            const float pt = fmaxf(0.05f, 1 - max3(st.beta));
+            shade = false;
+            while (true) {
                 out.rr_draws++;
-                if (rng_uniform(st.rs) < pt) local_hit = false;
-                else st.beta = divf(st.beta, 1 - pt);
+                const bool kill = rng_uniform(st.rs) < pt;
+                st.bounces = st.bounces + 1;  // :126
+                if (!kill) {
+                    st.beta = divf(st.beta, 1 - pt);
+                    shade = true;
+                    break;
+                }
+                if (ap.lockstep || !(st.bounces < ap.max_bounces)) break;
             }
+        } else {
+            st.bounces = st.bounces + 1;  // :126
         }
-        st.bounces = st.bounces + 1;  // :126
-        if (cont) {
-            if (local_hit) {
-                out.did_shade = true;
-                break;
-            }
-            if (ap.lockstep) break;                    // exactly one init() per round
-            if (!hit) st.bounces = ap.max_bounces;     // idle iterations consume nothing: skip them
-            continue;
+        if (shade) out.did_shade = true;
+        else if (ap.lockstep) return;  // killed this round; the next round rolls again
+    } else {
+        if (cont && ap.lockstep) {  // a miss idles: nothing but the counter moves (Appendix A.2)
+            st.bounces = st.bounces + 1;
+            return;
         }
-        // ---- gen() :250-275
+    }
+    if (!out.did_shade) {
+        // ---- gen() :250-275 (the init() that finds no bounce left; its own increment of `bounces` is overwritten)
         if (DEFER_GEN) {  // k_paths: camera rays are generated by the (much shorter) GEN block
             out.wants_gen = true;
             return;
         }
         gen_core(cam, ap, slot_global, st, out);
-        break;
+        return;
     }
-    if (!out.did_shade) return;
     // ---- mat() :139-248
     Material m = tab_material(tab, st.hit_info & 0xffff);
     V3 multiplier = scale(st.beta, (float)sc.num_lights);  // taken BEFORE the beta update (:150)
