@@ -681,7 +681,11 @@ __device__ __forceinline__ int stack_pop(int *lds_col, int *over_col, int &sp, i
     // always read the LDS column (clamped) and patch from the overflow only when needed: written as a
     // select of two pointers, the compiler merges the paths into one FLAT load, which is slower
     int v = lds_col[min(sp, cap - 1) * kBlock];
-    if (sp >= cap) v = over_col[(size_t)(sp - cap) * kOverStride];
+    if (sp >= cap) {
+        v = over_col[(size_t)(sp - cap) * kOverStride];
+        __asm__ volatile("" ::: "memory");  // keeps this a branch: merged, the two loads become one FLAT load behind
+                                            // a dozen instructions of 64-bit address selection, on every pop
+    }
     return v;
 }
 constexpr int kRefillAt = 40;                // finalise + refill once <= this many lanes still traverse
