@@ -79,7 +79,9 @@ struct Tri {
 // 48-byte record = 3 x float4: (p0.xyz, e1.x) (e1.yz, e2.xy) (e2.z, n.xyz)
 RT_DEV Tri load_tri(const float4 *__restrict__ tris, int k) {
     // 32-bit byte offset from a uniform base: lets the compiler use the SGPR-base addressing form
-    const float4 *q = (const float4 *)((const char *)tris + (unsigned)k * 48u);
+    // (24-bit multiply: full rate, the 32-bit one is quarter rate; a scene has far fewer than 2^24 triangles -- checked
+    // by rt_scene_create)
+    const float4 *q = (const float4 *)((const char *)tris + __umul24((unsigned)k, 48u));
     float4 a = q[0];
     float4 b = q[1];
     float4 c = q[2];

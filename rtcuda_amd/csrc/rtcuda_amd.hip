@@ -2410,6 +2410,7 @@ int rt_scene_create(const float *tri_p0p1p2, int n_tris, const int32_t *tri_mate
     if (!out_scene) return fail("rt_scene_create: out_scene is null");
     *out_scene = nullptr;
     if (n_tris < 0 || n_materials < 0 || n_lights < 0) return fail("rt_scene_create: negative count");
+    if (n_tris >= (1 << 24)) return fail("rt_scene_create: more than 2^24 - 1 triangles (24-bit triangle addressing)");
     if (n_tris > 0 && (!tri_p0p1p2 || !tri_material)) return fail("rt_scene_create: null triangle arrays");
     if (n_tris > 0 && (n_materials == 0 || !materials)) return fail("rt_scene_create: no materials");
     if (n_lights > 0 && !lights) return fail("rt_scene_create: null lights");
