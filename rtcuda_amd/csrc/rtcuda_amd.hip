@@ -251,6 +251,7 @@ struct AdvanceParams {
     int lockstep;        // 1: final generation, one init() per slot per round (literal reference schedule)
     int fb_fixed;        // framebuffer holds 64-bit fixed-point sums (see deposit())
     int w_over_spp;      // W / spp when spp divides W (then pixel = gen * w_over_spp + slot / spp: no 64-bit divide), else 0
+    int dpx, dpy;        // w_over_spp = dpy * width + dpx: how a slot's pixel moves per generation; dpy < 0: not usable
 };
 
 constexpr int kLdsTable = 64;                   // materials / lights staged in LDS per workgroup
@@ -359,8 +360,10 @@ struct AdvanceOut {
 
 // gen() (render.cuh:250-275) for one slot.  Camera ray id = generation * W + slot (see file header).  Leaves
 // st.bounces = kDone (no camera ray left) / kParked (the final generation runs in lockstep) or a new path.
+// `pxy` (optional): the slot's previous pixel as (x | y << 16), or -1.  A slot's pixel index grows by W / spp per
+// generation, so with it the pixel coordinates follow by an add and a carry instead of two integer divisions.
 __device__ __forceinline__ void gen_core(const Camera &cam, const AdvanceParams &ap, int slot_global, SlotState &st,
-                                         AdvanceOut &out) {
+                                         AdvanceOut &out, int *pxy = nullptr) {
     long long cid = (long long)st.gen * kW + slot_global;
     if (cid >= ap.cam_end) {
         st.bounces = kDone;
@@ -373,10 +376,22 @@ __device__ __forceinline__ void gen_core(const Camera &cam, const AdvanceParams 
     st.gen = st.gen + 1;
     // pixel = camera_ray_id / spp (render.cuh:254-256).  cid = gen * W + slot, so when spp divides W the quotient
     // splits exactly into two 32-bit terms; the general case keeps the 64-bit division.
-    if (ap.w_over_spp) st.pixel = (st.gen - 1) * ap.w_over_spp + (int)((unsigned)slot_global / (unsigned)ap.spp);  // (gen already counts this ray)
-    else st.pixel = (int)(cid / ap.spp);
-    int py = (int)((unsigned)st.pixel / (unsigned)ap.width);  // (both non-negative: the unsigned divide is the cheaper one)
-    int px = st.pixel - py * ap.width;
+    int px, py;
+    if (pxy && ap.dpy >= 0 && *pxy >= 0) {
+        px = (*pxy & 0xffff) + ap.dpx;
+        py = (*pxy >> 16) + ap.dpy;
+        if (px >= ap.width) {
+            px -= ap.width;
+            py++;
+        }
+        st.pixel = py * ap.width + px;
+    } else {
+        if (ap.w_over_spp) st.pixel = (st.gen - 1) * ap.w_over_spp + (int)((unsigned)slot_global / (unsigned)ap.spp);  // (gen already counts this ray)
+        else st.pixel = (int)(cid / ap.spp);
+        py = (int)((unsigned)st.pixel / (unsigned)ap.width);  // (both non-negative: the unsigned divide is the cheaper one)
+        px = st.pixel - py * ap.width;
+    }
+    if (pxy) *pxy = px | (py << 16);
     float jx = rng_uniform(st.rs);  // x first, then y (Appendix A.7)
     float jy = rng_uniform(st.rs);
     camera_get_ray(cam, (px + jx) / ap.width, (py + jy) / ap.height, out.ray_o, out.ray_d);
@@ -1062,7 +1077,7 @@ constexpr int kNodePerStep = RT_NODE_PER_STEP;  // node steps a lane makes per s
 // beta = 12 dwords) lives in the lane's LDS column and is only in registers inside the ADV block;
 // while a shadow ray is traced, the slot's path ray and the radiance to deposit wait in 9 more
 // dwords of LDS; the hit record is rebuilt from (tri, hu, hv) inside the ADV block.
-// LDS layout (dynamic): [stack: stack_cap x kBlock][parked ray: 9 x kBlock][slot state: 12 x kBlock][tables]
+// LDS layout (dynamic): [stack: stack_cap x kBlock][parked ray: 9 x kBlock][slot state: 12 + 1 x kBlock][tables]
 template <bool LDS_TABLES, bool WIDE, bool MAJORITY, int MIN_WAVES>
 __global__ void __launch_bounds__(kBlock, MIN_WAVES)
 k_paths(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__ fb, DWaveRow *__restrict__ rows,
@@ -1077,7 +1092,7 @@ k_paths(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__ f
     float *park = (float *)(s_lds + stack_cap * kBlock) + threadIdx.x;  // element k at park[k * kBlock]
     int *over = overflow + (blockIdx.x * kBlock + threadIdx.x) % kOverStride;
     int *cold = s_lds + (stack_cap + 9) * kBlock + threadIdx.x;  // element k at cold[k * kBlock]
-    float *s_tab = (float *)(s_lds + (stack_cap + 21) * kBlock);
+    float *s_tab = (float *)(s_lds + (stack_cap + 22) * kBlock);
     const float *tab = sc.tables;
     // small shards (MIN_WAVES == 2: at most 2 workgroups per CU, LDS to spare, latency-bound): the top of
     // the BVH is staged in LDS, so the first levels of every traversal do not leave the CU
@@ -1172,6 +1187,7 @@ k_paths(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__ f
         load_slot(i);
         phase = (bounces != kDone && bounces != kParked) ? (SPLIT_GEN ? PH_GEN : PH_ADV) : PH_IDLE;  // (untouched slots: bounces = INT_MAX)
         cold_save();
+        cold[12 * kBlock] = -1;  // no previous pixel
     }
     // wave-uniform event counters
     unsigned long long n_gen = 0, n_shade = 0, n_traced = 0, n_shadow = 0, n_emit = 0, n_deposit = 0, n_rr = 0;
@@ -1236,8 +1252,10 @@ k_paths(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__ f
                 st.bounces = 0;
                 st.pixel = 0;
                 st.beta = mk(0, 0, 0);
-                gen_core(cam, ap, ap.slot_lo + i, st, out);
+                int pxy = cold[12 * kBlock];
+                gen_core(cam, ap, ap.slot_lo + i, st, out, &pxy);
                 if (out.new_ray) {
+                    cold[12 * kBlock] = pxy;
                     o = out.ray_o;
                     d = out.ray_d;
                     inv = inv_dir(d);
@@ -1270,6 +1288,7 @@ k_paths(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__ f
                         if (bounces != kDone && bounces != kParked) {
                             phase = PH_GEN;  // untouched slots start with bounces = INT_MAX: their first step is gen()
                             cold_save();
+                            cold[12 * kBlock] = -1;
                         } else {
                             i = ap.n;  // (cannot happen: untouched slots start alive)
                         }
@@ -2043,6 +2062,8 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
     ap.lockstep = 0;
     ap.fb_fixed = (flags & kFlagFixedFb) ? 1 : 0;
     ap.w_over_spp = (kW % spp == 0) ? kW / spp : 0;
+    ap.dpx = ap.w_over_spp % width;
+    ap.dpy = (ap.w_over_spp > 0 && width < 32768 && height < 32768) ? ap.w_over_spp / width : -1;
     const bool lds_tables = scene->n_mats <= kLdsTable && scene->n_lights <= kLdsTable;
 
     hipEvent_t ev_start, ev_stop;
@@ -2109,7 +2130,7 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
         const int paths_cap = std::min(8, std::max(1, scene->stack_bound));
         int *d_over2 = nullptr;
         if (ensure_overflow(scene->stack_bound - paths_cap, &d_over2)) return 1;
-        size_t lds_paths = sizeof(int) * (size_t)kBlock * (size_t)(paths_cap + 21) + (lds_tables ? sizeof(float) * (size_t)((scene->tab_dwords + 3) & ~3) : 0);
+        size_t lds_paths = sizeof(int) * (size_t)kBlock * (size_t)(paths_cap + 22) + (lds_tables ? sizeof(float) * (size_t)((scene->tab_dwords + 3) & ~3) : 0);
         bool majority = true;
         if (const char *e = getenv("RT_MAJORITY")) majority = atoi(e) != 0;
         const int dbg = (flags & 0x100u) ? 1 : 0;
