@@ -82,6 +82,8 @@ struct DScene {
     const float4 *nodes;   // 4 x float4 per 4-wide node record (rt_bvh.h)
     const float4 *tris;    // 3 x float4 per triangle, leaf order
     const int2 *tri_info;  // leaf order: {material index, light index or -1}
+    const float4 *tri_shade;  // leaf order: what mat() needs of a hit triangle besides the point -- the flipped unit
+                              // normal -normalize(n) (render.cuh:153) and the packed ids (material | light + 1 << 16)
     const Material *mats;
     const Light *lights;
     int num_lights;
@@ -260,6 +262,18 @@ constexpr int kTabDwordsMax = kLdsTable * 29;   // 5 + 8 + 12 + 4 dwords per (ma
 // Per-light values that depend on the light triangle only, computed once per scene on the device
 // with the same operations mat() would redo per shade: 1 / Triangle::area() (triangle.cuh:79,84-86)
 // and d_triangle->n.unit_vector() (light.cuh:46).
+// Per-triangle shading record, computed once per scene with the operations mat() would redo at every shade
+// (isect_unit_n = -d_triangle->n.unit_vector(), render.cuh:153; vec3.cuh:131-134).
+__global__ void k_build_tri_shade(const float4 *__restrict__ tris, const int2 *__restrict__ tri_info, int n,
+                                  float4 *__restrict__ out) {
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    Tri tr = load_tri(tris, k);
+    V3 un = neg(unit(tr.n));
+    int2 ml = tri_info[k];
+    out[k] = make_float4(un.x, un.y, un.z, __int_as_float((ml.x & 0xffff) | ((ml.y + 1) << 16)));
+}
+
 __global__ void k_build_tables(const Material *mats, int n_mats, const Light *lights, int n_lights,
                                const float4 *tris, float *tab) {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1324,10 +1338,10 @@ k_paths(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__ f
                 st.isect_p = st.isect_n = mk(0, 0, 0);
                 if (tri >= 0) {  // hit record in the form mat() consumes (render.cuh:152-153, 311-316)
                     Tri tr = load_tri(sc.tris, tri);
-                    int2 ml = sc.tri_info[(unsigned)tri];
+                    float4 sh = sc.tri_shade[(unsigned)tri];
                     st.isect_p = tri_point(tr, hu, hv);
-                    st.isect_n = neg(unit(tr.n));
-                    st.hit_info = (ml.x & 0xffff) | ((ml.y + 1) << 16);
+                    st.isect_n = mk(sh.x, sh.y, sh.z);
+                    st.hit_info = __float_as_int(sh.w);
                 }
                 advance_core<SPLIT_GEN>(sc, tab, cam, ap, ap.slot_lo + i, st, out, fb);
                 bounces = st.bounces;
@@ -1686,6 +1700,7 @@ struct rt_scene {
     int builder = 0;             // 0 host SAH, 1 device LBVH
     float4 *d_tris = nullptr;
     int2 *d_tri_info = nullptr;
+    float4 *d_tri_shade = nullptr;
     Material *d_mats = nullptr;
     Light *d_lights = nullptr;
     float *d_tables = nullptr;    // shading tables (see DScene)
@@ -1698,6 +1713,7 @@ struct rt_scene {
         s.nodes = d_nodes;
         s.tris = d_tris;
         s.tri_info = d_tri_info;
+        s.tri_shade = d_tri_shade;
         s.mats = d_mats;
         s.lights = d_lights;
         s.num_lights = n_lights;
@@ -2545,6 +2561,12 @@ int rt_scene_create(const float *tri_p0p1p2, int n_tris, const int32_t *tri_mate
     HIP_TRY(hipMemcpy(sc->d_tris, trec.data(), sizeof(float) * trec.size(), hipMemcpyHostToDevice));
     HIP_TRY(hipMalloc((void **)&sc->d_tri_info, sizeof(int2) * info.size()));
     HIP_TRY(hipMemcpy(sc->d_tri_info, info.data(), sizeof(int2) * info.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc((void **)&sc->d_tri_shade, sizeof(float4) * std::max<size_t>(info.size(), 1)));
+    if (n_tris > 0) {
+        hipLaunchKernelGGL(k_build_tri_shade, dim3((n_tris + 255) / 256), dim3(256), 0, nullptr, sc->d_tris, sc->d_tri_info, n_tris,
+                           sc->d_tri_shade);
+        HIP_TRY(hipGetLastError());
+    }
     HIP_TRY(hipMalloc((void **)&sc->d_mats, sizeof(Material) * std::max(n_materials, 1)));
     if (n_materials)
         HIP_TRY(hipMemcpy(sc->d_mats, materials, sizeof(Material) * n_materials, hipMemcpyHostToDevice));
@@ -2570,6 +2592,7 @@ void rt_scene_destroy(rt_scene *scene) {
     (void)hipFree(scene->d_nodes);
     (void)hipFree(scene->d_tris);
     (void)hipFree(scene->d_tri_info);
+    (void)hipFree(scene->d_tri_shade);
     (void)hipFree(scene->d_mats);
     (void)hipFree(scene->d_lights);
     (void)hipFree(scene->d_order);
