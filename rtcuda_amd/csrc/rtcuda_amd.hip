@@ -180,6 +180,10 @@ __device__ __forceinline__ unsigned lane_id() {
 __device__ __forceinline__ unsigned prefix_popc(unsigned long long mask) {
     return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
 }
+// Wave votes straight from the condition's compare (HIP's wave_ballot(int) first materialises the predicate as 0 / 1 in
+// a VGPR and compares that with zero again: two more VALU instructions per vote, a dozen votes per scheduling decision).
+__device__ __forceinline__ unsigned long long wave_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+__device__ __forceinline__ int wave_count(bool p) { return (int)__builtin_popcountll(__builtin_amdgcn_ballot_w64(p)); }
 __device__ __forceinline__ unsigned wave_index() { return (blockIdx.x * blockDim.x + threadIdx.x) >> 6; }
 // lanes 0..7 of the wave add v[lane] to the wave's own row: one 64-byte load + one 64-byte store
 __device__ __forceinline__ void row_add(DWaveRow *rows, const unsigned long long (&v)[C_COUNT]) {
@@ -630,18 +634,18 @@ k_advance(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__
     if (in_range && !out.has_shadow) p.stmax(i) = -1.f;  // no shadow ray from this slot this round
 
     // ---- event counters: this wave's own row
-    unsigned long long traced = __ballot(out.did_gen || out.did_shade);
+    unsigned long long traced = wave_ballot(out.did_gen || out.did_shade);
     int rr_tot = out.rr_draws;
-    if (__ballot(out.rr_draws != 0)) {
+    if (wave_ballot(out.rr_draws != 0)) {
         for (int off = 32; off > 0; off >>= 1) rr_tot += __shfl_xor(rr_tot, off);
     } else {
         rr_tot = 0;
     }
-    unsigned long long v[C_COUNT] = {(unsigned long long)__popcll(__ballot(out.did_gen)),
-                                     (unsigned long long)__popcll(__ballot(out.did_shade)),
+    unsigned long long v[C_COUNT] = {(unsigned long long)wave_count((out.did_gen)),
+                                     (unsigned long long)wave_count((out.did_shade)),
                                      (unsigned long long)__popcll(traced),
-                                     (unsigned long long)__popcll(__ballot(out.has_shadow)),
-                                     (unsigned long long)__popcll(__ballot(out.did_emit)),
+                                     (unsigned long long)wave_count((out.has_shadow)),
+                                     (unsigned long long)wave_count((out.did_emit)),
                                      0ull,
                                      (unsigned long long)rr_tot,
                                      0ull};
@@ -650,7 +654,7 @@ k_advance(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__
     // round that closes a batch: one plain store per live wave in 1 round out of 8
     if ((ap.round & ap.batch_mask) == ap.batch_mask && traced != 0 && lane_id() == 0) ctr->last_live_round = ap.round;
     if (ap.lockstep) {
-        unsigned long long sm = __ballot(out.did_shade);
+        unsigned long long sm = wave_ballot(out.did_shade);
         if (sm != 0 && lane_id() == 0) atomicAdd(&ctr->round_shades, (unsigned)__popcll(sm));
     }
 }
@@ -879,7 +883,7 @@ __global__ void __launch_bounds__(kBlock, 8) k_trace(DScene sc, DPools p, TraceP
 #endif
 
     while (true) {
-        unsigned long long act = __ballot(id >= 0 && cur != kEntryDone);
+        unsigned long long act = wave_ballot(id >= 0 && cur != kEntryDone);
 #ifdef RT_TRACE_PROFILE
         pf_outer++;
         pf_act_at_top += __popcll(act);
@@ -889,10 +893,10 @@ __global__ void __launch_bounds__(kBlock, 8) k_trace(DScene sc, DPools p, TraceP
             const bool fin = id >= 0 && cur == kEntryDone;
 #ifdef RT_TRACE_PROFILE
             pf_refill++;
-            pf_fin_lanes += __popcll(__ballot(fin));
+            pf_fin_lanes += wave_count((fin));
 #endif
             const bool is_any = MODE == MODE_POOL ? (id & kAnyBit) != 0 : MODE == MODE_TEST_ANY;
-            if (MODE == MODE_POOL) deposits += __popcll(__ballot(fin && is_any && hu == 0.f));
+            if (MODE == MODE_POOL) deposits += wave_count((fin && is_any && hu == 0.f));
             if (fin) {
                 const int slot = id & (kAnyBit - 1);
                 if (MODE == MODE_POOL) {
@@ -929,7 +933,7 @@ __global__ void __launch_bounds__(kBlock, 8) k_trace(DScene sc, DPools p, TraceP
             }
             // ---- refill idle lanes (up to three chunks per refill: shadow rays are sparse)
             for (int tries = 0; tries < 3; tries++) {
-                unsigned long long idle = __ballot(id < 0);
+                unsigned long long idle = wave_ballot(id < 0);
                 int n_idle = __popcll(idle);
                 if (n_idle == 0) break;
                 if (pend_lo == pend_hi && !exhausted) {
@@ -943,7 +947,7 @@ __global__ void __launch_bounds__(kBlock, 8) k_trace(DScene sc, DPools p, TraceP
                         bool valid = cand < total;
                         if (MODE == MODE_POOL && valid)
                             valid = any_chunk ? p.stmax(cand) >= 0.f : (p.bounces(cand) != kDone && p.bounces(cand) != kParked);
-                        unsigned long long vm = __ballot(valid);
+                        unsigned long long vm = wave_ballot(valid);
                         if (valid) pend[prefix_popc(vm)] = any_chunk ? (cand | kAnyBit) : cand;
                         pend_lo = 0;
                         pend_hi = __popcll(vm);
@@ -984,24 +988,24 @@ __global__ void __launch_bounds__(kBlock, 8) k_trace(DScene sc, DPools p, TraceP
                     break;
                 }
             }
-            act = __ballot(id >= 0 && cur != kEntryDone);
+            act = wave_ballot(id >= 0 && cur != kEntryDone);
             if (act == 0) {
                 if (exhausted && pend_lo == pend_hi) break;  // nothing in flight, nothing pending, no chunks left
                 continue;
             }
         }
         // ---- inner phase: step through node records until no lane holds an inner entry
-        while (__ballot(cur >= 0) != 0) {
+        while (wave_ballot(cur >= 0) != 0) {
 #ifdef RT_TRACE_PROFILE
             pf_inner_it++;
-            pf_inner_lanes += __popcll(__ballot(cur >= 0));
+            pf_inner_lanes += wave_count((cur >= 0));
 #endif
             if (cur >= 0) inner_step<WIDE>(sc, o, inv, tmax, cur, sp, stack, over, stack_cap);
         }
         // ---- leaf phase: every lane that holds a leaf tests its triangles (triangle.cuh:39-58)
 #ifdef RT_TRACE_PROFILE
         {
-            unsigned long long lm = __ballot(cur != kEntryDone && cur < 0);
+            unsigned long long lm = wave_ballot(cur != kEntryDone && cur < 0);
             if (lm) {
                 pf_leaf_it++;
                 pf_leaf_lanes += __popcll(lm);
@@ -1237,10 +1241,10 @@ k_paths(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__ f
         const bool trav = phase == PH_ANY || phase == PH_CLOSEST;
         const bool want_node = trav && cur >= 0;
         const bool want_tri = trav && cur != kEntryDone && cur < 0;
-        const int n_adv = __popcll(__ballot(phase == PH_ADV));
-        const int n_genw = __popcll(__ballot(phase == PH_GEN));
-        const int n_node = __popcll(__ballot(want_node));
-        const int n_tri = __popcll(__ballot(want_tri));
+        const int n_adv = wave_count((phase == PH_ADV));
+        const int n_genw = wave_count((phase == PH_GEN));
+        const int n_node = wave_count((want_node));
+        const int n_tri = wave_count((want_tri));
         if (n_adv + n_genw + n_node + n_tri == 0) break;
         // Every block is issued for the whole wave whatever the number of lanes that need it.  The ADV
         // block is ~15x longer than a node step or a triangle test, so it waits for `adv_batch` lanes
@@ -1309,8 +1313,8 @@ k_paths(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__ f
                     }
                 }
             }
-            n_gen += __popcll(__ballot(out.did_gen));
-            n_traced += __popcll(__ballot(out.new_ray));
+            n_gen += wave_count((out.did_gen));
+            n_traced += wave_count((out.new_ray));
 #ifdef RT_TRACE_PROFILE
             pf_gen_cycles += __builtin_readcyclecounter() - pf_tg;
 #endif
@@ -1395,13 +1399,13 @@ k_paths(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__ f
                 }
                 if (phase != PH_IDLE) cold_save();
             }
-            if (!SPLIT_GEN) n_gen += __popcll(__ballot(out.did_gen));
-            n_shade += __popcll(__ballot(out.did_shade));
-            n_traced += __popcll(__ballot(out.new_ray));
-            n_shadow += __popcll(__ballot(out.has_shadow));
-            n_emit += __popcll(__ballot(out.did_emit));
+            if (!SPLIT_GEN) n_gen += wave_count((out.did_gen));
+            n_shade += wave_count((out.did_shade));
+            n_traced += wave_count((out.new_ray));
+            n_shadow += wave_count((out.has_shadow));
+            n_emit += wave_count((out.did_emit));
             int rr = out.rr_draws;
-            if (__ballot(rr != 0)) {
+            if (wave_ballot(rr != 0)) {
                 for (int off = 32; off > 0; off >>= 1) rr += __shfl_xor(rr, off);
                 n_rr += (unsigned long long)rr;
             }
@@ -1469,7 +1473,7 @@ k_paths(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__ f
         }
         // ---------------- finished rays
         const bool fin = trav && cur == kEntryDone;
-        n_deposit += __popcll(__ballot(fin && is_any && hu == 0.f));
+        n_deposit += wave_count((fin && is_any && hu == 0.f));
         if (fin) {
             if (is_any) {
                 if (hu == 0.f && !debug_no_deposit) {  // unoccluded: render.cuh:291-293
