@@ -1098,7 +1098,7 @@ constexpr int kNodePerStep = RT_NODE_PER_STEP;  // node steps a lane makes per s
 // LDS layout (dynamic): [stack: stack_cap x kBlock][parked ray: 9 x kBlock][slot state: 12 + 1 x kBlock][tables]
 template <bool LDS_TABLES, bool WIDE, bool MAJORITY, int MIN_WAVES>
 __global__ void __launch_bounds__(kBlock, MIN_WAVES)
-k_paths(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__ fb, DWaveRow *__restrict__ rows,
+k_paths(DScene sc, DPools p, Camera cam_arg, AdvanceParams ap_arg, float *__restrict__ fb, DWaveRow *__restrict__ rows,
         int stack_cap, int *overflow, int adv_batch, int debug_no_deposit, unsigned long long *prof, int top_n,
         int prio_period, int rot_wave, int rot_set, int gen_batch) {
     // The GEN block exists where the chip is short of issue slots (4 waves per SIMD): there it takes a third of the
@@ -1121,7 +1121,27 @@ k_paths(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__ f
         for (int k = threadIdx.x; k < sc.tab_dwords; k += kBlock) s_tab[k] = sc.tables[k];
         tab = s_tab;
     }
-    if (LDS_TABLES || top_n > 0) __syncthreads();
+    // The camera and the frame parameters are only needed inside the GEN / ADV blocks: kept as kernel arguments
+    // they occupy ~30 SGPRs for the whole loop and push other scalars out into VGPR lanes (v_readlane /
+    // v_writelane are VALU work).  Staged in LDS they are read where they are used.
+    struct Uniforms {
+        Camera cam;
+        AdvanceParams ap;
+    };
+    static_assert(sizeof(Uniforms) % 4 == 0, "dword copy");
+    Uniforms *s_uni = (Uniforms *)(s_top + 4 * (size_t)top_n);
+    {
+        Uniforms u;
+        u.cam = cam_arg;
+        u.ap = ap_arg;
+        const int *srcw = (const int *)&u;
+        for (int k = threadIdx.x; k < (int)(sizeof(Uniforms) / 4); k += kBlock) ((int *)s_uni)[k] = srcw[k];
+    }
+    __syncthreads();
+    const Camera &cam = s_uni->cam;
+    const AdvanceParams &ap = s_uni->ap;
+    // what the scheduling loop itself needs stays scalar
+    const int ap_n = ap_arg.n, ap_max_bounces = ap_arg.max_bounces, ap_fb_fixed = ap_arg.fb_fixed;
     // A lane works through the slots i, i + G, i + 2G, ... (G = lanes of the grid), each for the whole
     // frame, one after the other: with G dividing the slot count every lane gets the same number of
     // slots, so all lanes -- and all workgroups, which are all resident -- finish together.
@@ -1201,7 +1221,7 @@ k_paths(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__ f
     V3 o = mk(0, 0, 0), d = mk(0, 0, 0), inv = mk(0, 0, 0);
     float tmax = 0.f, hu = 0.f, hv = 0.f;
     int cur = kEntryDone, sp = 0, tri = -1;
-    if (i < ap.n) {
+    if (i < ap_n) {
         load_slot(i);
         phase = (bounces != kDone && bounces != kParked) ? (SPLIT_GEN ? PH_GEN : PH_ADV) : PH_IDLE;  // (untouched slots: bounces = INT_MAX)
         cold_save();
@@ -1301,14 +1321,14 @@ k_paths(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__ f
                     tri = -1;
                     slot_set++;
                     i = slot_of(slot_set);
-                    if (i < ap.n) {
+                    if (i < ap_n) {
                         load_slot(i);
                         if (bounces != kDone && bounces != kParked) {
                             phase = PH_GEN;  // untouched slots start with bounces = INT_MAX: their first step is gen()
                             cold_save();
                             cold[12 * kBlock] = -1;
                         } else {
-                            i = ap.n;  // (cannot happen: untouched slots start alive)
+                            i = ap_n;  // (cannot happen: untouched slots start alive)
                         }
                     }
                 }
@@ -1386,10 +1406,10 @@ k_paths(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__ f
                     tri = -1;
                     slot_set++;
                     i = slot_of(slot_set);
-                    if (i < ap.n) {
+                    if (i < ap_n) {
                         load_slot(i);
                         if (bounces != kDone && bounces != kParked) phase = PH_ADV;
-                        else i = ap.n;  // (cannot happen: untouched slots start alive)
+                        else i = ap_n;  // (cannot happen: untouched slots start alive)
                     }
                 }
                 if (phase == PH_ANY || phase == PH_CLOSEST) {
@@ -1478,7 +1498,7 @@ k_paths(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__ f
             if (is_any) {
                 if (hu == 0.f && !debug_no_deposit) {  // unoccluded: render.cuh:291-293
                     const int pixel = cold[1 * kBlock];
-                    deposit(fb, ap.fb_fixed, pixel, park[6 * kBlock], park[7 * kBlock], park[8 * kBlock]);
+                    deposit(fb, ap_fb_fixed, pixel, park[6 * kBlock], park[7 * kBlock], park[8 * kBlock]);
                 }
                 // now the slot's path ray
                 o = mk(park[0 * kBlock], park[1 * kBlock], park[2 * kBlock]);
@@ -1493,7 +1513,7 @@ k_paths(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__ f
                 // (tri, hu, hv, d) carry the hit to the ADV block; a path that missed, or has no bounce left (and is not
                 // at bounce 0, where a hit light still emits: render.cuh:98-109), can only generate
                 const int b = cold[0 * kBlock];
-                phase = (SPLIT_GEN && (tri < 0 || (b >= ap.max_bounces && b > 0))) ? PH_GEN : PH_ADV;
+                phase = (SPLIT_GEN && (tri < 0 || (b >= ap_max_bounces && b > 0))) ? PH_GEN : PH_ADV;
             }
         }
     }
@@ -2150,7 +2170,8 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
         const int paths_cap = std::min(8, std::max(1, scene->stack_bound));
         int *d_over2 = nullptr;
         if (ensure_overflow(scene->stack_bound - paths_cap, &d_over2)) return 1;
-        size_t lds_paths = sizeof(int) * (size_t)kBlock * (size_t)(paths_cap + 22) + (lds_tables ? sizeof(float) * (size_t)((scene->tab_dwords + 3) & ~3) : 0);
+        size_t lds_paths = sizeof(int) * (size_t)kBlock * (size_t)(paths_cap + 22) + (lds_tables ? sizeof(float) * (size_t)((scene->tab_dwords + 3) & ~3) : 0) +
+                           sizeof(Camera) + sizeof(AdvanceParams);
         bool majority = true;
         if (const char *e = getenv("RT_MAJORITY")) majority = atoi(e) != 0;
         const int dbg = (flags & 0x100u) ? 1 : 0;
