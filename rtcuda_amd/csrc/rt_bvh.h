@@ -113,7 +113,12 @@ struct Result {
     bool ok = true;              // false if a leaf could not be referenced (more than 7 triangles)
 };
 
-constexpr int kMaxLeaf = 4;
+// largest leaf the SAH may keep (a leaf reference carries the count in 3 bits); tunable for experiments: RT_BVH_MAX_LEAF
+inline int max_leaf() {
+    static int c = [] { const char *e = getenv("RT_BVH_MAX_LEAF"); int v = e ? atoi(e) : 4; return v < 1 ? 1 : (v > 7 ? 7 : v); }();
+    return c;
+}
+#define kMaxLeaf (rtbvh::max_leaf())
 constexpr int kTopPrefix = 1024;  // records laid out breadth-first at the front (LDS-cacheable top of the tree)
 constexpr int kMaxBinDepth = 60;
 
