@@ -124,6 +124,32 @@ def test_render_matches_oracle_matte(api, oracle, gpu_matte, cpu_matte, w, h, sp
     assert np.abs(img_g - img_c).max() < 1e-4
 
 
+@pytest.mark.parametrize("w,h,spp,max_bounces,seed", [
+    (37, 23, 16, 10, 1),    # odd sizes: the per-generation pixel step carries across rows
+    (61, 7, 64, 10, 1),     # a very wide image: several carries per slot
+    (33, 19, 48, 10, 1),    # spp does not divide W: the general (64-bit divide) pixel path
+    (40, 30, 3, 10, 7),     # another seed, odd spp
+    (32, 24, 8, 0, 1),      # no bounce at all: emission only
+    (32, 24, 8, 1, 1),
+    (32, 24, 8, 2, 1),
+    (24, 16, 8, 20, 1),     # long Russian-roulette chains
+])
+def test_render_edge_configurations_match_oracle(api, oracle, gpu_full, cpu_full, w, h, spp, max_bounces, seed):
+    """Sizes, sample counts, bounce limits and seeds around the special cases of gen() and init(): same integer event
+    totals as the oracle, same image up to the float summation order."""
+    cam = default_camera(oracle, w / h)
+    img_c, sum_c, st_c = cpu_full.render(cam, w, h, spp, max_bounces=max_bounces, seed=seed, threads=8)
+    img_g, st_g = gpu_full.render(api.make_camera(aspect=w / h), w, h, spp, max_bounces=max_bounces, seed=seed)
+    assert st_g["camera_rays"] == w * h * spp
+    assert st_g["shade_events"] == st_c["sum_mat"]
+    assert st_g["any_rays"] == st_c["sum_ah"]
+    assert st_g["emission_adds"] == st_c["emission_adds"]
+    assert st_g["shadow_adds"] == st_c["ah_adds"]
+    assert st_g["rr_draws"] == st_c["rr_draws"]
+    assert _rms(img_g, img_c).max() < 2e-6
+    assert np.abs(img_g - img_c).max() < 1e-4
+
+
 def test_render_matches_oracle_full_bsdf(api, oracle, gpu_full, cpu_full):
     w, h, spp = 96, 54, 8
     cam = default_camera(oracle, w / h)
