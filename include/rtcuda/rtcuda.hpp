@@ -3,7 +3,9 @@
 // Same names, constructor signatures and call sequence as lashhw/rtcuda's headers, so its driver
 // (main.cu:41-173) compiles against this file with the CUDA allocation calls deleted:
 //
-//   Vec3                                  vec3.cuh:4-30        (host subset: what the driver touches)
+//   Vec3 + operators, dot, cross, ...     vec3.cuh:4-147       (everything but the device-only atomic_add)
+//   Matrix4x4, Transform                  matrix4x4.hpp, transform.hpp   (included below: rtcuda/matrix4x4.hpp, transform.hpp)
+//   PLY ingest                            happly.h (vendored)  -> rtcuda/ply.hpp (own reader, happly's two accessor names)
 //   Triangle(p0, p1, p2)                  triangle.cuh:6-7
 //   Material::make_matte/mirror/glass     material.cuh:25-44
 //   Light::make_point_light/area_light    light.cuh:70-84
@@ -30,15 +32,57 @@
 #include <vector>
 
 #include "../rtcuda_amd.h"
+#include "matrix4x4.hpp"
+#include "ply.hpp"
+#include "transform.hpp"
 
+// vec3.cuh:4-147, host side.  Arithmetic forms are the reference's where they round differently from the obvious
+// spelling: division by a scalar multiplies by the fp32 reciprocal (vec3.cuh:56-59, :123-129), unit_vector multiplies
+// by 1 / length (:131-134), Vec3 / Vec3 is a true per-component divide (:44-46), refract takes its ratio as double.
 struct Vec3 {
     Vec3() {}
     constexpr Vec3(float x, float y, float z) : x(x), y(y), z(z) {}
     constexpr Vec3(float xyz) : x(xyz), y(xyz), z(xyz) {}
     static Vec3 make_zeros() { return Vec3(0.f, 0.f, 0.f); }
     static Vec3 make_ones() { return Vec3(1.f, 1.f, 1.f); }
+
+    Vec3 operator-() const { return Vec3(-x, -y, -z); }
+    Vec3 &operator+=(const Vec3 &b) { x += b.x; y += b.y; z += b.z; return *this; }
+    Vec3 &operator-=(const Vec3 &b) { x -= b.x; y -= b.y; z -= b.z; return *this; }
+    Vec3 &operator*=(const Vec3 &b) { x *= b.x; y *= b.y; z *= b.z; return *this; }
+    Vec3 &operator/=(const Vec3 &b) { x /= b.x; y /= b.y; z /= b.z; return *this; }
+    Vec3 &operator*=(float t) { x *= t; y *= t; z *= t; return *this; }
+    Vec3 &operator/=(float t) { return *this *= 1.f / t; }
+
+    float max() const { return fmaxf(fmaxf(x, y), z); }
+    float length_squared() const { return x * x + y * y + z * z; }
+    float length() const { return sqrtf(length_squared()); }
+    Vec3 unit_vector() const { Vec3 r = *this; r.unit_vector_inplace(); return r; }
+    void unit_vector_inplace() { *this *= 1.f / length(); }
+    void sqrt_inplace() { x = sqrtf(x); y = sqrtf(y); z = sqrtf(z); }
+
     float x, y, z;
 };
+inline Vec3 operator+(const Vec3 &a, const Vec3 &b) { return Vec3(a.x + b.x, a.y + b.y, a.z + b.z); }
+inline Vec3 operator-(const Vec3 &a, const Vec3 &b) { return Vec3(a.x - b.x, a.y - b.y, a.z - b.z); }
+inline Vec3 operator*(const Vec3 &a, const Vec3 &b) { return Vec3(a.x * b.x, a.y * b.y, a.z * b.z); }
+inline Vec3 operator/(const Vec3 &a, const Vec3 &b) { return Vec3(a.x / b.x, a.y / b.y, a.z / b.z); }
+inline Vec3 operator*(const Vec3 &v, float t) { return Vec3(v.x * t, v.y * t, v.z * t); }
+inline Vec3 operator*(float t, const Vec3 &v) { return v * t; }
+inline Vec3 operator/(const Vec3 &v, float t) { return v * (1.f / t); }
+inline float dot(const Vec3 &a, const Vec3 &b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline Vec3 cross(const Vec3 &a, const Vec3 &b) {
+    return Vec3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+inline Vec3 reflect(const Vec3 &v, const Vec3 &unit_n) { return v - 2.f * dot(v, unit_n) * unit_n; }
+// vec3.cuh:82-86 (the double ratio narrows to float at the scalar * Vec3 product); :76-80 derives cos_theta itself
+inline Vec3 refract(const Vec3 &unit_v, const Vec3 &unit_n, double eta_ratio, float cos_theta) {
+    const Vec3 parallel = (float)eta_ratio * (unit_v + cos_theta * unit_n);
+    return parallel + -sqrtf(1.f - parallel.length_squared()) * unit_n;
+}
+inline Vec3 refract(const Vec3 &unit_v, const Vec3 &unit_n, double eta_ratio) {
+    return refract(unit_v, unit_n, eta_ratio, (float)(double)-dot(unit_v, unit_n));
+}
 
 struct Triangle {
     Triangle() {}

@@ -27,7 +27,7 @@ FLAG_DETERMINISTIC = 2
 EXPORTS = [
     "rt_scene_create", "rt_scene_destroy", "rt_scene_info", "rt_scene_build_info", "rt_camera_make", "rt_render",
     "rt_render_shard", "rt_render_shard_fixed", "rt_post_process", "rt_post_process_fixed", "rt_trace_closest", "rt_trace_any", "rt_xorwow_states",
-    "rt_measure_copy_bandwidth", "rt_last_error", "rt_version",
+    "rt_measure_copy_bandwidth", "rt_calibrate_valu", "rt_last_error", "rt_version",
 ]
 
 
@@ -115,6 +115,7 @@ def lib():
     L.rt_trace_any.argtypes = [vp, ci, vp, vp, vp, vp, vp]
     L.rt_xorwow_states.argtypes = [ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, ci, vp, vp]
     L.rt_measure_copy_bandwidth.argtypes = [ctypes.c_int64, ci, ctypes.POINTER(ctypes.c_double)]
+    L.rt_calibrate_valu.argtypes = [ci, ci, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
     _lib = L
     return L
 
@@ -250,6 +251,13 @@ def measure_copy_bandwidth(nbytes: int = 1 << 30, reps: int = 5) -> float:
     out = ctypes.c_double(0.0)
     _check(lib().rt_measure_copy_bandwidth(nbytes, reps, ctypes.byref(out)), "rt_measure_copy_bandwidth")
     return out.value
+
+
+def calibrate_valu(waves_per_simd: int = 4, iters: int = 20000):
+    """(lane-operations/s the vector ALUs sustain on independent v_fma_f32, wave-instructions per launch)."""
+    rate, winstr = ctypes.c_double(0.0), ctypes.c_double(0.0)
+    _check(lib().rt_calibrate_valu(waves_per_simd, iters, ctypes.byref(rate), ctypes.byref(winstr)), "rt_calibrate_valu")
+    return rate.value, winstr.value
 
 
 def render(width: int, height: int, num_samples: int, max_bounces: int, camera: np.ndarray, scene: Scene,

@@ -1566,6 +1566,29 @@ __global__ void k_copy_f4(const float4 *__restrict__ src, float4 *__restrict__ d
     for (; i < n; i += stride) dst[i] = src[i];
 }
 
+// VALU issue calibration: every wave issues `iters` x 16 independent v_fma_f32 (inline asm, so the compiler neither
+// packs nor folds them).  Launched with `waves_per_simd` waves on every SIMD it measures what the vector ALU of this
+// chip sustains in lane-operations per second -- the roof the render kernels (VALU-issue-bound) are priced against --
+// and, run under the PMC set of tools/, what SQ_ACTIVE_INST_VALU / SQ_BUSY_CYCLES read at that known rate.
+__global__ void __launch_bounds__(256) k_valu_calibrate(float *__restrict__ out, int iters, float seed) {
+    float a0 = seed, a1 = seed + 1.f, a2 = seed + 2.f, a3 = seed + 3.f, a4 = seed + 4.f, a5 = seed + 5.f, a6 = seed + 6.f,
+          a7 = seed + 7.f, a8 = seed + 8.f, a9 = seed + 9.f, a10 = seed + 10.f, a11 = seed + 11.f, a12 = seed + 12.f,
+          a13 = seed + 13.f, a14 = seed + 14.f, a15 = seed + 15.f;
+    const float m = 0.999f + seed * 1e-9f, c = 1e-3f;
+    for (int k = 0; k < iters; k++) {
+        __asm__ volatile(
+            "v_fma_f32 %0, %0, %16, %17\n v_fma_f32 %1, %1, %16, %17\n v_fma_f32 %2, %2, %16, %17\n v_fma_f32 %3, %3, %16, %17\n"
+            "v_fma_f32 %4, %4, %16, %17\n v_fma_f32 %5, %5, %16, %17\n v_fma_f32 %6, %6, %16, %17\n v_fma_f32 %7, %7, %16, %17\n"
+            "v_fma_f32 %8, %8, %16, %17\n v_fma_f32 %9, %9, %16, %17\n v_fma_f32 %10, %10, %16, %17\n v_fma_f32 %11, %11, %16, %17\n"
+            "v_fma_f32 %12, %12, %16, %17\n v_fma_f32 %13, %13, %16, %17\n v_fma_f32 %14, %14, %16, %17\n v_fma_f32 %15, %15, %16, %17\n"
+            : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(a8), "+v"(a9), "+v"(a10),
+              "+v"(a11), "+v"(a12), "+v"(a13), "+v"(a14), "+v"(a15)
+            : "v"(m), "v"(c));
+    }
+    float r = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7)) + ((a8 + a9) + (a10 + a11)) + ((a12 + a13) + (a14 + a15));
+    if (r == 12345.678f) out[blockIdx.x * blockDim.x + threadIdx.x] = r;  // (never true: keeps the chain alive)
+}
+
 // ============================================================================ device BVH build (LBVH)
 // a BVH build on the GPU.  Optional (RT_BVH_BUILDER=lbvh): a linear BVH --
 // 30-bit Morton codes of the triangle centroids, sorted, binary radix tree by longest common prefix
@@ -1929,6 +1952,8 @@ struct Context {
     bool rng_valid = false;
     uint32_t *rng_backup = nullptr;  // 6 x n words
     std::vector<hipEvent_t> timing_events;
+    int *d_over = nullptr;  // overflow part of the traversal stacks of this context's grids (ensure_overflow)
+    int over_levels = 0;
     std::mutex busy;  // a context (pools, counters, events) serves one render at a time
 };
 std::mutex g_ctx_mutex;
@@ -1984,41 +2009,22 @@ int grid_for(int n) { return (n + kBlock - 1) / kBlock; }
         else hipLaunchKernelGGL((k_trace<MODE, false>), grid, dim3(kBlock), lds, stream, __VA_ARGS__);       \
     } while (0)
 
-// Global overflow part of the traversal stacks: `levels` entries for each of kOverStride lanes, one
-// buffer per device, grown on demand (never shrunk).  Shared by concurrent renders on a device: every
-// lane of every trace grid indexes its own column (grids are at most kOverStride lanes), and a lane
-// only reads back what it pushed itself.
-struct OverflowBuf {
-    int device = -1;
-    int levels = 0;
-    int *ptr = nullptr;
-};
-std::mutex g_over_mutex;
-std::vector<OverflowBuf> g_over;
-int ensure_overflow(int levels, int **out) {
-    int dev = 0;
-    HIP_TRY(hipGetDevice(&dev));
+// Global overflow part of the traversal stacks: `levels` entries for each of kOverStride lanes.  Every OWNER of
+// concurrently running grids has its own buffer -- a render context (one render at a time: Context::busy), or one
+// call of a stage-level test entry point -- because a lane indexes its column by its position in ITS grid only:
+// two grids in flight on one device (RT_SPLIT sub-shards, host threads rendering different shard sizes) would
+// otherwise push to and pop from the same columns.  Grown on demand under the owner's lock, never shrunk.
+int ensure_overflow(int *&ptr, int &have_levels, int levels) {
     levels = std::max(levels, 1);
-    std::lock_guard<std::mutex> lock(g_over_mutex);
-    for (auto &b : g_over)
-        if (b.device == dev) {
-            if (b.levels < levels) {
-                int *np = nullptr;
-                HIP_TRY(hipMalloc((void **)&np, sizeof(int) * (size_t)levels * kOverStride));
-                // the old buffer may still be in use by a concurrent render: leak-free swap is not worth
-                // the bookkeeping; it is released at process exit
-                b.ptr = np;
-                b.levels = levels;
-            }
-            *out = b.ptr;
-            return 0;
-        }
-    OverflowBuf b;
-    b.device = dev;
-    b.levels = levels;
-    HIP_TRY(hipMalloc((void **)&b.ptr, sizeof(int) * (size_t)levels * kOverStride));
-    g_over.push_back(b);
-    *out = b.ptr;
+    if (ptr && have_levels >= levels) return 0;
+    if (ptr) {
+        HIP_TRY(hipDeviceSynchronize());  // (the owner is idle; this only guards against a caller's stray stream)
+        (void)hipFree(ptr);
+        ptr = nullptr;
+        have_levels = 0;
+    }
+    HIP_TRY(hipMalloc((void **)&ptr, sizeof(int) * (size_t)levels * kOverStride));
+    have_levels = levels;
     return 0;
 }
 
@@ -2056,6 +2062,8 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
     if (width <= 0 || height <= 0 || spp <= 0 || max_bounces < 0) return fail("rt_render_shard: bad dimensions");
     if (shard_count <= 0 || kW % shard_count != 0 || shard_index < 0 || shard_index >= shard_count)
         return fail("rt_render_shard: shard_count must divide 1048576 and 0 <= shard_index < shard_count");
+    if ((long long)width * height > (long long)(0x7fffffff / 3))  // framebuffer values are indexed with 32 bits
+        return fail("rt_render_shard: width*height exceeds 715827882 pixels");
     long long cam_end = (long long)width * height * spp;
     if (cam_end + 13LL * kW >= (1LL << 31))  // the reference's int32 camera_ray ids (render.cuh:370-371,440)
         return fail("rt_render_shard: width*height*spp exceeds the reference's int32 camera-ray range");
@@ -2087,8 +2095,10 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
     }
     const int stack_cap = std::min(kLdsStack, std::max(1, scene->stack_bound));
     const size_t lds_bytes = sizeof(int) * (size_t)kBlock * (size_t)(stack_cap + 1);  // stack + pending
-    int *d_over = nullptr;
-    if (ensure_overflow(scene->stack_bound - stack_cap, &d_over)) return 1;
+    // one buffer serves the context's k_trace and k_paths grids (never in flight together); k_paths keeps fewer
+    // entries in LDS, so it needs the deeper overflow
+    if (ensure_overflow(c.d_over, c.over_levels, scene->stack_bound - std::min(stack_cap, std::min(8, std::max(1, scene->stack_bound))))) return 1;
+    int *const d_over = c.d_over;
     hipLaunchKernelGGL(k_pool_init, dim3(grid_for(n)), dim3(kBlock), 0, st, c.pools, n, max_bounces);
     HIP_TRY(hipGetLastError());
 
@@ -2110,9 +2120,16 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
     ap.dpy = (ap.w_over_spp > 0 && width < 32768 && height < 32768) ? ap.w_over_spp / width : -1;
     const bool lds_tables = scene->n_mats <= kLdsTable && scene->n_lights <= kLdsTable;
 
-    hipEvent_t ev_start, ev_stop;
-    HIP_TRY(hipEventCreate(&ev_start));
-    HIP_TRY(hipEventCreate(&ev_stop));
+    struct EventPair {  // destroyed on every return path
+        hipEvent_t a = nullptr, b = nullptr;
+        ~EventPair() {
+            if (a) (void)hipEventDestroy(a);
+            if (b) (void)hipEventDestroy(b);
+        }
+    } frame_events;
+    HIP_TRY(hipEventCreate(&frame_events.a));
+    HIP_TRY(hipEventCreate(&frame_events.b));
+    const hipEvent_t ev_start = frame_events.a, ev_stop = frame_events.b;
     HIP_TRY(hipEventRecord(ev_start, st));
 
     // Rounds are enqueued in batches; after each batch the counters are snapshotted into pinned
@@ -2172,8 +2189,7 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
         int adv_batch = 30;  // lanes waiting for the ADV block before it runs (measured: flat 28..36)
         if (const char *e = getenv("RT_ADV_BATCH")) adv_batch = std::max(1, std::min(64, atoi(e)));
         const int paths_cap = std::min(8, std::max(1, scene->stack_bound));
-        int *d_over2 = nullptr;
-        if (ensure_overflow(scene->stack_bound - paths_cap, &d_over2)) return 1;
+        int *const d_over2 = d_over;
         size_t lds_paths = sizeof(int) * (size_t)kBlock * (size_t)(paths_cap + 22) + (lds_tables ? sizeof(float) * (size_t)((scene->tab_dwords + 3) & ~3) : 0) +
                            sizeof(Camera) + sizeof(AdvanceParams);
         bool majority = true;
@@ -2354,8 +2370,6 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
 #endif
     float ms_total = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms_total, ev_start, ev_stop));
-    HIP_TRY(hipEventDestroy(ev_start));
-    HIP_TRY(hipEventDestroy(ev_stop));
     std::vector<DWaveRow> h_rows((size_t)c.n_rows);
     HIP_TRY(hipMemcpy(h_rows.data(), c.d_rows, sizeof(DWaveRow) * (size_t)c.n_rows, hipMemcpyDeviceToHost));
     unsigned long long fin[C_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -2696,6 +2710,7 @@ int rt_render_shard_fixed(const rt_scene *scene, const rt_camera *camera, int wi
 
 int rt_post_process_fixed(const int64_t *d_sum_fixed, float *d_rgb_out, int num_pixels, int num_samples, void *stream) {
     if (!d_sum_fixed || !d_rgb_out || num_pixels <= 0 || num_samples <= 0) return fail("rt_post_process_fixed: bad argument");
+    if (num_pixels > 0x7fffffff / 3) return fail("rt_post_process_fixed: more than 715827882 pixels");
     int nv = num_pixels * 3;
     float inv = 1.f / (float)num_samples;
     hipLaunchKernelGGL(k_post_process_fixed, dim3((nv + 255) / 256), dim3(256), 0, (hipStream_t)stream,
@@ -2706,6 +2721,7 @@ int rt_post_process_fixed(const int64_t *d_sum_fixed, float *d_rgb_out, int num_
 
 int rt_post_process(float *d_rgb, int num_pixels, int num_samples, void *stream) {
     if (!d_rgb || num_pixels <= 0 || num_samples <= 0) return fail("rt_post_process: bad argument");
+    if (num_pixels > 0x7fffffff / 3) return fail("rt_post_process: more than 715827882 pixels");
     int nv = num_pixels * 3;
     float inv = 1.f / (float)num_samples;
     hipLaunchKernelGGL(k_post_process, dim3((nv + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_rgb, nv, inv);
@@ -2717,6 +2733,7 @@ int rt_render(const rt_scene *scene, const rt_camera *camera, int width, int hei
               int max_bounces, uint64_t seed, uint32_t flags, float *out_rgb, rt_stats *stats) {
     if (!out_rgb) return fail("rt_render: out_rgb is null");
     if (width <= 0 || height <= 0) return fail("rt_render: bad dimensions");
+    if ((long long)width * height > (long long)(0x7fffffff / 3)) return fail("rt_render: width*height exceeds 715827882 pixels");
     const bool fixed = (flags & RT_FLAG_DETERMINISTIC) != 0;
     const size_t n_values = 3 * (size_t)width * height;
     const size_t bytes = sizeof(float) * n_values;
@@ -2770,7 +2787,8 @@ int rt_trace_closest(const rt_scene *scene, int n, const float *origin_xyz, cons
     const int test_grid = std::min(grid_for(n), 2048);
     const int stack_cap = std::min(kLdsStack, std::max(1, scene->stack_bound));
     int *d_over = nullptr;
-    if (ensure_overflow(scene->stack_bound - stack_cap, &d_over)) return 1;
+    int over_levels = 0;
+    if (ensure_overflow(d_over, over_levels, scene->stack_bound - stack_cap)) return 1;
     {
         TraceParams tp{};
         tp.total = n;
@@ -2792,7 +2810,7 @@ int rt_trace_closest(const rt_scene *scene, int n, const float *origin_xyz, cons
     HIP_TRY(hipMemcpy(u, d_u, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(v, d_v, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost));
     (void)hipFree(d_o); (void)hipFree(d_d); (void)hipFree(d_tm); (void)hipFree(d_t);
-    (void)hipFree(d_u); (void)hipFree(d_v); (void)hipFree(d_h);
+    (void)hipFree(d_u); (void)hipFree(d_v); (void)hipFree(d_h); (void)hipFree(d_over);
     return 0;
 }
 
@@ -2820,7 +2838,8 @@ int rt_trace_any(const rt_scene *scene, int n, const float *origin_xyz, const fl
     const int test_grid = std::min(grid_for(n), 2048);
     const int stack_cap = std::min(kLdsStack, std::max(1, scene->stack_bound));
     int *d_over = nullptr;
-    if (ensure_overflow(scene->stack_bound - stack_cap, &d_over)) return 1;
+    int over_levels = 0;
+    if (ensure_overflow(d_over, over_levels, scene->stack_bound - stack_cap)) return 1;
     {
         TraceParams tp{};
         tp.total = n;
@@ -2836,7 +2855,7 @@ int rt_trace_any(const rt_scene *scene, int n, const float *origin_xyz, const fl
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(occluded, d_occ, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost));
     (void)hipFree(d_o); (void)hipFree(d_d); (void)hipFree(d_tm); (void)hipFree(d_e); (void)hipFree(d_occ);
-   
+    (void)hipFree(d_over);
     return 0;
 }
 
@@ -2890,6 +2909,38 @@ int rt_measure_copy_bandwidth(int64_t bytes, int reps, double *out_bytes_per_s) 
     (void)hipFree(a);
     (void)hipFree(b);
     *out_bytes_per_s = best;
+    return 0;
+}
+
+int rt_calibrate_valu(int waves_per_simd, int iters, double *out_lane_ops_per_s, double *out_wave_instr) {
+    if (waves_per_simd < 1 || waves_per_simd > 8 || iters < 1 || !out_lane_ops_per_s) return fail("rt_calibrate_valu: bad argument");
+    int dev = 0, cus = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    // one 256-thread workgroup = one wave on each of a CU's four SIMDs
+    const int blocks = cus * waves_per_simd;
+    float *d_out = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_out, sizeof(float) * (size_t)blocks * 256));
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    double best = 0.0;
+    for (int r = 0; r < 4; r++) {
+        HIP_TRY(hipEventRecord(e0, nullptr));
+        hipLaunchKernelGGL(k_valu_calibrate, dim3(blocks), dim3(256), 0, nullptr, d_out, iters, 1.f);
+        HIP_TRY(hipEventRecord(e1, nullptr));
+        HIP_TRY(hipEventSynchronize(e1));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+        const double lane_ops = (double)blocks * 256.0 * 16.0 * (double)iters;
+        if (r > 0 && ms > 0.f) best = std::max(best, lane_ops / (ms * 1e-3));
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventDestroy(e0));
+    HIP_TRY(hipEventDestroy(e1));
+    (void)hipFree(d_out);
+    *out_lane_ops_per_s = best;
+    if (out_wave_instr) *out_wave_instr = (double)blocks * 4.0 * 16.0 * (double)iters;  // v_fma_f32 wave-instructions per launch
     return 0;
 }
 

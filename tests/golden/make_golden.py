@@ -17,7 +17,9 @@ from oracle.oracle import Oracle, build  # noqa: E402
 from rtcuda_amd import scenes  # noqa: E402
 
 CASES = [("matte", 32, 32, 16), ("full_bsdf", 48, 27, 8), ("sixteen_lights", 40, 30, 4), ("matte", 1, 1, 3),
-         ("full_bsdf", 7, 5, 1)]
+         ("full_bsdf", 7, 5, 1),
+         # more than W = 1 048 576 camera rays: 2.25 / 2.29 generations, so the product's persistent kernel does the work
+         ("full_bsdf", 128, 72, 256), ("matte", 100, 60, 400)]
 
 
 def main():

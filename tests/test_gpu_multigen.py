@@ -1,0 +1,233 @@
+"""GPU parity of the PERSISTENT kernel (k_paths) against the CPU oracle.  Run with -m gpu.
+
+A render of w*h*spp <= W = 1 048 576 camera rays has one generation only; that generation is the
+final one and runs on the lockstep round pipeline (k_advance + k_trace), so k_paths parks every slot
+at once.  Every case here has MORE than W camera rays -- 2 to 4.7 generations -- so that all but the
+last generation run inside k_paths: its ADV / GEN / ANY / CLOSEST blocks, the pixel stepping of
+gen() for generation >= 1 (add-and-carry, W / spp, 64-bit divide), the non-lockstep Russian-roulette
+re-roll chain, the idle skip, the GEN / ADV routing at max_bounces, and the small-shard build
+(MIN_WAVES = 2) that every rank of an 8-GPU run launches.  Reference lines being matched:
+render.cuh:84-137 (init), :139-248 (mat), :250-275 (gen), :278-328 (ah / ch), :428-449 (host loop).
+
+Bar: integer event totals EQUAL to the oracle's, image RMS < 2e-6 per channel (only the order of
+the float atomics differs; north-star tolerance 1e-4), fixed-point sums bit-equal between shardings.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import default_camera
+
+pytestmark = pytest.mark.gpu
+
+W = 1 << 20
+
+
+@pytest.fixture(scope="module")
+def api():
+    from rtcuda_amd import api as _api
+    _api.lib()  # raises if the HIP library is missing: there is no fallback
+    return _api
+
+
+_scene_cache = {}
+
+
+def _scenes(api, oracle, variant):
+    """(GPU scene, oracle scene) of a BASELINE scene variant, built once per module."""
+    if variant not in _scene_cache:
+        from rtcuda_amd import scenes
+        arrays = scenes.cornell_bunny(variant)
+        _scene_cache[variant] = (api.Scene(arrays), oracle.scene(arrays))
+    return _scene_cache[variant]
+
+
+def _rms(a, b):
+    """Per-channel RMS difference.  The reference's estimator itself yields a NaN contribution now and then (first
+    seen: full_bsdf 300x200x48, pixel (184, 12) -- a glass path; render.cuh has no guard and SURVEY Appendix A.4
+    names one such source); a NaN pixel must be a NaN pixel on BOTH sides and is left out of the RMS."""
+    na, nb = np.isnan(a), np.isnan(b)
+    assert np.array_equal(na, nb), (np.argwhere(na != nb)[:8], int(na.sum()), int(nb.sum()))
+    assert na.sum() <= max(3, 1e-5 * a.size)
+    d = np.where(na, 0.0, a.astype(np.float64) - np.where(nb, 0.0, b.astype(np.float64)))
+    return np.sqrt(np.mean(d ** 2, axis=(0, 1)))
+
+
+def _max_abs(a, b):
+    m = ~np.isnan(b)
+    return np.abs(a[m] - b[m]).max()
+
+
+def _assert_same_events(st_g, st_c, n_rays):
+    assert st_g["camera_rays"] == n_rays
+    assert st_g["shade_events"] == st_c["sum_mat"]
+    assert st_g["any_rays"] == st_c["sum_ah"]
+    assert st_g["emission_adds"] == st_c["emission_adds"]
+    assert st_g["shadow_adds"] == st_c["ah_adds"]
+    assert st_g["rr_draws"] == st_c["rr_draws"]
+    assert st_c["ch_adds"] == 0  # the one ray kind the product does not trace never contributes (Appendix A.3)
+
+
+def _generations(w, h, spp):
+    return -(-(w * h * spp) // W)
+
+
+MULTIGEN_CASES = [
+    # variant, w, h, spp, max_bounces, seed
+    ("full_bsdf", 480, 270, 32, 10, 1),       # 3.96 generations; spp | W and 480 | W/spp ... dpx = 128: carries
+    ("full_bsdf", 300, 200, 48, 10, 1),       # spp does not divide W: 64-bit divide path at generation >= 1
+    ("full_bsdf", 257, 130, 64, 10, 1),       # odd width, spp | W: add-and-carry pixel stepping (dpx = 193)
+    ("full_bsdf", 512, 512, 9, 0, 1),         # no bounce at all: every closest hit routes straight to GEN / emission
+    ("full_bsdf", 512, 512, 9, 1, 1),
+    ("full_bsdf", 400, 300, 20, 20, 1),       # long Russian-roulette chains in the non-lockstep re-roll loop
+    ("full_bsdf", 480, 270, 17, 10, 12345),   # another seed, odd spp
+    ("matte", 256, 256, 40, 10, 1),           # C1's scene
+    ("four_bunnies", 480, 270, 20, 10, 1),    # C4's geometry (deep BVH: global stack overflow in k_paths)
+    ("sixteen_lights", 480, 270, 20, 10, 1),  # C5's lights
+]
+
+
+@pytest.mark.parametrize("variant,w,h,spp,max_bounces,seed", MULTIGEN_CASES)
+def test_persistent_kernel_matches_oracle(api, oracle, variant, w, h, spp, max_bounces, seed):
+    assert w * h * spp > W, "these cases must run k_paths for real"
+    gpu, cpu = _scenes(api, oracle, variant)
+    img_c, _, st_c = cpu.render(default_camera(oracle, w / h), w, h, spp, max_bounces=max_bounces, seed=seed,
+                                threads=os.cpu_count() or 8)
+    img_g, st_g = gpu.render(api.make_camera(aspect=w / h), w, h, spp, max_bounces=max_bounces, seed=seed)
+    _assert_same_events(st_g, st_c, w * h * spp)
+    # the product's schedule: one persistent launch + the lockstep rounds of the final generation only
+    assert st_g["iterations"] <= max_bounces + 2
+    assert st_c["iterations"] > (max_bounces + 1) * (_generations(w, h, spp) - 1)
+    rms = _rms(img_g, img_c)
+    assert rms.max() < 2e-6, rms
+    assert _max_abs(img_g, img_c) < 1e-4
+
+
+def test_persistent_kernel_deterministic_mode_matches_oracle(api, oracle):
+    """RT_FLAG_DETERMINISTIC over 2.5 generations: bit-reproducible, and equal to the oracle within the
+    fixed-point quantum."""
+    w, h, spp = 256, 256, 40
+    gpu, cpu = _scenes(api, oracle, "matte")
+    cam = api.make_camera(aspect=1.0)
+    a, st_a = gpu.render(cam, w, h, spp, flags=api.FLAG_DETERMINISTIC)
+    b, st_b = gpu.render(cam, w, h, spp, flags=api.FLAG_DETERMINISTIC)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    img_c, _, st_c = cpu.render(default_camera(oracle, 1.0), w, h, spp, threads=os.cpu_count() or 8)
+    _assert_same_events(st_a, st_c, w * h * spp)
+    assert _rms(a, img_c).max() < 2e-6
+
+
+def test_small_shard_build_of_the_persistent_kernel_matches_oracle(api, oracle):
+    """8 slot-range shards of a 3.96-generation frame: each shard is what one rank of an 8-GPU run renders, and
+    launches the MIN_WAVES = 2 build of k_paths (gen() inside ADV, LDS top of the tree).  Per-shard event totals
+    and raw sums against the oracle's render of the same slot range; the shards' fixed-point sums add up to
+    EXACTLY the unsharded frame."""
+    import torch
+    w, h, spp = 480, 270, 32
+    shards = 8
+    gpu, cpu = _scenes(api, oracle, "full_bsdf")
+    cam_g, cam_c = api.make_camera(aspect=w / h), default_camera(oracle, w / h)
+    full = torch.zeros(h * w * 3, dtype=torch.int64, device="cuda")
+    st_full = gpu.render_shard_fixed(cam_g, w, h, spp, 0, 1, full.data_ptr())
+    acc = torch.zeros_like(full)
+    tot = {k: 0 for k in ("camera_rays", "shade_events", "any_rays", "emission_adds", "shadow_adds", "rr_draws")}
+    n = W // shards
+    for r in range(shards):
+        part = torch.zeros(h * w * 3, dtype=torch.float32, device="cuda")
+        st = gpu.render_shard(cam_g, w, h, spp, r, shards, part.data_ptr())
+        gpu.render_shard_fixed(cam_g, w, h, spp, r, shards, acc.data_ptr())
+        for k in tot:
+            tot[k] += st[k]
+        if r in (0, 5):  # the oracle on the same slot range (two shards keep the CPU time down)
+            _, raw_c, st_c = cpu.render(cam_c, w, h, spp, slot_lo=r * n, slot_hi=(r + 1) * n,
+                                        threads=os.cpu_count() or 8)
+            # (the oracle's shard run stops when ITS slots stop shading; the product's lockstep rounds do the same)
+            assert st["shade_events"] == st_c["sum_mat"] and st["any_rays"] == st_c["sum_ah"]
+            assert st["shadow_adds"] == st_c["ah_adds"] and st["rr_draws"] == st_c["rr_draws"]
+            got = part.cpu().numpy().reshape(h, w, 3)
+            assert np.allclose(got, raw_c, rtol=2e-5, atol=1e-6, equal_nan=True)
+    torch.cuda.synchronize()
+    for k in tot:
+        assert tot[k] == st_full[k], k
+    assert torch.equal(acc, full)
+    img_c, _, st_c = cpu.render(cam_c, w, h, spp, threads=os.cpu_count() or 8)
+    assert tot["shade_events"] == st_c["sum_mat"] and tot["any_rays"] == st_c["sum_ah"]
+    out = torch.zeros(h * w * 3, dtype=torch.float32, device="cuda")
+    api.post_process_fixed(acc.data_ptr(), out.data_ptr(), w * h, spp)
+    torch.cuda.synchronize()
+    assert _rms(out.cpu().numpy().reshape(h, w, 3), img_c).max() < 2e-6
+
+
+def test_two_and_four_shards_sum_exactly(api, oracle):
+    import torch
+    w, h, spp = 300, 200, 48
+    gpu, _ = _scenes(api, oracle, "full_bsdf")
+    cam = api.make_camera(aspect=w / h)
+    full = torch.zeros(h * w * 3, dtype=torch.int64, device="cuda")
+    gpu.render_shard_fixed(cam, w, h, spp, 0, 1, full.data_ptr())
+    for shards in (2, 4):
+        acc = torch.zeros_like(full)
+        for r in range(shards):
+            gpu.render_shard_fixed(cam, w, h, spp, r, shards, acc.data_ptr())
+        torch.cuda.synchronize()
+        assert torch.equal(acc, full)
+
+
+def test_round_pipeline_and_scheduling_variants_agree_over_generations(api, oracle, monkeypatch):
+    """The frame as one persistent launch (default), as one launch per round (RT_PERSISTENT=0), and the scheduling
+    knobs of k_paths are the same estimator over several generations: equal event totals, same image."""
+    w, h, spp = 400, 300, 20  # 2.29 generations
+    gpu, cpu = _scenes(api, oracle, "full_bsdf")
+    cam = api.make_camera(aspect=w / h)
+    img_p, st_p = gpu.render(cam, w, h, spp)
+    keys = ("camera_rays", "shade_events", "closest_rays", "any_rays", "emission_adds", "shadow_adds", "rr_draws")
+    monkeypatch.setenv("RT_PERSISTENT", "0")
+    img_r, st_r = gpu.render(cam, w, h, spp)
+    monkeypatch.delenv("RT_PERSISTENT")
+    for k in keys:
+        assert st_p[k] == st_r[k], k
+    assert st_r["iterations"] > st_p["iterations"]
+    assert _rms(img_p, img_r).max() < 2e-6
+    for env in ({"RT_MAJORITY": "0"}, {"RT_ADV_BATCH": "7", "RT_GEN_BATCH": "1"}, {"RT_PRIO_ROTATE": "0"},
+                {"RT_PATHS_BLOCKS": "256"}, {"RT_SPLIT": "2"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        img_m, st_m = gpu.render(cam, w, h, spp)
+        for k in env:
+            monkeypatch.delenv(k)
+        for k in keys:
+            assert st_m[k] == st_p[k], (env, k)
+        assert _rms(img_m, img_p).max() < 2e-6, env
+
+
+def test_concurrent_sub_shards_keep_their_own_overflow_stacks(api, oracle, monkeypatch):
+    """RT_SPLIT=2 runs two k_paths grids at once on one device.  The deep four-bunny tree overflows the 8 LDS
+    stack entries of k_paths routinely, so the grids must not share overflow columns."""
+    w, h, spp = 480, 270, 20
+    gpu, _ = _scenes(api, oracle, "four_bunnies")
+    cam = api.make_camera(aspect=w / h)
+    img_1, st_1 = gpu.render(cam, w, h, spp)
+    monkeypatch.setenv("RT_SPLIT", "2")
+    img_2, st_2 = gpu.render(cam, w, h, spp)
+    monkeypatch.delenv("RT_SPLIT")
+    for k in ("camera_rays", "shade_events", "closest_rays", "any_rays", "emission_adds", "shadow_adds", "rr_draws"):
+        assert st_1[k] == st_2[k], k
+    assert _rms(img_1, img_2).max() < 2e-6
+
+
+GOLDEN = np.load(os.path.join(os.path.dirname(__file__), "golden", "render_goldens.npz"))
+
+
+@pytest.mark.parametrize("variant,w,h,spp", [("full_bsdf", 128, 72, 256), ("matte", 100, 60, 400)])
+def test_multi_generation_render_matches_committed_golden(api, variant, w, h, spp):
+    """2.25- and 2.29-generation frames against the committed fixtures (no oracle at run time)."""
+    from rtcuda_amd import scenes
+    key = f"{variant}_{w}x{h}x{spp}"
+    sc = api.Scene(scenes.cornell_bunny(variant))
+    img, st = sc.render(api.make_camera(aspect=w / h), w, h, spp)
+    assert [st["shade_events"], st["any_rays"], st["emission_adds"], st["shadow_adds"], st["rr_draws"],
+            st["camera_rays"]] == GOLDEN[key + "_counts"].tolist()
+    ref = GOLDEN[key + "_img"].astype(np.float32)
+    assert _rms(img, ref).max() < 2e-6
+    assert _max_abs(img, ref) < 1e-4
