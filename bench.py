@@ -13,8 +13,16 @@ post-processes: total work is fixed, so "scaling" is "strong".
 
 Rank 0 prints ONE JSON line with the contract fields plus
   roofline      dominant kernel (k_paths: the whole asynchronous part of the frame in one persistent
-                launch) -- SURVEY 8d's algorithmic bytes per launch / its HIP-event duration, against
-                the 8 TB/s HBM peak; plus the device copy bandwidth measured in the same run
+                launch).  The kernel keeps rays, hit records and slot state in registers / LDS and gathers
+                a 5.7 MB scene from L2, so HBM cannot bind it (measured traffic: `hbm`); what binds it is
+                vector-ALU issue.  `bound` is therefore "valu": achieved = ACTIVE lane-operations per
+                second (SQ_INSTS_VALU x 64 x lane utilisation of the committed PMC pass of this command,
+                profiles/pmc_k_paths.json, / the launch duration measured live with HIP events), peak =
+                256 CUs x 4 SIMDs x 32 lanes x 2.4 GHz = 78.6 T lane-op/s (the 157.3 TFLOP/s fp32 vector
+                spec / 2), next to the rate a pure v_fma_f32 kernel sustains in the same run.  SURVEY 8d's
+                algorithmic bytes at the REFERENCE's record sizes are kept as `reference_equivalent_GBs`.
+  parity        (N = 1) the same scene at the CPU sample's spp rendered on the GPU and compared with the
+                oracle: integer event totals and image RMS
   cpu_baseline  the CPU oracle (a port of the reference's algorithm; the reference itself needs
                 nvcc + cuRAND + CUB and cannot be built here) timed on a bounded sample
 """
@@ -37,6 +45,8 @@ APPX_C = {  # scene: (NPc, TTc, NPa, TTa)
     "full_bsdf": (12.15, 4.09, 6.71, 5.83), "matte": (8.17, 3.32, 7.78, 6.10),
     "four_bunnies": (17.77, 4.84, 12.69, 6.78), "sixteen_lights": (8.31, 3.34, 10.87, 6.14)}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32 at 2.4 GHz; peak fp32 vector 157.3 TFLOP/s = 2 flop x 78.6 T lane-op/s
+VALU_PEAK_LANE_OPS = 256 * 4 * 32 * 2.4e9
 
 
 def closest_ray_bytes(np_c: float, tt_c: float) -> float:
@@ -66,7 +76,12 @@ def main():
                     help="accumulate in 64-bit fixed point (order-independent: the N-GPU image equals the 1-GPU image bit for bit)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--debug-flags", type=int, default=0, help="perf experiments only (results invalid)")
+    ap.add_argument("--allow-invalid", action="store_true", help="accept --debug-flags != 0 (the line is marked invalid)")
+    ap.add_argument("--no-parity", action="store_true", help="skip the GPU-vs-oracle parity block")
     args = ap.parse_args()
+    if args.debug_flags != 0 and not args.allow_invalid:
+        raise SystemExit("--debug-flags changes what the kernels do (e.g. 0x100 drops every framebuffer deposit): the "
+                         "number would be invalid.  Pass --allow-invalid to run anyway; the JSON line is then marked.")
 
     import numpy as np
     import torch
@@ -128,8 +143,13 @@ def main():
     t0 = time.perf_counter()
     agg = {"seconds_trace": 0.0, "closest_rays": 0, "launches_trace": 0,
            "seconds_advance": 0.0, "seconds_render": 0.0, "any_rays": 0, "shade_events": 0}
+    rays_per_rank = w * h * spp // world  # (every rank owns W / world slots; with spp | W / world exactly this many)
     for _ in range(args.steps):
         step()
+        if world == 1 and last_stats["camera_rays"] != w * h * spp:
+            raise SystemExit(f"timed step traced {last_stats['camera_rays']} camera rays, expected {w * h * spp}")
+        if world > 1 and abs(last_stats["camera_rays"] - rays_per_rank) > (1 << 20) // world:
+            raise SystemExit(f"rank {rank}: timed step traced {last_stats['camera_rays']} camera rays, expected ~{rays_per_rank}")
         for k in agg:
             agg[k] += last_stats[k]
     fence()
@@ -152,19 +172,24 @@ def main():
                                    f"{args.max_bounces} (BASELINE configs[1] when 1920x1080x256 full_bsdf)",
                        "scene": args.scene, "width": w, "height": h, "spp": spp, "max_bounces": args.max_bounces,
                        "parallelism": f"slot-shard x{world} + 1 RCCL reduce" if world > 1 else "1 GPU",
-                       "accumulation": "int64 fixed point (order-independent)" if args.deterministic else "fp32 atomics"},
+                       "accumulation": "int64 fixed point (order-independent)" if args.deterministic else "fp32 atomics",
+                       "debug_flags": args.debug_flags},
             "ms_per_frame": round(1e3 * elapsed / max(args.steps, 1), 3),
         }
+        if args.debug_flags != 0:
+            out["invalid"] = "debug_flags != 0: work was skipped inside the timed region"
+            out["value"] = None
         # ---- CPU baseline (rank 0, N = 1 only): the oracle on a bounded sample of the same workload
         np_c, tt_c, np_a, tt_a = APPX_C[args.scene]
         np_src = "SURVEY.md Appendix C"
+        out["parity"] = None
         if world == 1 and not args.no_cpu_baseline:
             from oracle.oracle import Oracle
             cores = max(1, min(os.cpu_count() or 1, 16))
             orc = Oracle("pinned")
             osc = orc.scene(arrays)
             ocam = orc.camera((0.5, 0.5, 1.5), (0.5, 0.5, 0.0), (0.0, 1.0, 0.0), 37.8, w / h)
-            _, _, ost = osc.render(ocam, w, h, args.cpu_spp, args.max_bounces, 1, threads=cores, collect_stats=True)
+            oimg, _, ost = osc.render(ocam, w, h, args.cpu_spp, args.max_bounces, 1, threads=cores, collect_stats=True)
             cpu_v = w * h * args.cpu_spp / ost["seconds_loop"] / 1e6
             out["cpu_baseline"] = {
                 "value": round(cpu_v, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
@@ -177,59 +202,104 @@ def main():
                 np_a = ost["ah_node_pairs"] / ost["ah_rays"]
                 tt_a = ost["ah_tri_tests"] / ost["ah_rays"]
                 np_src = f"oracle statistics of the cpu_baseline sample ({args.cpu_spp} spp)"
+            # ---- parity of THIS binary on THIS box: the sample frame on the GPU against the oracle -- its watertight
+            # mode for the strict comparison (equal integer event totals), the literal reference walk (the run just
+            # timed) beside it: that one loses about one accepted hit in 10^7 rays (tests/test_traversal_audit.py)
+            if not args.no_parity and args.debug_flags == 0:
+                gimg, gst = scene.render(cam, w, h, args.cpu_spp, max_bounces=args.max_bounces, seed=1)
+                wimg, _, wst = osc.set_watertight(True).render(ocam, w, h, args.cpu_spp, args.max_bounces, 1, threads=cores)
+                pairs = (("shade_events", "sum_mat"), ("any_rays", "sum_ah"), ("emission_adds", "emission_adds"),
+                         ("shadow_adds", "ah_adds"), ("rr_draws", "rr_draws"))
+
+                def rms_of(a, b):
+                    m = ~(np.isnan(a) | np.isnan(b))
+                    return float(np.sqrt(np.mean((a[m].astype(np.float64) - b[m]) ** 2)))
+                out["parity"] = {
+                    "frame": f"{w}x{h}x{args.cpu_spp} ({w * h * args.cpu_spp / (1 << 20):.1f} generations: all but the last "
+                             f"run in the persistent kernel)",
+                    "events_equal": all(gst[g] == wst[o] for g, o in pairs) and gst["camera_rays"] == w * h * args.cpu_spp,
+                    "events": {g: [int(gst[g]), int(wst[o])] for g, o in pairs},
+                    "rms": rms_of(gimg, wimg), "max_abs": float(np.nanmax(np.abs(gimg - wimg))),
+                    "nan_pixels_gpu_oracle": [int(np.isnan(gimg).any(axis=2).sum()), int(np.isnan(wimg).any(axis=2).sum())],
+                    "vs_literal_reference_walk": {
+                        "event_deltas": {g: int(gst[g]) - int(ost[o]) for g, o in pairs}, "rms": rms_of(gimg, oimg),
+                        "pixels_over_1e-4": int((np.nan_to_num(np.abs(gimg - oimg)).max(axis=2) > 1e-4).sum())},
+                    "tolerance": "north star: 1e-4 per-channel RMS; tests: equal event totals, RMS < 2e-6"}
+                if not out["parity"]["events_equal"] or out["parity"]["rms"] > 1e-4:
+                    out["invalid"] = "parity check failed: the GPU frame differs from the oracle"
+                # the timed frames must carry the same per-sample work as the oracle's sample (statistical guard)
+                for g, o in (("shade_events", "sum_mat"), ("any_rays", "sum_ah")):
+                    r_gpu = agg[g] / (float(w) * h * spp * args.steps)
+                    r_cpu = ost[o] / (float(w) * h * args.cpu_spp)
+                    if abs(r_gpu - r_cpu) > 0.005 * r_cpu:
+                        out["invalid"] = f"timed frames: {g} per sample {r_gpu:.4f} vs oracle sample {r_cpu:.4f}"
         else:
             out["cpu_baseline"] = None
-        # ---- roofline of the dominant kernel.  Default pipeline: ONE k_paths launch per frame (init + mat +
-        # gen + ch + ah of every slot as phases of a persistent kernel), so "per launch" = per frame and the
-        # algorithmic bytes are SURVEY 8d's whole-sample formula
-        #   B = 153 g + 49 (max_bounces + 1) g + 430 m + closest_bytes c + any_bytes a
-        # (g camera rays, m shade events, c / a closest- / any-hit rays, counted by the run itself).
-        # With RT_PERSISTENT=0 the dominant kernel is k_trace<MODE_POOL> (one launch per round) and only the
-        # two ray terms apply.
+        # ---- roofline of the dominant kernel.  Default pipeline: ONE k_paths launch per frame (init + mat + gen + ch +
+        # ah of every slot as phases of a persistent kernel), so "per launch" = per frame.
         if agg["launches_trace"] > 0 and agg["seconds_trace"] > 0:
             launches = agg["launches_trace"]
             persistent = launches == args.steps
+            kernel = "k_paths" if persistent else "k_trace<MODE_POOL>"
             c_per = agg["closest_rays"] / launches
             a_per = agg["any_rays"] / launches
             avg_s = agg["seconds_trace"] / launches
-            bytes_per_launch = closest_ray_bytes(np_c, tt_c) * c_per + any_ray_bytes(np_a, tt_a) * a_per
+            # context only: SURVEY 8d's algorithmic bytes at the REFERENCE's record sizes,
+            #   B = 153 g + 49 (max_bounces + 1) g + 430 m + closest_bytes c + any_bytes a
+            # -- bytes the reference streams through HBM every iteration and this design keeps on chip
+            ref_bytes = closest_ray_bytes(np_c, tt_c) * c_per + any_ray_bytes(np_a, tt_a) * a_per
             if persistent:
                 g_per = float(w) * h * spp / world
                 m_per = agg["shade_events"] / launches
-                bytes_per_launch += (153.0 + 49.0 * (args.max_bounces + 1)) * g_per + 430.0 * m_per
-            achieved = bytes_per_launch / avg_s / 1e9
-            out["roofline"] = {
-                "kernel": "k_paths" if persistent else "k_trace<MODE_POOL>", "bound": "hbm",
-                "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                "bytes_per_closest_ray": round(closest_ray_bytes(np_c, tt_c), 1),
-                "bytes_per_any_ray": round(any_ray_bytes(np_a, tt_a), 1), "np_tt_source": np_src,
-                "bytes_per_sample": round(bytes_per_launch / (float(w) * h * spp / world), 1) if persistent else None,
-                "closest_rays_per_launch": round(c_per, 1), "any_rays_per_launch": round(a_per, 1),
-                "avg_launch_us": round(avg_s * 1e6, 2), "launches": launches,
-                "stage_share_of_render": {
-                    "dominant": round(agg["seconds_trace"] / max(agg["seconds_render"], 1e-12), 4),
-                    "advance": round(agg["seconds_advance"] / max(agg["seconds_render"], 1e-12), 4)},
-                "grays_per_s": round((agg["closest_rays"] + agg["any_rays"]) / max(agg["seconds_trace"], 1e-12) / 1e9, 3),
-                "frac_note": "algorithmic bytes use the REFERENCE's record sizes (SURVEY 8d); this kernel keeps rays, hit "
-                             "records and slot state in registers / LDS and gathers the 5.7 MB BVH from L2, so the bytes "
-                             "it would have to stream at the reference's layouts exceed what HBM could deliver (frac > 1 "
-                             "means exactly that); the kernel is bound by VALU issue at ~50 % lane utilisation "
-                             "(profiles/r01_pmc.json), not by HBM -- `traffic` is the HBM traffic actually measured"}
-            try:  # the HBM denominator measured on the box in the same run (device float4 copy)
-                out["roofline"]["copy_bandwidth_measured_GBs"] = round(api.measure_copy_bandwidth(1 << 30, 5) / 1e9, 1)
+                ref_bytes += (153.0 + 49.0 * (args.max_bounces + 1)) * g_per + 430.0 * m_per
+            roof = {"kernel": kernel, "bound": "valu", "achieved": None, "peak": round(VALU_PEAK_LANE_OPS / 1e12, 2),
+                    "unit": "Tlane-op/s", "frac": None, "traffic": None,
+                    "avg_launch_us": round(avg_s * 1e6, 2), "launches": launches,
+                    "closest_rays_per_launch": round(c_per, 1), "any_rays_per_launch": round(a_per, 1),
+                    "grays_per_s": round((agg["closest_rays"] + agg["any_rays"]) / max(agg["seconds_trace"], 1e-12) / 1e9, 3),
+                    "stage_share_of_render": {
+                        "dominant": round(agg["seconds_trace"] / max(agg["seconds_render"], 1e-12), 4),
+                        "advance": round(agg["seconds_advance"] / max(agg["seconds_render"], 1e-12), 4)},
+                    "reference_equivalent_GBs": round(ref_bytes / avg_s / 1e9, 1),
+                    "reference_equivalent_bytes_per_sample": round(ref_bytes / (float(w) * h * spp / world), 1) if persistent else None,
+                    "np_tt_source": np_src}
+            pmc_file = os.path.join(ROOT, "profiles", "pmc_k_paths.json")
+            key = f"{args.scene}_{w}x{h}x{spp}_n{world}"
+            pmc = json.load(open(pmc_file)).get(key) if os.path.exists(pmc_file) else None
+            if pmc and pmc.get("kernel") == kernel:
+                lane_util = pmc["SQ_THREAD_CYCLES_VALU"] / (64.0 * pmc["SQ_ACTIVE_INST_VALU"])
+                lane_ops = pmc["SQ_INSTS_VALU"] * 64.0 * lane_util  # ACTIVE lane-operations of one launch
+                roof["achieved"] = round(lane_ops / avg_s / 1e12, 3)
+                roof["frac"] = round(lane_ops / avg_s / VALU_PEAK_LANE_OPS, 4)
+                roof["lane_utilisation"] = round(lane_util, 4)
+                roof["valu_wave_instructions_per_launch"] = pmc["SQ_INSTS_VALU"]
+                roof["valu_issue_frac"] = round(pmc["SQ_INSTS_VALU"] * 64.0 / avg_s / VALU_PEAK_LANE_OPS, 4)
+                roof["active_lane_ops_per_ray"] = round(lane_ops / max(c_per + a_per, 1.0), 1)
+                roof["traffic"] = pmc.get("hbm_bytes_per_launch")
+                if roof["traffic"]:
+                    roof["hbm"] = {"achieved_GBs": round(roof["traffic"] / avg_s / 1e9, 1), "peak_GBs": HBM_PEAK_GBS,
+                                   "frac": round(roof["traffic"] / avg_s / 1e9 / HBM_PEAK_GBS, 4)}
+                roof["pmc_source"] = pmc.get("note", "profiles/pmc_k_paths.json")
+            else:
+                roof["pmc_source"] = f"no committed PMC pass for {key}: achieved / frac / traffic are null"
+            try:  # the two roofs measured on the box in the same run: vector-ALU issue and device copy bandwidth
+                rate, _ = api.calibrate_valu(4, 20000)
+                roof["peak_measured"] = round(rate / 1e12, 2)
+                if roof["achieved"] is not None:
+                    roof["frac_of_measured_peak"] = round(roof["achieved"] * 1e12 / rate, 4)
+                roof["copy_bandwidth_measured_GBs"] = round(api.measure_copy_bandwidth(1 << 30, 5) / 1e9, 1)
             except Exception as e:  # noqa: BLE001 -- reported, never fatal for the bench line
-                out["roofline"]["copy_bandwidth_measured_GBs"] = None
-                out["roofline"]["copy_bandwidth_error"] = str(e)
-            traffic_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-            if os.path.exists(traffic_file):
-                tr = json.load(open(traffic_file))
-                key = f"{args.scene}_{w}x{h}x{spp}_n{world}"
-                if key in tr and tr[key].get("kernel") == out["roofline"]["kernel"]:
-                    out["roofline"]["traffic"] = tr[key]["hbm_bytes_per_launch"]
-                    out["roofline"]["traffic_note"] = tr[key].get("note", "")
+                roof["calibration_error"] = str(e)
+            roof["frac_note"] = ("frac = active lane-operations/s over the fp32 vector peak in lane-operations/s; "
+                                 "valu_issue_frac counts every issued wave-instruction as 64 lanes (what the SIMDs spend "
+                                 "issue slots on); the gap between the two is lane utilisation.  HBM is not the bound: see hbm.frac")
+            out["roofline"] = roof
         else:
             out["roofline"] = None
+        if world > 1:  # the 1-GPU shard measurements this scaling run can be held against
+            pred = os.path.join(ROOT, "profiles", "shard_rate_prediction.json")
+            if os.path.exists(pred):
+                out["predicted_scaling"] = json.load(open(pred))
         out["per_frame"] = {"closest_rays": agg["closest_rays"] // max(args.steps, 1),
                             "any_rays": agg["any_rays"] // max(args.steps, 1),
                             "shade_events": agg["shade_events"] // max(args.steps, 1),

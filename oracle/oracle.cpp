@@ -361,6 +361,7 @@ struct Scene {
     int max_depth = 0;
     mutable TravStats st_closest, st_any;
     bool collect_stats = false;
+    bool watertight = false;  // see AabbIsect
 };
 
 // ---------------------------------------------------------------- BVH builder (bvh.cuh:30-219)
@@ -475,9 +476,36 @@ void build_bvh(Scene &sc, const std::vector<Prim> &prims_in) {
 }
 
 // ---------------------------------------------------------------- traversal
+// `watertight` (Scene::watertight, off by default = the literal reference): the reference's slab test works on exact
+// boxes in fp32 and loses, about once in 10^7 rays, a triangle its own triangle test accepts (zero-thickness boxes of
+// axis-aligned triangles, grazing rays).  The image-defining function is the triangle test; which accepted hits the
+// BVH walk happens to drop is a property of the reference's tree and rounding that no other tree can reproduce.
+// With the flag set the box decision is made conservatively (boxes widened by 8 ulps, slabs in double), so the walk
+// returns what exhaustive search over all triangles returns; the near-first ORDER still uses the reference's fp32
+// entry distances.  tests/test_traversal_audit.py measures the difference between the two modes and checks every
+// differing ray against exhaustive search.
 struct AabbIsect {  // aabb_intersector.cuh:14-36
     int ox, oy, oz;
     V3 inv, so;
+    bool watertight = false;
+    double wo[3], winv[3];
+    AabbIsect(const Ray &ray, bool wt) : AabbIsect(ray) {
+        watertight = wt;
+        wo[0] = ray.o.x; wo[1] = ray.o.y; wo[2] = ray.o.z;
+        winv[0] = inv.x; winv[1] = inv.y; winv[2] = inv.z;
+    }
+    bool hit_conservative(const BBox &bb) const {
+        double t_in = -1e300, t_out = 1e300;
+        for (int a = 0; a < 3; a++) {
+            double lo = bb.b[2 * a], hi = bb.b[2 * a + 1];
+            lo -= fabs(lo) * 1e-6 + 1e-7;
+            hi += fabs(hi) * 1e-6 + 1e-7;
+            double t0 = (lo - wo[a]) * winv[a], t1 = (hi - wo[a]) * winv[a];
+            t_in = std::max(t_in, std::min(t0, t1));
+            t_out = std::min(t_out, std::max(t0, t1));
+        }
+        return t_in <= t_out;
+    }
     explicit AabbIsect(const Ray &ray) {
         ox = ray.d.x < 0 ? 1 : 0;
         oy = ray.d.y < 0 ? 1 : 0;
@@ -497,6 +525,7 @@ struct AabbIsect {  // aabb_intersector.cuh:14-36
         float xy = inv.y * bb.b[3 - oy] + so.y;
         float xz = inv.z * bb.b[5 - oz] + so.z;
         float exit = fminf(xx, fminf(xy, xz));
+        if (watertight) return hit_conservative(bb);
         return entry <= exit;
     }
 };
@@ -538,7 +567,7 @@ bool traverse_closest(const Scene &sc, Ray &ray, Isect &is, int &prim, TravStats
     const Node *nodes = sc.nodes.data();
     if (nodes[0].num_prims > 0) return leaf_closest(sc, nodes[0], ray, is, prim, st);
     bool hit = false;
-    AabbIsect ai(ray);
+    AabbIsect ai(ray, sc.watertight);
     Stack stack;
     int left = nodes[0].index;
     while (true) {
@@ -590,7 +619,7 @@ bool traverse_any(const Scene &sc, int excluded_tri, const Ray &ray, TravStats *
     if (st) st->rays++;
     const Node *nodes = sc.nodes.data();
     if (nodes[0].num_prims > 0) return leaf_any(sc, excluded_tri, nodes[0], ray, st);
-    AabbIsect ai(ray);
+    AabbIsect ai(ray, sc.watertight);
     Stack stack;
     int left = nodes[0].index;
     while (true) {
@@ -858,6 +887,19 @@ double now_s() {
     return ts.tv_sec + 1e-9 * ts.tv_nsec;
 }
 
+// Optional log of every ray a render traces (test tooling for the traversal audit: tests/test_traversal_audit.py
+// replays the logged rays through the product's BVH walk and through exhaustive search).  Filled in the serial
+// sections of render_literal only.
+struct RayLog {
+    bool on = false;
+    std::vector<float> any_odt;      // 7 per shadow ray: o, d, tmax
+    std::vector<int32_t> any_info;   // 2 per shadow ray: excluded triangle, occluded (0 / 1)
+    std::vector<float> closest_od;   // 6 per path ray: o, d
+    std::vector<int32_t> closest_tri;  // hit triangle (original index) or -1
+    std::vector<float> closest_t;
+};
+RayLog g_raylog;
+
 // Literal restatement of render() (render.cuh:366-457).  slot_lo/slot_hi restrict the slots that
 // are allowed to generate camera rays (used to check partition invariance: the image is the sum of
 // the shards because slot s only ever serves camera rays c == s (mod W)); the full render is
@@ -1109,6 +1151,14 @@ void render_literal(const Scene &sc, const Camera &cam, int width, int height, i
                 sc.st_any.tri_tests += t.tri_tests;
                 sc.st_any.max_stack = std::max(sc.st_any.max_stack, t.max_stack);
             }
+            if (g_raylog.on)
+                for (int tid = 0; tid < n_ah; tid++) {
+                    const Ray &r = p.ray[p.ah_c[tid]];
+                    const float rec[7] = {r.o.x, r.o.y, r.o.z, r.d.x, r.d.y, r.d.z, r.tmax};
+                    g_raylog.any_odt.insert(g_raylog.any_odt.end(), rec, rec + 7);
+                    g_raylog.any_info.push_back(p.ah_target[p.ah_c[tid] - W]);
+                    g_raylog.any_info.push_back(deposit[tid] ? 0 : 1);
+                }
             for (int tid = 0; tid < n_ah; tid++)
                 if (deposit[tid]) {
                     int ah_id = p.ah_c[tid];
@@ -1153,6 +1203,16 @@ void render_literal(const Scene &sc, const Camera &cam, int width, int height, i
                 sc.st_closest.tri_tests += t.tri_tests;
                 sc.st_closest.max_stack = std::max(sc.st_closest.max_stack, t.max_stack);
             }
+            if (g_raylog.on)
+                for (int tid = 0; tid < n_ch; tid++) {
+                    const int rid = p.ch_c[tid];
+                    if (rid >= W) continue;  // (path rays only; the BSDF-sampled shadow rays never contribute)
+                    const Ray &r = p.ray[rid];
+                    const float rec[6] = {r.o.x, r.o.y, r.o.z, r.d.x, r.d.y, r.d.z};
+                    g_raylog.closest_od.insert(g_raylog.closest_od.end(), rec, rec + 6);
+                    g_raylog.closest_tri.push_back(p.hit[rid] ? sc.prims[p.isect_prim[rid]].tri : -1);
+                    g_raylog.closest_t.push_back(p.hit[rid] ? p.isect[rid].t : 0.f);
+                }
             for (int tid = 0; tid < n_ch; tid++)
                 if (deposit[tid]) {
                     int rid = p.ch_c[tid];
@@ -1404,6 +1464,46 @@ void orc_trace_any(const orc_scene *h, int n, const float *o3, const float *d3, 
         Ray r{mk(o3[3 * i], o3[3 * i + 1], o3[3 * i + 2]), mk(d3[3 * i], d3[3 * i + 1], d3[3 * i + 2]), tmax[i]};
         occluded[i] = traverse_any(sc, excluded_tri[i], r, nullptr) ? 1 : 0;
     }
+}
+
+// exhaustive any hit: the first triangle in ORIGINAL order the triangle test accepts that is not the excluded one
+void orc_trace_any_brute(const orc_scene *h, int n, const float *o3, const float *d3, const float *tmax,
+                         const int32_t *excluded_tri, int32_t *occluder, int threads) {
+    const Scene &sc = h->sc;
+#pragma omp parallel for num_threads(threads > 0 ? threads : 1) schedule(dynamic, 64)
+    for (int i = 0; i < n; i++) {
+        Ray r{mk(o3[3 * i], o3[3 * i + 1], o3[3 * i + 2]), mk(d3[3 * i], d3[3 * i + 1], d3[3 * i + 2]), tmax[i]};
+        occluder[i] = -1;
+        for (size_t k = 0; k < sc.tris.size(); k++) {
+            Isect tmp;
+            if ((int)k != excluded_tri[i] && sc.tris[k].intersect(r, tmp)) {
+                occluder[i] = (int)k;
+                break;
+            }
+        }
+    }
+}
+
+// 0 (default): the reference's slab test, literally.  1: conservative box decisions (see AabbIsect).
+void orc_scene_set_watertight(orc_scene *h, int on) { h->sc.watertight = on != 0; }
+
+// ray log of the NEXT orc_render calls (see RayLog): enable clears it
+void orc_raylog_enable(int on) {
+    g_raylog = RayLog();
+    g_raylog.on = on != 0;
+}
+void orc_raylog_counts(int64_t *out2) {
+    out2[0] = (int64_t)g_raylog.any_info.size() / 2;
+    out2[1] = (int64_t)g_raylog.closest_tri.size();
+}
+void orc_raylog_fetch_any(float *odt7, int32_t *info2) {
+    memcpy(odt7, g_raylog.any_odt.data(), sizeof(float) * g_raylog.any_odt.size());
+    memcpy(info2, g_raylog.any_info.data(), sizeof(int32_t) * g_raylog.any_info.size());
+}
+void orc_raylog_fetch_closest(float *od6, int32_t *tri, float *t) {
+    memcpy(od6, g_raylog.closest_od.data(), sizeof(float) * g_raylog.closest_od.size());
+    memcpy(tri, g_raylog.closest_tri.data(), sizeof(int32_t) * g_raylog.closest_tri.size());
+    memcpy(t, g_raylog.closest_t.data(), sizeof(float) * g_raylog.closest_t.size());
 }
 
 // literal render.  stats_out: RenderStats as 20 int64/double slots (see oracle.py);

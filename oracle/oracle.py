@@ -72,6 +72,12 @@ class Oracle:
                                        ctypes.c_int]
         L.orc_closest_ties.restype = ctypes.c_int
         L.orc_trace_any.argtypes = [ctypes.c_void_p, ctypes.c_int, _fp, _fp, _fp, _fp, _fp, ctypes.c_int]
+        L.orc_trace_any_brute.argtypes = L.orc_trace_any.argtypes
+        L.orc_scene_set_watertight.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        L.orc_raylog_enable.argtypes = [ctypes.c_int]
+        L.orc_raylog_counts.argtypes = [ctypes.c_void_p]
+        L.orc_raylog_fetch_any.argtypes = [_fp, _fp]
+        L.orc_raylog_fetch_closest.argtypes = [_fp, _fp, _fp]
         L.orc_render.argtypes = [ctypes.c_void_p, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                  ctypes.c_uint64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                  _fp, _fp, _fp, _fp, ctypes.c_int]
@@ -151,6 +157,27 @@ class Oracle:
         self.lib.orc_sample_f(_ptr(material), _ptr(wo), _ptr(n), _ptr(state), _ptr(out))
         return out
 
+    # ------------------------------------------------------------------ ray log (traversal audit)
+    def raylog_enable(self, on: bool = True) -> None:
+        """Log every shadow ray and path ray the following renders trace (cleared by each call)."""
+        self.lib.orc_raylog_enable(int(on))
+
+    def raylog_fetch(self) -> dict:
+        cnt = np.zeros(2, np.int64)
+        self.lib.orc_raylog_counts(_ptr(cnt))
+        na, nc = int(cnt[0]), int(cnt[1])
+        odt = np.zeros((max(na, 1), 7), np.float32)
+        info = np.zeros((max(na, 1), 2), np.int32)
+        od = np.zeros((max(nc, 1), 6), np.float32)
+        tri = np.zeros(max(nc, 1), np.int32)
+        t = np.zeros(max(nc, 1), np.float32)
+        self.lib.orc_raylog_fetch_any(_ptr(odt), _ptr(info))
+        self.lib.orc_raylog_fetch_closest(_ptr(od), _ptr(tri), _ptr(t))
+        return {"any_o": odt[:na, 0:3].copy(), "any_d": odt[:na, 3:6].copy(), "any_tmax": odt[:na, 6].copy(),
+                "any_excluded": info[:na, 0].copy(), "any_occluded": info[:na, 1].copy(),
+                "closest_o": od[:nc, 0:3].copy(), "closest_d": od[:nc, 3:6].copy(), "closest_tri": tri[:nc].copy(),
+                "closest_t": t[:nc].copy()}
+
     # ------------------------------------------------------------------ scene
     def scene(self, arrays) -> "OracleScene":
         return OracleScene(self, arrays)
@@ -168,6 +195,12 @@ class OracleScene:
         lights = np.ascontiguousarray(arrays.lights)
         self.h = L.orc_scene_create(_ptr(tris), tris.shape[0], _ptr(tm), _ptr(tl), _ptr(mats), mats.shape[0],
                                     _ptr(lights), lights.shape[0])
+
+    def set_watertight(self, on: bool = True) -> "OracleScene":
+        """Conservative box decisions instead of the reference's fp32 slab test (oracle.cpp, AabbIsect): the BVH walk
+        then returns what exhaustive search returns.  Default off = the literal reference."""
+        self.o.lib.orc_scene_set_watertight(self.h, int(on))
+        return self
 
     def close(self):
         if self.h:
@@ -223,6 +256,17 @@ class OracleScene:
         n = o3.shape[0]
         occ = np.zeros(n, np.int32)
         self.o.lib.orc_trace_any(self.h, n, _ptr(o3), _ptr(d3), _ptr(tmax), _ptr(excluded), _ptr(occ), threads)
+        return occ
+
+    def trace_any_brute(self, o3, d3, tmax, excluded, threads: int = 8):
+        """Exhaustive any hit: index of the first accepted, non-excluded triangle (original order) or -1."""
+        o3 = np.ascontiguousarray(o3, np.float32)
+        d3 = np.ascontiguousarray(d3, np.float32)
+        tmax = np.ascontiguousarray(tmax, np.float32)
+        excluded = np.ascontiguousarray(excluded, np.int32)
+        n = o3.shape[0]
+        occ = np.zeros(n, np.int32)
+        self.o.lib.orc_trace_any_brute(self.h, n, _ptr(o3), _ptr(d3), _ptr(tmax), _ptr(excluded), _ptr(occ), threads)
         return occ
 
     def render(self, cam12, width, height, spp, max_bounces=10, seed=1, slot_lo=0, slot_hi=1 << 20,

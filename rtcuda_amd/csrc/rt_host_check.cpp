@@ -221,4 +221,87 @@ int rt_bvh_selfcheck(const float *verts, int n, int n_rays, const float *o3, con
         fprintf(stderr, "bvh walk: inner %.2f leaf %.2f tri %.2f per ray\n", (double)sum_inner / n_rays, (double)sum_leaf / n_rays, (double)sum_tri / n_rays);
     return 0;
 }
+
+// ---- CPU walk of the product's default tree (2-wide records, padded boxes) for arbitrary rays: the control flow and
+// the fp32 expressions of inner_step<false> + the triangle blocks of k_trace / k_paths in rtcuda_amd.hip.  Used by the
+// traversal audit (tests/test_traversal_audit.py): rays logged from an oracle render are replayed here, on the
+// oracle's reference traversal and through exhaustive search, to show which of the two BVH walks loses hits.
+struct HostWalk {
+    rtbvh::Result r;
+    std::vector<Tri> tris;     // leaf order
+    std::vector<int> inverse;  // original index -> leaf-order index
+    int n = 0;
+};
+void *rt_hostwalk_create(const float *verts, int n) {
+    HostWalk *w = new HostWalk();
+    w->n = n;
+    w->r = rtbvh::build(verts, n);
+    if (!w->r.ok) { delete w; return nullptr; }
+    w->tris.resize(n);
+    w->inverse.assign(n, 0);
+    for (int k = 0; k < n; k++) {
+        const float *q = verts + 9 * (size_t)w->r.order[k];
+        V3 p0{q[0], q[1], q[2]}, p1{q[3], q[4], q[5]}, p2{q[6], q[7], q[8]};
+        w->tris[k].p0 = p0; w->tris[k].e1 = sub(p0, p1); w->tris[k].e2 = sub(p2, p0); w->tris[k].n = cross(w->tris[k].e1, w->tris[k].e2);
+        w->inverse[w->r.order[k]] = k;
+    }
+    return w;
+}
+void rt_hostwalk_destroy(void *h) { delete (HostWalk *)h; }
+// mode 0: closest hit -> out_i = original triangle index or -1, out_t = t;  mode 1: any hit excluding excluded[i]
+// (original index or -1) -> out_i = 0 / 1
+int rt_hostwalk_trace(void *h, int mode, int n_rays, const float *o3, const float *d3, const float *tmax_in, const int *excluded,
+                      int *out_i, float *out_t) {
+    const HostWalk &w = *(const HostWalk *)h;
+    const rtbvh::Result &r = w.r;
+    int failures = 0;
+#pragma omp parallel for schedule(dynamic, 1024) reduction(+ : failures)
+    for (int i = 0; i < n_rays; i++) {
+        std::vector<int> pstack(r.pair_depth + 8);
+        V3 o{o3[3 * i], o3[3 * i + 1], o3[3 * i + 2]}, d{d3[3 * i], d3[3 * i + 1], d3[3 * i + 2]};
+        auto clampinv = [](float x) { return 1.f / ((fabsf(x) < FLT_EPSILON) ? copysignf(FLT_EPSILON, x) : x); };
+        V3 inv{clampinv(d.x), clampinv(d.y), clampinv(d.z)};
+        float tmax = tmax_in[i], t;
+        const int excl = (mode == 1 && excluded[i] >= 0 && excluded[i] < w.n) ? w.inverse[excluded[i]] : -1;
+        int best = -1, sp = 0, cur = w.n > 0 ? 0 : rtbvh::kNoChild;
+        bool occluded = false;
+        int64_t steps = 0;
+        while (cur != rtbvh::kNoChild && !occluded) {
+            if (++steps > 1000000) { failures++; break; }
+            if (cur >= 0) {
+                const rtbvh::Pair &p = r.pairs[cur];
+                float el, er;
+                bool hl = box_hit(o, inv, p.lbox, p.lbox + 3, tmax, el) && p.llink != rtbvh::kNoChild;
+                bool hr = box_hit(o, inv, p.rbox, p.rbox + 3, tmax, er) && p.rlink != rtbvh::kNoChild;
+                if (hl && hr) {
+                    bool lf = !(el > er);
+                    if (sp >= (int)pstack.size()) { failures++; break; }
+                    pstack[sp++] = lf ? p.rlink : p.llink;
+                    cur = lf ? p.llink : p.rlink;
+                } else if (hl) cur = p.llink;
+                else if (hr) cur = p.rlink;
+                else cur = sp > 0 ? pstack[--sp] : rtbvh::kNoChild;
+            } else {
+                int ref = ~cur, first = ref >> 3, count = ref & 7;
+                for (int k = first; k < first + count; k++)
+                    if (tri_hit(w.tris[k], o, d, tmax, t)) {
+                        if (mode == 1) {
+                            if (k != excl) { occluded = true; break; }
+                        } else {
+                            tmax = t;
+                            best = k;
+                        }
+                    }
+                cur = sp > 0 ? pstack[--sp] : rtbvh::kNoChild;
+            }
+        }
+        if (mode == 1) {
+            out_i[i] = occluded ? 1 : 0;
+        } else {
+            out_i[i] = best >= 0 ? r.order[best] : -1;
+            out_t[i] = best >= 0 ? tmax : 0.f;
+        }
+    }
+    return failures;
+}
 }

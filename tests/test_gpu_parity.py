@@ -1,4 +1,10 @@
-"""GPU parity tests: the HIP path (through the C-ABI) against the CPU oracle.  Run with -m gpu."""
+"""GPU parity tests: the HIP path (through the C-ABI) against the CPU oracle.  Run with -m gpu.
+
+Every render in THIS file has at most W = 1 048 576 camera rays, i.e. ONE generation -- which is the final generation
+and therefore runs on the lockstep round pipeline (k_advance + k_trace); the persistent kernel k_paths only parks the
+slots.  What is covered here is that pipeline, the stage-level entry points, the host logic and the edge cases of the
+final generation (tiny frames, termination rule).  The persistent kernel -- the one bench.py times -- is held against
+the oracle over several generations in tests/test_gpu_multigen.py."""
 import numpy as np
 import pytest
 
@@ -125,18 +131,21 @@ def test_render_matches_oracle_matte(api, oracle, gpu_matte, cpu_matte, w, h, sp
 
 
 @pytest.mark.parametrize("w,h,spp,max_bounces,seed", [
-    (37, 23, 16, 10, 1),    # odd sizes: the per-generation pixel step carries across rows
-    (61, 7, 64, 10, 1),     # a very wide image: several carries per slot
-    (33, 19, 48, 10, 1),    # spp does not divide W: the general (64-bit divide) pixel path
+    # (one generation each: gen() runs once per slot, in k_advance; the per-generation pixel stepping and the
+    #  non-lockstep Russian-roulette loop are NOT reached here -- see tests/test_gpu_multigen.py for those)
+    (37, 23, 16, 10, 1),    # odd sizes
+    (61, 7, 64, 10, 1),     # a very wide image
+    (33, 19, 48, 10, 1),    # spp does not divide W: pixel = camera ray / spp by the 64-bit divide
     (40, 30, 3, 10, 7),     # another seed, odd spp
     (32, 24, 8, 0, 1),      # no bounce at all: emission only
     (32, 24, 8, 1, 1),
     (32, 24, 8, 2, 1),
-    (24, 16, 8, 20, 1),     # long Russian-roulette chains
+    (24, 16, 8, 20, 1),     # Russian roulette over 20 lockstep rounds
 ])
 def test_render_edge_configurations_match_oracle(api, oracle, gpu_full, cpu_full, w, h, spp, max_bounces, seed):
-    """Sizes, sample counts, bounce limits and seeds around the special cases of gen() and init(): same integer event
-    totals as the oracle, same image up to the float summation order."""
+    """Sizes, sample counts, bounce limits and seeds through the lockstep pipeline (final-generation schedule, the
+    reference's termination rule render.cuh:436): same integer event totals as the oracle, same image up to the float
+    summation order."""
     cam = default_camera(oracle, w / h)
     img_c, sum_c, st_c = cpu_full.render(cam, w, h, spp, max_bounces=max_bounces, seed=seed, threads=8)
     img_g, st_g = gpu_full.render(api.make_camera(aspect=w / h), w, h, spp, max_bounces=max_bounces, seed=seed)
@@ -259,9 +268,10 @@ def test_cpp_drop_in_driver_matches_python_path(api, gpu_matte, tmp_path):
     assert (got != ref).mean() < 1e-3 and np.abs(got - ref).max() <= 1
 
 
-def test_round_pipeline_and_persistent_kernel_agree(api, oracle, gpu_full, monkeypatch):
-    """The frame as one persistent launch (k_paths, default) and as one launch per round
-    (k_advance + k_trace, RT_PERSISTENT=0) are the same estimator: identical event totals and image."""
+def test_single_generation_frame_is_the_same_with_and_without_the_persistent_launch(api, oracle, gpu_full, monkeypatch):
+    """A one-generation frame: with the persistent launch (which only parks the slots here) and with RT_PERSISTENT=0 the
+    lockstep pipeline produces the same totals and image.  The several-generation version of this comparison, where
+    k_paths does the work, is test_gpu_multigen.test_round_pipeline_and_scheduling_variants_agree_over_generations."""
     w, h, spp = 160, 90, 16
     cam = api.make_camera(aspect=w / h)
     img_p, st_p = gpu_full.render(cam, w, h, spp)
@@ -272,11 +282,6 @@ def test_round_pipeline_and_persistent_kernel_agree(api, oracle, gpu_full, monke
         assert st_p[k] == st_r[k], k
     assert st_r["iterations"] > st_p["iterations"]
     assert _rms(img_p, img_r).max() < 2e-6
-    # and the scheduling variants of the persistent kernel change nothing but speed
-    monkeypatch.setenv("RT_MAJORITY", "0")
-    monkeypatch.setenv("RT_ADV_BATCH", "7")
-    img_m, st_m = gpu_full.render(cam, w, h, spp)
-    assert st_m["shade_events"] == st_p["shade_events"] and _rms(img_m, img_p).max() < 2e-6
 
 
 def test_both_node_formats_match_oracle(api, oracle, cpu_matte, bunny_matte, monkeypatch):

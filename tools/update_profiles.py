@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Copy what tools/refresh_profiles.sh measured (gpurun_out/r01/) into profiles/ and recompute
-profiles/pmc_traffic.json (the `roofline.traffic` field of bench.py) from the PMC summary.
+"""Copy what tools/refresh_profiles.sh measured (gpurun_out/<tag>/) into profiles/ and rebuild
+profiles/pmc_k_paths.json, from which bench.py takes the per-launch counters of its roofline.
+
+usage: update_profiles.py <tag>          e.g. r02
 
 HBM bytes per k_paths launch = (2 * FETCH_SIZE + WRITE_SIZE) KB, as MI355X_MICROARCH.md prescribes for gfx950
 (FETCH_SIZE counts half of streaming reads; uncalibrated for this gather / scratch pattern)."""
@@ -10,36 +12,63 @@ import shutil
 import sys
 
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = os.path.join(root, "gpurun_out", sys.argv[1] if len(sys.argv) > 1 else "r01")
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+src = os.path.join(root, "gpurun_out", tag)
 dst = os.path.join(root, "profiles")
-shutil.copy(os.path.join(src, "kernel_stats.csv"), os.path.join(dst, "r01_kernel_stats.csv"))
-shutil.copy(os.path.join(src, "pmc_summary.json"), os.path.join(dst, "r01_pmc.json"))
-shutil.copy(os.path.join(src, "bench_n1.json"), os.path.join(dst, "bench_r01_n1.json"))
-for extra in ("shard_rate.txt", "scenes.txt"):
-    if os.path.exists(os.path.join(src, extra)):
-        shutil.copy(os.path.join(src, extra), os.path.join(dst, "r01_" + extra))
-pmc = json.load(open(os.path.join(src, "pmc_summary.json")))
-key = [k for k in pmc if "k_paths" in k][0]
-c = {n: v["mean_per_dispatch"] for n, v in pmc[key].items()}
-traffic = {
-    "full_bsdf_1920x1080x256_n1": {
-        "kernel": "k_paths",
-        "fetch_size_kb": c["FETCH_SIZE"],
-        "write_size_kb": c["WRITE_SIZE"],
-        "hbm_bytes_per_launch": int((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024),
-        "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `bench.py --steps 1 --warmup 0 "
-                "--no-cpu-baseline --no-kernel-timing` (profiles/r01_pmc.json, tools/refresh_profiles.sh); bytes = "
-                "(2*FETCH_SIZE + WRITE_SIZE) KB per MI355X_MICROARCH.md (gfx950 FETCH_SIZE counts half of streaming "
-                "reads; uncalibrated for this gather/scratch pattern).  Writes are the framebuffer atomics (one 64-byte "
-                "write each) and register spills; reads are spills and L2 misses of the BVH gather (5.7 MB scene, 4 MB "
-                "L2 per XCD).",
-    }
-}
-json.dump(traffic, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
-gui = c["GRBM_GUI_ACTIVE"] / 8.0  # summed over the 8 XCDs
-print("k_paths: %.1f ms @ %.2f GHz" % (gui / 2.4e6, 2.4))
-print("VALU busy %.1f %%  (4 x SQ_ACTIVE_INST_VALU / (1024 SIMDs x kernel cycles))" % (400.0 * c["SQ_ACTIVE_INST_VALU"] / (1024 * gui)))
-print("lane utilisation %.1f %%  (SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU))" % (100.0 * c["SQ_THREAD_CYCLES_VALU"] / (64 * c["SQ_ACTIVE_INST_VALU"])))
-print("HBM traffic %.1f GB per launch; L2 hit rate %.1f %%" % (traffic["full_bsdf_1920x1080x256_n1"]["hbm_bytes_per_launch"] / 1e9,
-                                                              100.0 * c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"])))
-print("instructions per launch: VALU %.3g SALU %.3g VMEM %.3g LDS %.3g" % (c["SQ_INSTS_VALU"], c["SQ_INSTS_SALU"], c["SQ_INSTS_VMEM"], c["SQ_INSTS_LDS"]))
+
+
+def counters(path, kernel="k_paths"):
+    pmc = json.load(open(path))
+    key = [k for k in pmc if kernel in k][0]
+    return key, {n: v["mean_per_dispatch"] for n, v in pmc[key].items()}
+
+
+table_path = os.path.join(dst, "pmc_k_paths.json")
+table = json.load(open(table_path)) if os.path.exists(table_path) else {}
+for scene in ("full_bsdf", "four_bunnies", "sixteen_lights", "matte"):
+    d = os.path.join(src, scene)
+    if not os.path.exists(os.path.join(d, "pmc_summary.json")):
+        continue
+    shutil.copy(os.path.join(d, "kernel_stats.csv"), os.path.join(dst, f"{tag}_{scene}_kernel_stats.csv"))
+    shutil.copy(os.path.join(d, "pmc_summary.json"), os.path.join(dst, f"{tag}_{scene}_pmc.json"))
+    kname, c = counters(os.path.join(d, "pmc_summary.json"))
+    gui = c["GRBM_GUI_ACTIVE"] / 8.0  # summed over the 8 XCDs
+    entry = {"kernel": "k_paths", "kernel_instance": kname,
+             "SQ_INSTS_VALU": c["SQ_INSTS_VALU"], "SQ_ACTIVE_INST_VALU": c["SQ_ACTIVE_INST_VALU"],
+             "SQ_THREAD_CYCLES_VALU": c["SQ_THREAD_CYCLES_VALU"], "SQ_INSTS_SALU": c["SQ_INSTS_SALU"],
+             "SQ_INSTS_VMEM": c["SQ_INSTS_VMEM"], "SQ_INSTS_LDS": c["SQ_INSTS_LDS"],
+             "SQ_WAVE_CYCLES": c["SQ_WAVE_CYCLES"], "SQ_WAIT_ANY": c["SQ_WAIT_ANY"], "SQ_WAIT_INST_ANY": c["SQ_WAIT_INST_ANY"],
+             "kernel_cycles": gui, "fetch_size_kb": c["FETCH_SIZE"], "write_size_kb": c["WRITE_SIZE"],
+             "hbm_bytes_per_launch": int((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024),
+             "l2_hit_rate": c["TCC_HIT_sum"] / max(c["TCC_HIT_sum"] + c["TCC_MISS_sum"], 1.0),
+             "note": f"rocprofv3 --pmc passes of `bench.py --scene {scene} --spp 256 --steps 1 --warmup 0 --no-cpu-baseline "
+                     f"--no-kernel-timing` (tools/profile_scene.sh; profiles/{tag}_{scene}_pmc.json); HBM bytes = (2*FETCH_SIZE + "
+                     "WRITE_SIZE) KB per MI355X_MICROARCH.md (gfx950 FETCH_SIZE counts half of streaming reads)"}
+    table[f"{scene}_1920x1080x256_n1"] = entry
+    lane_util = c["SQ_THREAD_CYCLES_VALU"] / (64 * c["SQ_ACTIVE_INST_VALU"])
+    print("%-15s %.1f ms | VALU wave-instr %.4g | lane util %.1f %% | issue %.1f %% of 1 per 2 clk per SIMD | active lane-ops %.4g | "
+          "HBM %.1f GB | L2 hit %.1f %% | wait_any %.0f %% wait_inst %.0f %% of wave cycles" % (
+              scene, gui / 2.4e6, c["SQ_INSTS_VALU"], 100 * lane_util, 100 * 2 * c["SQ_INSTS_VALU"] / (1024 * gui),
+              c["SQ_INSTS_VALU"] * 64 * lane_util, entry["hbm_bytes_per_launch"] / 1e9, 100 * entry["l2_hit_rate"],
+              100 * c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], 100 * c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"]))
+json.dump(table, open(table_path, "w"), indent=1)
+for name in ("bench_n1.json", "shard_rate.txt", "valu_calibration.json", "valu_calibration_pmc.json"):
+    if os.path.exists(os.path.join(src, name)):
+        shutil.copy(os.path.join(src, name), os.path.join(dst, f"{tag}_{name}"))
+if os.path.exists(os.path.join(src, "shard8", "pmc_summary.json")):
+    shutil.copy(os.path.join(src, "shard8", "pmc_summary.json"), os.path.join(dst, f"{tag}_shard8_pmc.json"))
+# shard-rate curve -> what bench.py echoes when n_gpus > 1
+rates = {}
+p = os.path.join(src, "shard_rate.txt")
+if os.path.exists(p):
+    for ln in open(p):
+        if ln.startswith("shards "):
+            tok = ln.replace(":", "").split()
+            rates[int(tok[1])] = float(ln.split("->")[1].split()[0])
+if rates:
+    base = rates.get(1)
+    json.dump({"source": f"tools/shard_rate.py on one MI355X ({tag}): the rate of ONE rank's slot shard, before the 24.9 MB reduce",
+               "per_gpu_Msamples_per_s": rates,
+               "predicted_Msamples_per_s": {n: round(n * r, 1) for n, r in rates.items()},
+               "predicted_speedup": {n: round(n * r / base, 3) for n, r in rates.items()} if base else None},
+              open(os.path.join(dst, "shard_rate_prediction.json"), "w"), indent=1)
