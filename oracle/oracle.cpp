@@ -543,6 +543,20 @@ bool leaf_closest(const Scene &sc, const Node &nd, Ray &ray, Isect &is, int &pri
     bool hit = false;
     for (int i = nd.index; i < nd.index + nd.num_prims; i++) {
         if (st) st->tri_tests++;
+        if (sc.watertight) {
+            // canonical tie rule of the watertight mode: of two triangles hit at EXACTLY the same t the one with the
+            // larger index in the caller's order wins, whatever the tree (the literal rule below -- the later TESTED
+            // one wins, triangle.cuh:49 -- depends on the reference's tree order: SURVEY Appendix A.10)
+            Isect cand;
+            if (sc.tris[sc.prims[i].tri].intersect(ray, cand)) {
+                if (cand.t == ray.tmax && prim >= 0 && sc.prims[i].tri < sc.prims[prim].tri) continue;
+                is = cand;
+                hit = true;
+                prim = i;
+                ray.tmax = cand.t;
+            }
+            continue;
+        }
         if (sc.tris[sc.prims[i].tri].intersect(ray, is)) {
             hit = true;
             prim = i;

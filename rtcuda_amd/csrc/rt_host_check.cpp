@@ -287,7 +287,7 @@ int rt_hostwalk_trace(void *h, int mode, int n_rays, const float *o3, const floa
                     if (tri_hit(w.tris[k], o, d, tmax, t)) {
                         if (mode == 1) {
                             if (k != excl) { occluded = true; break; }
-                        } else {
+                        } else if (!(t == tmax && best >= 0) || r.order[k] > r.order[best]) {  // closest_hit_wins()
                             tmax = t;
                             best = k;
                         }

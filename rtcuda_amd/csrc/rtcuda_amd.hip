@@ -84,6 +84,7 @@ struct DScene {
     const int2 *tri_info;  // leaf order: {material index, light index or -1}
     const float4 *tri_shade;  // leaf order: what mat() needs of a hit triangle besides the point -- the flipped unit
                               // normal -normalize(n) (render.cuh:153) and the packed ids (material | light + 1 << 16)
+    const int *order;         // leaf order -> the caller's triangle index (closest-hit tie rule, test output)
     const Material *mats;
     const Light *lights;
     int num_lights;
@@ -721,6 +722,15 @@ __device__ __forceinline__ int stack_pop(int *lds_col, int *over_col, int &sp, i
     }
     return v;
 }
+// Closest hit among EQUAL distances.  The reference accepts `t <= tmax` (triangle.cuh:49), so of two triangles hit at
+// exactly the same t (a shared edge) the one its BVH walk tests LAST wins -- a property of the
+// reference's tree that no other tree can reproduce.  Here the tie goes to the triangle with the larger index in the
+// CALLER's order, whatever the tree: the result is a function of the ray and the triangle list alone (the oracle's
+// watertight mode applies the same rule; ties are ~1 in 10^7 rays).  `tri` / `tmax`: best hit so far.
+__device__ __forceinline__ bool closest_hit_wins(const DScene &sc, float t, float tmax, int k, int tri) {
+    if (t == tmax && tri >= 0) return sc.order[(unsigned)k] > sc.order[(unsigned)tri];
+    return true;
+}
 constexpr int kRefillAt = 40;                // finalise + refill once <= this many lanes still traverse
 __device__ __forceinline__ int leaf_ref(int first, int count) { return ~((first << 3) | count); }
 
@@ -1032,7 +1042,7 @@ __global__ void __launch_bounds__(kBlock, 8) k_trace(DScene sc, DPools p, TraceP
                             stop = true;
                             break;
                         }
-                    } else {  // bvh.cuh:227-231: later equal-t hit wins (t <= tmax)
+                    } else if (closest_hit_wins(sc, t, tmax, k, tri)) {  // bvh.cuh:227-231 (t <= tmax)
                         tmax = t;
                         hu = u;
                         hv = v;
@@ -1476,7 +1486,7 @@ k_paths(DScene sc, DPools p, Camera cam_arg, AdvanceParams ap_arg, float *__rest
                                 hu = 1.f;
                                 stop = true;
                             }
-                        } else {  // bvh.cuh:227-231: later equal-t hit wins (t <= tmax)
+                        } else if (closest_hit_wins(sc, t, tmax, k, tri)) {  // bvh.cuh:227-231 (t <= tmax)
                             tmax = t;
                             hu = u;
                             hv = v;
@@ -1765,6 +1775,7 @@ struct rt_scene {
         s.tris = d_tris;
         s.tri_info = d_tri_info;
         s.tri_shade = d_tri_shade;
+        s.order = d_order;
         s.mats = d_mats;
         s.lights = d_lights;
         s.num_lights = n_lights;

@@ -11,8 +11,10 @@ What is checked here, without a GPU:
   * every ray an oracle render traces (oracle ray log) is replayed through that walk;
   * wherever the product's walk and the reference's literal walk disagree, exhaustive search over all triangles
     decides -- and must side with the product;
-  * the oracle's `watertight` mode (conservative box decisions) agrees with the product's walk on EVERY ray, which is
-    why the GPU parity tests can demand equal integer event totals against it.
+  * the oracle's `watertight` mode (conservative box decisions + a tree-independent rule for hits at exactly equal t:
+    the larger caller index wins, where the reference lets its tree order decide -- SURVEY Appendix A.10) agrees with
+    the product's walk on EVERY ray, triangle index included, which is why the GPU parity tests can demand equal
+    integer event totals against it at any frame size.
 """
 import ctypes
 import os
@@ -132,5 +134,6 @@ def test_every_ray_of_a_render_replayed_through_the_product_walk(oracle, variant
     tri, t = walk.closest(log["closest_o"], log["closest_d"])
     hit_c = log["closest_tri"] >= 0
     assert np.array_equal(tri >= 0, hit_c) and np.array_equal(t[hit_c], log["closest_t"][hit_c])
+    assert np.array_equal(tri, log["closest_tri"])  # ties included: both sides give them to the larger caller index
     for k in ("sum_mat", "sum_ah", "emission_adds", "ah_adds", "rr_draws"):
         assert abs(st_w[k] - st[k]) <= 8, k  # the two modes differ by a handful of rays at most
