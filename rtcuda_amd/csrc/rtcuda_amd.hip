@@ -677,15 +677,18 @@ k_advance(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__
 //     scratch memory); entries are inner pair indices (>= 0) or leaf references (< 0).
 //
 // The box test only culls: it is conservative (boxes padded by the builder, exit distance widened
-// by 2 ulp) and may use any arithmetic.  The triangle test is the reference's, bit for bit.
+// by 8 ulp) and may use any arithmetic.  The triangle test is the reference's, bit for bit.
 struct RayPrep {
     V3 o, d, inv;
 };
 __device__ __forceinline__ V3 inv_dir(V3 d) {
-    // aabb_intersector.cuh:17-19 clamps |d| away from 0 the same way before inverting
-    float ix = 1.f / ((fabsf(d.x) < kFltEps) ? copysignf(kFltEps, d.x) : d.x);
-    float iy = 1.f / ((fabsf(d.y) < kFltEps) ? copysignf(kFltEps, d.y) : d.y);
-    float iz = 1.f / ((fabsf(d.z) < kFltEps) ? copysignf(kFltEps, d.z) : d.z);
+    // aabb_intersector.cuh:17-19 clamps |d| away from 0 the same way before inverting.  The reciprocal itself is the
+    // hardware's v_rcp_f32 (1 ulp) rather than an IEEE division (11 instructions each, three per ray): 1 / d only feeds
+    // the box test, which only culls -- box_hit / inner_step widen the exit distance by 8 ulps, which covers the 1 ulp
+    // per axis this costs on top of the rounding of the slab arithmetic (the builder pads every box by 2 ulps)
+    float ix = __builtin_amdgcn_rcpf((fabsf(d.x) < kFltEps) ? copysignf(kFltEps, d.x) : d.x);
+    float iy = __builtin_amdgcn_rcpf((fabsf(d.y) < kFltEps) ? copysignf(kFltEps, d.y) : d.y);
+    float iz = __builtin_amdgcn_rcpf((fabsf(d.z) < kFltEps) ? copysignf(kFltEps, d.z) : d.z);
     return mk(ix, iy, iz);
 }
 __device__ __forceinline__ bool box_hit(V3 o, V3 inv, float lox, float loy, float loz, float hix, float hiy,
@@ -696,7 +699,7 @@ __device__ __forceinline__ bool box_hit(V3 o, V3 inv, float lox, float loy, floa
     float t_in = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
     float t_out = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
     entry = t_in;
-    t_out = t_out * 1.0000004f;
+    t_out = t_out * 1.000001f;
     return t_in <= t_out && t_out >= 0.f && t_in <= tmax;
 }
 
@@ -705,13 +708,25 @@ constexpr int kEntryDone = (int)0x80000000;  // "nothing left to visit" marker f
 // Traversal stack: the first `cap` entries of a lane live in its LDS column, deeper ones (rare: the
 // bound is 3 per tree level, the typical depth under 10) in a per-lane column of a global overflow
 // buffer, so LDS use -- and with it occupancy -- is set by the common case, not the worst case.
-__device__ __forceinline__ void stack_push(int *lds_col, int *over_col, int &sp, int cap, int v) {
+// (`col` != kNoCol: `over_col` is the buffer's uniform base and the lane's column index comes as a 32-bit offset --
+// one VGPR instead of a 64-bit per-lane pointer)
+constexpr unsigned kNoCol = 0xffffffffu;
+__device__ __forceinline__ void stack_push(int *lds_col, int *over_col, int &sp, int cap, int v, unsigned col = kNoCol) {
     if (sp < cap) lds_col[sp * kBlock] = v;
+    else if (col != kNoCol) over_col[col + (unsigned)(sp - cap) * (unsigned)kOverStride] = v;
     else over_col[(size_t)(sp - cap) * kOverStride] = v;
     sp++;
 }
-__device__ __forceinline__ int stack_pop(int *lds_col, int *over_col, int &sp, int cap) {
+__device__ __forceinline__ int stack_pop(int *lds_col, int *over_col, int &sp, int cap, unsigned col = kNoCol) {
     sp--;
+    if (col != kNoCol) {
+        int v = lds_col[min(sp, cap - 1) * kBlock];
+        if (sp >= cap) {
+            v = over_col[col + (unsigned)(sp - cap) * (unsigned)kOverStride];
+            __asm__ volatile("" ::: "memory");
+        }
+        return v;
+    }
     // always read the LDS column (clamped) and patch from the overflow only when needed: written as a
     // select of two pointers, the compiler merges the paths into one FLAT load, which is slower
     int v = lds_col[min(sp, cap - 1) * kBlock];
@@ -740,7 +755,8 @@ __device__ __forceinline__ int leaf_ref(int first, int count) { return ~((first 
 // in LDS by the caller; nullptr / 0 otherwise.
 template <bool WIDE>
 __device__ __forceinline__ void inner_step(const DScene &sc, V3 o, V3 inv, float tmax, int &cur, int &sp, int *stack,
-                                           int *over, int stack_cap, const float4 *top = nullptr, int top_n = 0) {
+                                           int *over, int stack_cap, const float4 *top = nullptr, int top_n = 0,
+                                           unsigned over_col = kNoCol) {
     float4 q0, q1, q2, q3;
     if (top_n > 0 && cur < top_n) {
         const float4 *q = top + 4 * cur;
@@ -773,19 +789,19 @@ __device__ __forceinline__ void inner_step(const DScene &sc, V3 o, V3 inv, float
         const float er = fmaxf(fmaxf(fminf(ax.y, bx.y), fminf(ay.y, by.y)), fminf(az.y, bz.y));
         v2f t_out = {fminf(fminf(fmaxf(ax.x, bx.x), fmaxf(ay.x, by.x)), fmaxf(az.x, bz.x)),
                      fminf(fminf(fmaxf(ax.y, bx.y), fmaxf(ay.y, by.y)), fmaxf(az.y, bz.y))};
-        t_out = t_out * v2f{1.0000004f, 1.0000004f};
+        t_out = t_out * v2f{1.000001f, 1.000001f};
         bool hl = el <= t_out.x && t_out.x >= 0.f && el <= tmax && cl != kEntryDone;
         bool hr = er <= t_out.y && t_out.y >= 0.f && er <= tmax && cr != kEntryDone;
         if (hl && hr) {
             bool left_first = !(el > er);
-            stack_push(stack, over, sp, stack_cap, left_first ? cr : cl);
+            stack_push(stack, over, sp, stack_cap, left_first ? cr : cl, over_col);
             cur = left_first ? cl : cr;
         } else if (hl) {
             cur = cl;
         } else if (hr) {
             cur = cr;
         } else if (sp > 0) {
-            cur = stack_pop(stack, over, sp, stack_cap);
+            cur = stack_pop(stack, over, sp, stack_cap, over_col);
         } else {
             cur = kEntryDone;
         }
@@ -1574,7 +1590,7 @@ template <bool LDS_TABLES, int S, int MIN_WAVES>
 __global__ void __launch_bounds__(kBlock, MIN_WAVES)
 k_flow(DScene sc, DPools p, Camera cam_arg, AdvanceParams ap_arg, float *__restrict__ fb, DWaveRow *__restrict__ rows,
        int stack_cap, int *overflow, float4 *__restrict__ ray_buf, int adv_batch, int turn_at, int debug_no_deposit,
-       int prio_period, int rot_wave, int rot_set) {
+       int prio_period, int rot_wave, int rot_set, unsigned long long *prof) {
     constexpr int kCold = 16;                          // dword arrays per position: see the enum below
     constexpr int kWaveDwords = (kCold + 1) * S + S / 2 + S;  // cold + slot_of + adv ring (u16) + ray ring (u16, 2S entries)
     enum { F_BOUNCES, F_PIXEL, F_GEN, F_RD, F_R0, F_R1, F_R2, F_R3, F_R4, F_BX, F_BY, F_BZ, F_SPARE, F_L0, F_L1, F_L2 };
@@ -1582,7 +1598,7 @@ k_flow(DScene sc, DPools p, Camera cam_arg, AdvanceParams ap_arg, float *__restr
     // and a position's shadow ray is queued before its path ray) the hit record {triangle, u, v} of the path ray
     extern __shared__ int s_lds[];
     int *stack = s_lds + threadIdx.x;
-    int *over = overflow + (blockIdx.x * kBlock + threadIdx.x) % kOverStride;
+    const unsigned over_col = (blockIdx.x * kBlock + threadIdx.x) % (unsigned)kOverStride;  // this lane's overflow column
     const unsigned lane = lane_id();
     const int wave_in_block = (int)(threadIdx.x >> 6);
     int *wl = s_lds + stack_cap * kBlock + wave_in_block * kWaveDwords;  // this wave's area
@@ -1625,6 +1641,9 @@ k_flow(DScene sc, DPools p, Camera cam_arg, AdvanceParams ap_arg, float *__restr
         return (int)(set * (unsigned)lanes_in_grid + b * 64u + ((unsigned)j & 63u));
     };
     float4 *rb = ray_buf + (size_t)wave_in_grid * S * 4;  // 4 x float4 per position
+    // one float4 per LANE behind the records: {radiance, pixel} of the shadow ray the lane is tracing (kept out of
+    // the registers: only an unoccluded shadow ray reads it back, when it deposits)
+    const unsigned keep_at = (unsigned)(lanes_in_grid >> 6) * (unsigned)(S * 4) + (blockIdx.x * kBlock + threadIdx.x);
     // rings (wave-uniform)
     int adv_head = 0, adv_count = 0, ray_head = 0, ray_count = 0, next_j = 0;
     auto adv_push = [&](bool want, int q) {  // appends the positions of the lanes with `want`
@@ -1671,14 +1690,22 @@ k_flow(DScene sc, DPools p, Camera cam_arg, AdvanceParams ap_arg, float *__restr
     }
     next_j = min(S, n_list);
     // ---- per-lane ray state.  pos < 0: the lane has no ray.  `tri`: best hit so far / excluded triangle; `hu` doubles as
-    // the occluded flag of a shadow ray (as in k_trace); lr, lg, lb, pix: what an unoccluded shadow ray deposits, and where
-    int pos = -1, cur = kEntryDone, sp = 0, tri = -1, pix = 0;
-    bool is_any = false;
+    // the occluded flag of a shadow ray (as in k_trace)
+    // `pos`: position | kind << 15 (kind 1 = shadow ray)
+    constexpr int kAnyBit = 1 << 15;
+    int pos = -1, cur = kEntryDone, sp = 0, tri = -1;
     V3 o = mk(0, 0, 0), d = mk(0, 0, 0), inv = mk(0, 0, 0);
-    float tmax = 0.f, hu = 0.f, hv = 0.f, lr = 0.f, lg = 0.f, lb = 0.f;
+    float tmax = 0.f, hu = 0.f, hv = 0.f;
     unsigned long long n_gen = 0, n_shade = 0, n_traced = 0, n_shadow = 0, n_emit = 0, n_deposit = 0, n_rr = 0;
     unsigned prio_tick = 0;
     const unsigned prio_rank = (4u * blockIdx.x) / gridDim.x;
+#ifdef RT_TRACE_PROFILE
+    // [0] ADV blocks [1] ADV lanes [2] node blocks [3] node lanes [4] tri blocks [5] tri lanes [6] TURN blocks [7] lanes finalised
+    // [8] lanes refilled [9] ADV cycles [10] node cycles [11] tri cycles [12] TURN cycles [13] total cycles [14] waves
+    // [15] idle lanes (no ray) summed over node + tri blocks [16] finished lanes waiting, summed over node + tri blocks
+    unsigned long long pf[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long pf_t0 = __builtin_readcyclecounter();
+#endif
     while (true) {
         if (prio_period && (prio_tick++ & ((1u << prio_period) - 1u)) == 0u) {
             unsigned lvl = ((prio_tick >> prio_period) + prio_rank) & 3u;
@@ -1700,6 +1727,10 @@ k_flow(DScene sc, DPools p, Camera cam_arg, AdvanceParams ap_arg, float *__restr
         // ---------------- ADV block: a full batch is waiting, or nothing else can make progress
         if (adv_count >= adv_batch || (adv_count > 0 && n_busy == 0 && n_fin == 0 && ray_count == 0)) {
             const int m = min(adv_count, 64);
+#ifdef RT_TRACE_PROFILE
+            pf[0]++; pf[1] += m;
+            const unsigned long long pf_ta = __builtin_readcyclecounter();
+#endif
             const bool mine = (int)lane < m;
             int at = adv_head + (int)lane;
             at = at >= S ? at - S : at;
@@ -1818,15 +1849,26 @@ k_flow(DScene sc, DPools p, Camera cam_arg, AdvanceParams ap_arg, float *__restr
                 for (int off = 32; off > 0; off >>= 1) rr += __shfl_xor(rr, off);
                 n_rr += (unsigned long long)rr;
             }
+#ifdef RT_TRACE_PROFILE
+            pf[9] += __builtin_readcyclecounter() - pf_ta;
+#endif
             continue;
         }
         // ---------------- TURN block: hand finished rays back, take new ones.  Runs when enough lanes have nothing to
         // trace (and there is something to take or to hand back), or when no lane traces at all.
         if ((n_busy <= turn_at && (n_fin > 0 || ray_count > 0)) || (n_busy == 0 && (n_fin > 0 || ray_count > 0))) {
             const bool fin = pos >= 0 && cur == kEntryDone;
+            const bool is_any = (pos & kAnyBit) != 0;
+#ifdef RT_TRACE_PROFILE
+            pf[6]++; pf[7] += n_fin;
+            const unsigned long long pf_tt = __builtin_readcyclecounter();
+#endif
             if (fin) {
                 if (is_any) {
-                    if (hu == 0.f && !debug_no_deposit) deposit(fb, ap_fb_fixed, pix, lr, lg, lb);  // render.cuh:291-293
+                    if (hu == 0.f && !debug_no_deposit) {  // unoccluded: render.cuh:291-293
+                        const float4 kp = ray_buf[keep_at];
+                        deposit(fb, ap_fb_fixed, __float_as_int(kp.w), kp.x, kp.y, kp.z);
+                    }
                 } else {  // hit record of the path ray -> the position (render.cuh:311-316)
                     cold[F_L0 * S + pos] = tri;
                     cold[F_L1 * S + pos] = __float_as_int(hu);
@@ -1843,20 +1885,18 @@ k_flow(DScene sc, DPools p, Camera cam_arg, AdvanceParams ap_arg, float *__restr
                 int at = ray_head + r;
                 at = at >= 2 * S ? at - 2 * S : at;
                 const unsigned e = ray_q[at];
-                pos = (int)(e & 0x7fffu);
-                is_any = (e >> 15) != 0;
-                if (is_any) {
-                    const float4 a = rb[pos * 4 + 2], b = rb[pos * 4 + 3];
+                pos = (int)e;
+                const int q = (int)(e & 0x7fffu);
+                if (e & (unsigned)kAnyBit) {
+                    const float4 a = rb[q * 4 + 2], b = rb[q * 4 + 3];
                     o = mk(a.x, a.y, a.z);
                     d = mk(a.w, b.x, b.y);
                     tmax = b.z;
                     tri = __float_as_int(b.w);
-                    lr = __int_as_float(cold[F_L0 * S + pos]);
-                    lg = __int_as_float(cold[F_L1 * S + pos]);
-                    lb = __int_as_float(cold[F_L2 * S + pos]);
-                    pix = cold[F_PIXEL * S + pos];
+                    ray_buf[keep_at] = make_float4(__int_as_float(cold[F_L0 * S + q]), __int_as_float(cold[F_L1 * S + q]),
+                                        __int_as_float(cold[F_L2 * S + q]), __int_as_float(cold[F_PIXEL * S + q]));
                 } else {
-                    const float4 a = rb[pos * 4 + 0], b = rb[pos * 4 + 1];
+                    const float4 a = rb[q * 4 + 0], b = rb[q * 4 + 1];
                     d = mk(a.x, a.y, a.z);
                     o = mk(a.w, b.x, b.y);
                     tmax = kFltMax;
@@ -1870,18 +1910,36 @@ k_flow(DScene sc, DPools p, Camera cam_arg, AdvanceParams ap_arg, float *__restr
             ray_head += take;
             ray_head = ray_head >= 2 * S ? ray_head - 2 * S : ray_head;
             ray_count -= take;
+#ifdef RT_TRACE_PROFILE
+            pf[8] += take;
+            pf[12] += __builtin_readcyclecounter() - pf_tt;
+#endif
             continue;
         }
+#ifdef RT_TRACE_PROFILE
+        pf[15] += 64 - n_busy - n_fin; pf[16] += n_fin;
+        const unsigned long long pf_tn = __builtin_readcyclecounter();
+#endif
         // ---------------- node steps
         if (n_node > 0 && n_node >= n_tri) {
+#ifdef RT_TRACE_PROFILE
+            pf[2]++; pf[3] += n_node;
+#endif
             if (want_node) {
 #pragma unroll
                 for (int rep = 0; rep < kNodePerStep; rep++)
-                    if (cur >= 0) inner_step<false>(sc, o, inv, tmax, cur, sp, stack, over, stack_cap);
+                    if (cur >= 0) inner_step<false>(sc, o, inv, tmax, cur, sp, stack, overflow, stack_cap, nullptr, 0, over_col);
             }
+#ifdef RT_TRACE_PROFILE
+            pf[10] += __builtin_readcyclecounter() - pf_tn;
+#endif
         } else if (n_tri > 0) {
             // ---------------- triangle tests (triangle.cuh:39-58): the leaf reference is the cursor
+#ifdef RT_TRACE_PROFILE
+            pf[4]++; pf[5] += n_tri;
+#endif
             if (want_tri) {
+                const bool is_any = (pos & kAnyBit) != 0;
                 bool stop = false;
                 int reps = 0;
                 do {
@@ -1904,13 +1962,23 @@ k_flow(DScene sc, DPools p, Camera cam_arg, AdvanceParams ap_arg, float *__restr
                     }
                     if (stop) cur = kEntryDone;
                     else if (count > 1) cur = leaf_ref(k + 1, count - 1);
-                    else if (sp > 0) cur = stack_pop(stack, over, sp, stack_cap);
+                    else if (sp > 0) cur = stack_pop(stack, overflow, sp, stack_cap, over_col);
                     else cur = kEntryDone;
                     reps++;
                 } while (reps < kTriPerStep && cur != kEntryDone && cur < 0 && !stop);
             }
+#ifdef RT_TRACE_PROFILE
+            pf[11] += __builtin_readcyclecounter() - pf_tn;
+#endif
         }
     }
+#ifdef RT_TRACE_PROFILE
+    if (prof && lane == 0) {
+        pf[13] = __builtin_readcyclecounter() - pf_t0;
+        pf[14] = 1;
+        for (int k = 0; k < 20; k++) atomicAdd(&prof[k], pf[k]);
+    }
+#endif
     unsigned long long v[C_COUNT] = {n_gen, n_shade, n_traced, n_shadow, n_emit, n_deposit, n_rr, 0ull};
     row_add(rows, v);
 }
@@ -2637,7 +2705,8 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
             while (flow_blocks > per_cu * dev_cus_paths && flow_blocks % 2 == 0) flow_blocks /= 2;
             if (const char *e = getenv("RT_FLOW_BLOCKS")) flow_blocks = std::max(1, atoi(e));
             if (n % (flow_blocks * kBlock) != 0) return fail("rt_render_shard: RT_FLOW grid does not divide the shard");
-            const size_t records = (size_t)flow_blocks * (kBlock / 64) * (size_t)flow_s;
+            // 4 float4 per position + 1 float4 per lane (see k_flow: `keep`), counted in 64-byte records
+            const size_t records = (size_t)flow_blocks * (kBlock / 64) * (size_t)flow_s + (size_t)flow_blocks * kBlock / 4 + 1;
             if (c.ray_buf_records < records) {
                 if (c.d_ray_buf) (void)hipFree(c.d_ray_buf);
                 c.d_ray_buf = nullptr;
@@ -2659,10 +2728,26 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
             }
             if (flow_s == 96)
                 hipLaunchKernelGGL((k_flow<true, 96, 4>), dim3(flow_blocks), block, lds_flow, st, sc, c.pools, cam, ap, d_sum, c.d_rows,
-                                   paths_cap, d_over2, c.d_ray_buf, flow_adv, flow_turn, dbg, prio_rotate, fr_wave, fr_set);
+                                   paths_cap, d_over2, c.d_ray_buf, flow_adv, flow_turn, dbg, prio_rotate, fr_wave, fr_set, paths_prof);
             else
                 hipLaunchKernelGGL((k_flow<true, 128, 3>), dim3(flow_blocks), block, lds_flow, st, sc, c.pools, cam, ap, d_sum, c.d_rows,
-                                   paths_cap, d_over2, c.d_ray_buf, flow_adv, flow_turn, dbg, prio_rotate, fr_wave, fr_set);
+                                   paths_cap, d_over2, c.d_ray_buf, flow_adv, flow_turn, dbg, prio_rotate, fr_wave, fr_set, paths_prof);
+#ifdef RT_TRACE_PROFILE
+            {
+                HIP_TRY(hipStreamSynchronize(st));
+                unsigned long long h[24];
+                HIP_TRY(hipMemcpy(h, paths_prof, 192, hipMemcpyDeviceToHost));
+                const double tot = (double)h[13];
+                fprintf(stderr, "k_flow waves %llu | ADV blocks %llu avg lanes %.1f (%.1f%% of wave time, %.0f cyc/block) | node blocks %llu avg lanes %.1f (%.1f%%, %.0f) | "
+                                "tri blocks %llu avg lanes %.1f (%.1f%%, %.0f) | TURN blocks %llu fin %.1f refilled %.1f per block (%.1f%%, %.0f) | rest %.1f%% | in node+tri blocks: idle lanes %.1f, finished-waiting lanes %.1f\n",
+                        h[14], h[0], h[0] ? (double)h[1] / h[0] : 0.0, 100.0 * h[9] / tot, h[0] ? (double)h[9] / h[0] : 0.0, h[2], h[2] ? (double)h[3] / h[2] : 0.0,
+                        100.0 * h[10] / tot, h[2] ? (double)h[10] / h[2] : 0.0, h[4], h[4] ? (double)h[5] / h[4] : 0.0, 100.0 * h[11] / tot,
+                        h[4] ? (double)h[11] / h[4] : 0.0, h[6], h[6] ? (double)h[7] / h[6] : 0.0, h[6] ? (double)h[8] / h[6] : 0.0, 100.0 * h[12] / tot,
+                        h[6] ? (double)h[12] / h[6] : 0.0, 100.0 * (tot - h[9] - h[10] - h[11] - h[12]) / tot,
+                        (h[2] + h[4]) ? (double)h[15] / (h[2] + h[4]) : 0.0, (h[2] + h[4]) ? (double)h[16] / (h[2] + h[4]) : 0.0);
+                HIP_TRY(hipMemset(paths_prof, 0, 192));
+            }
+#endif
         } else {
 // MIN_WAVES: 4 waves per SIMD (128 VGPRs, some spills) when the grid fills the chip, 2 (256 VGPRs, no
         // spills) when the shard is so small that only 2 workgroups per CU exist anyway (8-GPU runs)
