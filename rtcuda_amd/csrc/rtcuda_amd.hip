@@ -362,6 +362,27 @@ __device__ __forceinline__ void deposit(float *__restrict__ fb, int fixed, int p
     }
 }
 
+// Per-lane sample accumulator of k_paths (3 floats in the lane's LDS column, element k at acc[k * kBlock]): the
+// contributions of ONE camera ray -- bounce-0 emission, then the unoccluded shadow rays in path order -- are summed here
+// and reach the framebuffer as one atomic triple when the slot starts its next camera ray (the reference issues one
+// atomic triple per contribution, in an order that differs from run to run: vec3.cuh:149-153).  A float atomic is a
+// fabric transaction whose acknowledgement a wave's later loads queue behind (vmcnt is in order), so the frame has
+// 0.5 G of them instead of 1.0 G and they sit in the GEN block instead of the traversal loop: +4 %.
+__device__ __forceinline__ void acc_add(float *acc, float r, float g, float b) {
+    acc[0 * kBlock] += r;
+    acc[1 * kBlock] += g;
+    acc[2 * kBlock] += b;
+}
+__device__ __forceinline__ void acc_flush(float *acc, float *__restrict__ fb, int fixed, int pixel) {
+    const float r = acc[0 * kBlock], g = acc[1 * kBlock], b = acc[2 * kBlock];
+    if (r != 0.f || g != 0.f || b != 0.f) {  // (a NaN contribution compares unequal to 0: it is deposited)
+        deposit(fb, fixed, pixel, r, g, b);
+        acc[0 * kBlock] = 0.f;
+        acc[1 * kBlock] = 0.f;
+        acc[2 * kBlock] = 0.f;
+    }
+}
+
 struct SlotState {
     int bounces, hit_info, pixel, gen;
     Rng rs;
@@ -420,10 +441,11 @@ __device__ __forceinline__ void gen_core(const Camera &cam, const AdvanceParams 
     out.did_gen = true;
 }
 
+// `acc` (k_paths only): the lane's sample accumulator; nullptr = deposit straight into the framebuffer.
 template <bool DEFER_GEN>
 __device__ __forceinline__ void advance_core(const DScene &sc, const float *tab, const Camera &cam,
                                              const AdvanceParams &ap, int slot_global, SlotState &st, AdvanceOut &out,
-                                             float *__restrict__ fb) {
+                                             float *__restrict__ fb, float *acc = nullptr) {
     const int off_ltri = tab_off_ltri(sc.num_mats, sc.num_lights);
     const int off_lpre = tab_off_lpre(sc.num_mats, sc.num_lights);
     out.did_gen = out.did_shade = out.has_shadow = out.did_emit = out.new_ray = out.wants_gen = false;
@@ -436,7 +458,8 @@ __device__ __forceinline__ void advance_core(const DScene &sc, const float *tab,
     // along such a chain, so the chain is a tight loop of draws.  `lockstep`: exactly one init() per call.
     if (st.bounces == 0 && hit && light_of_hit >= 0) {  // :98-103 emission only at bounce 0
         Light l = tab_light(tab, sc.num_mats, light_of_hit);
-        deposit(fb, ap.fb_fixed, st.pixel, l.lx, l.ly, l.lz);
+        if (acc) acc_add(acc, l.lx, l.ly, l.lz);
+        else deposit(fb, ap.fb_fixed, st.pixel, l.lx, l.ly, l.lz);
         out.did_emit = true;
     }
     const bool cont = st.bounces < ap.max_bounces;  // :109
@@ -473,6 +496,7 @@ __device__ __forceinline__ void advance_core(const DScene &sc, const float *tab,
             out.wants_gen = true;
             return;
         }
+        if (acc) acc_flush(acc, fb, ap.fb_fixed, st.pixel);  // the camera ray that ends here: its sum -> its pixel
         gen_core(cam, ap, slot_global, st, out);
         return;
     }
@@ -1121,7 +1145,7 @@ constexpr int kNodePerStep = RT_NODE_PER_STEP;  // node steps a lane makes per s
 // beta = 12 dwords) lives in the lane's LDS column and is only in registers inside the ADV block;
 // while a shadow ray is traced, the slot's path ray and the radiance to deposit wait in 9 more
 // dwords of LDS; the hit record is rebuilt from (tri, hu, hv) inside the ADV block.
-// LDS layout (dynamic): [stack: stack_cap x kBlock][parked ray: 9 x kBlock][slot state: 12 + 1 x kBlock][tables]
+// LDS layout (dynamic): [stack: stack_cap x kBlock][parked ray: 9 x kBlock][slot state: 12 + 1 x kBlock][sample sum: 3 x kBlock][tables]
 template <bool LDS_TABLES, bool WIDE, bool MAJORITY, int MIN_WAVES>
 __global__ void __launch_bounds__(kBlock, MIN_WAVES)
 k_paths(DScene sc, DPools p, Camera cam_arg, AdvanceParams ap_arg, float *__restrict__ fb, DWaveRow *__restrict__ rows,
@@ -1136,7 +1160,8 @@ k_paths(DScene sc, DPools p, Camera cam_arg, AdvanceParams ap_arg, float *__rest
     float *park = (float *)(s_lds + stack_cap * kBlock) + threadIdx.x;  // element k at park[k * kBlock]
     int *over = overflow + (blockIdx.x * kBlock + threadIdx.x) % kOverStride;
     int *cold = s_lds + (stack_cap + 9) * kBlock + threadIdx.x;  // element k at cold[k * kBlock]
-    float *s_tab = (float *)(s_lds + (stack_cap + 22) * kBlock);
+    float *acc = (float *)(s_lds + (stack_cap + 22) * kBlock) + threadIdx.x;  // sample accumulator (acc_add / acc_flush)
+    float *s_tab = (float *)(s_lds + (stack_cap + 25) * kBlock);
     const float *tab = sc.tables;
     // small shards (MIN_WAVES == 2: at most 2 workgroups per CU, LDS to spare, latency-bound): the top of
     // the BVH is staged in LDS, so the first levels of every traversal do not leave the CU
@@ -1247,6 +1272,7 @@ k_paths(DScene sc, DPools p, Camera cam_arg, AdvanceParams ap_arg, float *__rest
     V3 o = mk(0, 0, 0), d = mk(0, 0, 0), inv = mk(0, 0, 0);
     float tmax = 0.f, hu = 0.f, hv = 0.f;
     int cur = kEntryDone, sp = 0, tri = -1;
+    acc[0 * kBlock] = acc[1 * kBlock] = acc[2 * kBlock] = 0.f;
     if (i < ap_n) {
         load_slot(i);
         phase = (bounces != kDone && bounces != kParked) ? (SPLIT_GEN ? PH_GEN : PH_ADV) : PH_IDLE;  // (untouched slots: bounces = INT_MAX)
@@ -1321,6 +1347,7 @@ k_paths(DScene sc, DPools p, Camera cam_arg, AdvanceParams ap_arg, float *__rest
                 st.pixel = 0;
                 st.beta = mk(0, 0, 0);
                 int pxy = cold[12 * kBlock];
+                acc_flush(acc, fb, ap_fb_fixed, cold[1 * kBlock]);  // the camera ray that ended: its sum -> its pixel
                 gen_core(cam, ap, ap.slot_lo + i, st, out, &pxy);
                 if (out.new_ray) {
                     cold[12 * kBlock] = pxy;
@@ -1397,7 +1424,7 @@ k_paths(DScene sc, DPools p, Camera cam_arg, AdvanceParams ap_arg, float *__rest
                     st.isect_n = mk(sh.x, sh.y, sh.z);
                     st.hit_info = __float_as_int(sh.w);
                 }
-                advance_core<SPLIT_GEN>(sc, tab, cam, ap, ap.slot_lo + i, st, out, fb);
+                advance_core<SPLIT_GEN>(sc, tab, cam, ap, ap.slot_lo + i, st, out, fb, acc);
                 bounces = st.bounces;
                 pixel = st.pixel;
                 gen = st.gen;
@@ -1526,10 +1553,8 @@ k_paths(DScene sc, DPools p, Camera cam_arg, AdvanceParams ap_arg, float *__rest
         n_deposit += wave_count((fin && is_any && hu == 0.f));
         if (fin) {
             if (is_any) {
-                if (hu == 0.f && !debug_no_deposit) {  // unoccluded: render.cuh:291-293
-                    const int pixel = cold[1 * kBlock];
-                    deposit(fb, ap_fb_fixed, pixel, park[6 * kBlock], park[7 * kBlock], park[8 * kBlock]);
-                }
+                if (hu == 0.f && !debug_no_deposit)  // unoccluded: render.cuh:291-293
+                    acc_add(acc, park[6 * kBlock], park[7 * kBlock], park[8 * kBlock]);
                 // now the slot's path ray
                 o = mk(park[0 * kBlock], park[1 * kBlock], park[2 * kBlock]);
                 d = mk(park[3 * kBlock], park[4 * kBlock], park[5 * kBlock]);
@@ -2641,7 +2666,7 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
         if (const char *e = getenv("RT_ADV_BATCH")) adv_batch = std::max(1, std::min(64, atoi(e)));
         const int paths_cap = std::min(8, std::max(1, scene->stack_bound));
         int *const d_over2 = d_over;
-        size_t lds_paths = sizeof(int) * (size_t)kBlock * (size_t)(paths_cap + 22) + (lds_tables ? sizeof(float) * (size_t)((scene->tab_dwords + 3) & ~3) : 0) +
+        size_t lds_paths = sizeof(int) * (size_t)kBlock * (size_t)(paths_cap + 25) + (lds_tables ? sizeof(float) * (size_t)((scene->tab_dwords + 3) & ~3) : 0) +
                            sizeof(Camera) + sizeof(AdvanceParams);
         bool majority = true;
         if (const char *e = getenv("RT_MAJORITY")) majority = atoi(e) != 0;
