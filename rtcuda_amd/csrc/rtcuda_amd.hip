@@ -781,6 +781,8 @@ template <bool WIDE>
 __device__ __forceinline__ void inner_step(const DScene &sc, V3 o, V3 inv, float tmax, int &cur, int &sp, int *stack,
                                            int *over, int stack_cap, const float4 *top = nullptr, int top_n = 0,
                                            unsigned over_col = kNoCol) {
+    // (2-wide records) the top of the LDS part of the stack, in case this step ends in a pop: see below
+    const int spec_top = WIDE ? 0 : stack[max(min(sp - 1, stack_cap - 1), 0) * kBlock];
     float4 q0, q1, q2, q3;
     if (top_n > 0 && cur < top_n) {
         const float4 *q = top + 4 * cur;
@@ -816,19 +818,24 @@ __device__ __forceinline__ void inner_step(const DScene &sc, V3 o, V3 inv, float
         t_out = t_out * v2f{1.000001f, 1.000001f};
         bool hl = el <= t_out.x && t_out.x >= 0.f && el <= tmax && cl != kEntryDone;
         bool hr = er <= t_out.y && t_out.y >= 0.f && er <= tmax && cr != kEntryDone;
-        if (hl && hr) {
-            bool left_first = !(el > er);
-            stack_push(stack, over, sp, stack_cap, left_first ? cr : cl, over_col);
-            cur = left_first ? cl : cr;
-        } else if (hl) {
-            cur = cl;
-        } else if (hr) {
-            cur = cr;
-        } else if (sp > 0) {
-            cur = stack_pop(stack, over, sp, stack_cap, over_col);
-        } else {
-            cur = kEntryDone;
+        // What comes next, with as little divergent control flow as the three outcomes allow (every divergent branch
+        // costs the wave an exec-mask save / restore pair and a jump, a dozen scalar instructions per step before):
+        //   one child entered  -> it becomes the cursor;
+        //   both               -> the nearer one, the farther one onto the stack (the only branch left, a single store);
+        //   none               -> the top of the stack, read speculatively BEFORE the slab arithmetic (`spec_top`), so
+        //                         that the LDS latency of a pop is never on the critical path of a step.
+        const bool both = hl && hr, none = !(hl || hr);
+        const bool left_first = !(el > er);
+        int popped = sp > 0 ? spec_top : kEntryDone;
+        if (none && sp > stack_cap) {  // rare: the entry lives in the global overflow part
+            popped = over_col != kNoCol ? over[over_col + (unsigned)(sp - 1 - stack_cap) * (unsigned)kOverStride]
+                                        : over[(size_t)(sp - 1 - stack_cap) * kOverStride];
+            __asm__ volatile("" ::: "memory");
         }
+        const int entered = (hl && (!hr || left_first)) ? cl : cr;
+        cur = none ? popped : entered;
+        sp -= (none && sp > 0) ? 1 : 0;
+        if (both) stack_push(stack, over, sp, stack_cap, left_first ? cr : cl, over_col);
     }
     if (WIDE) {
         const unsigned exps = __float_as_uint(q0.w);
@@ -1139,6 +1146,10 @@ constexpr int kTriPerStep = RT_TRI_PER_STEP;  // triangle tests a lane makes per
 #define RT_NODE_PER_STEP 8
 #endif
 constexpr int kNodePerStep = RT_NODE_PER_STEP;  // node steps a lane makes per scheduled node block
+#ifndef RT_SPECULATE
+#define RT_SPECULATE 1
+#endif
+constexpr bool kSpeculate = RT_SPECULATE != 0;  // k_paths: postpone a leaf reached inside a node block (see `pend` there)
 
 // Register diet: across loop iterations a lane carries only ONE ray (o, d, 1/d, tmax) and the
 // traversal cursor (cur, sp, tri, hu, hv).  The slot's persistent state (bounces, pixel, gen, RNG,
@@ -1272,6 +1283,13 @@ k_paths(DScene sc, DPools p, Camera cam_arg, AdvanceParams ap_arg, float *__rest
     V3 o = mk(0, 0, 0), d = mk(0, 0, 0), inv = mk(0, 0, 0);
     float tmax = 0.f, hu = 0.f, hv = 0.f;
     int cur = kEntryDone, sp = 0, tri = -1;
+    // Speculative traversal (kSpeculate): a lane that reaches a leaf inside a node block does not stop there -- it sets
+    // the leaf aside in `pend` and goes on with the next stack entry, so the up-to-8 node steps of a block are used by
+    // most lanes to the end (without it half of them idle from the middle of the block on), and the triangle block
+    // finds two leaves per lane.  The triangles of the postponed leaf are tested a little later, with whatever tmax the
+    // ray has then: the closest hit is the minimum over the accepted hits whatever the order (ties: closest_hit_wins),
+    // an occluder is an occluder whenever it is found; the price is a few node visits a fresher tmax would have culled.
+    int pend = kEntryDone;
     acc[0 * kBlock] = acc[1 * kBlock] = acc[2 * kBlock] = 0.f;
     if (i < ap_n) {
         load_slot(i);
@@ -1312,7 +1330,7 @@ k_paths(DScene sc, DPools p, Camera cam_arg, AdvanceParams ap_arg, float *__rest
         // ---- what each lane wants next: the ADV block, a node step, or triangle tests
         const bool trav = phase == PH_ANY || phase == PH_CLOSEST;
         const bool want_node = trav && cur >= 0;
-        const bool want_tri = trav && cur != kEntryDone && cur < 0;
+        const bool want_tri = trav && ((cur != kEntryDone && cur < 0) || (kSpeculate && pend != kEntryDone));
         const int n_adv = wave_count((phase == PH_ADV));
         const int n_genw = wave_count((phase == PH_GEN));
         const int n_node = wave_count((want_node));
@@ -1470,12 +1488,15 @@ k_paths(DScene sc, DPools p, Camera cam_arg, AdvanceParams ap_arg, float *__rest
                     }
                 }
                 if (phase == PH_ANY || phase == PH_CLOSEST) {
-                    inv = inv_dir(d);
                     cur = 0;
                     sp = 0;
                 }
                 if (phase != PH_IDLE) cold_save();
             }
+            // 1 / d for EVERY lane, also those that only sat through the block: three v_rcp_f32, and 1 / d does not have
+            // to stay in registers across the ~1 500 instructions of the block -- those three registers are what
+            // decides between a build with and without spills at 128 VGPRs
+            inv = inv_dir(d);
             if (!SPLIT_GEN) n_gen += wave_count((out.did_gen));
             n_shade += wave_count((out.did_shade));
             n_traced += wave_count((out.new_ray));
@@ -1502,8 +1523,14 @@ k_paths(DScene sc, DPools p, Camera cam_arg, AdvanceParams ap_arg, float *__rest
                 // a bounded while-while: up to kNodePerStep consecutive node steps (2 triangle tests in the
                 // triangle block) per scheduling decision -- measured best at 8 / 2 (+22 % over 1 / 1; 4 / 2: +20 %)
 #pragma unroll
-                for (int rep = 0; rep < kNodePerStep; rep++)
-                    if (cur >= 0) inner_step<WIDE>(sc, o, inv, tmax, cur, sp, stack, over, stack_cap, s_top, top_n);
+                for (int rep = 0; rep < kNodePerStep; rep++) {
+                    if (cur >= 0) {
+                        inner_step<WIDE>(sc, o, inv, tmax, cur, sp, stack, over, stack_cap, s_top, top_n);
+                    } else if (kSpeculate && cur != kEntryDone && pend == kEntryDone && sp > 0) {
+                        pend = cur;  // a leaf: set it aside, go on with the next entry
+                        cur = stack_pop(stack, over, sp, stack_cap);
+                    }
+                }
             }
 #ifdef RT_TRACE_PROFILE
             pf[9] += __builtin_readcyclecounter() - pf_tn;
@@ -1519,7 +1546,8 @@ k_paths(DScene sc, DPools p, Camera cam_arg, AdvanceParams ap_arg, float *__rest
                 bool stop = false;
                 int reps = 0;
                 do {
-                    int ref = ~cur;
+                    const bool from_pend = kSpeculate && pend != kEntryDone;  // the postponed leaf first
+                    int ref = ~(from_pend ? pend : cur);
                     int k = ref >> 3, count = ref & 7;
                     Tri tr = load_tri(sc.tris, k);
                     float t, u, v;
@@ -1536,20 +1564,29 @@ k_paths(DScene sc, DPools p, Camera cam_arg, AdvanceParams ap_arg, float *__rest
                             tri = k;
                         }
                     }
-                    if (stop) cur = kEntryDone;
-                    else if (count > 1) cur = leaf_ref(k + 1, count - 1);
-                    else if (sp > 0) cur = stack_pop(stack, over, sp, stack_cap);
-                    else cur = kEntryDone;
+                    if (stop) {
+                        cur = kEntryDone;
+                        pend = kEntryDone;
+                    } else if (from_pend) {
+                        pend = count > 1 ? leaf_ref(k + 1, count - 1) : kEntryDone;
+                    } else if (count > 1) {
+                        cur = leaf_ref(k + 1, count - 1);
+                    } else if (sp > 0) {
+                        cur = stack_pop(stack, over, sp, stack_cap);
+                    } else {
+                        cur = kEntryDone;
+                    }
                     reps++;
                     // MAJORITY: kTriPerStep triangles per step; otherwise the whole leaf (and chained leaves) now
-                } while ((!MAJORITY || reps < kTriPerStep) && cur != kEntryDone && cur < 0 && !stop);
+                } while ((!MAJORITY || reps < kTriPerStep) && !stop &&
+                         ((cur != kEntryDone && cur < 0) || (kSpeculate && pend != kEntryDone)));
             }
 #ifdef RT_TRACE_PROFILE
             pf[10] += __builtin_readcyclecounter() - pf_tt;
 #endif
         }
         // ---------------- finished rays
-        const bool fin = trav && cur == kEntryDone;
+        const bool fin = trav && cur == kEntryDone && (!kSpeculate || pend == kEntryDone);
         n_deposit += wave_count((fin && is_any && hu == 0.f));
         if (fin) {
             if (is_any) {
