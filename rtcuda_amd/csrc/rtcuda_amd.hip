@@ -732,25 +732,13 @@ constexpr int kEntryDone = (int)0x80000000;  // "nothing left to visit" marker f
 // Traversal stack: the first `cap` entries of a lane live in its LDS column, deeper ones (rare: the
 // bound is 3 per tree level, the typical depth under 10) in a per-lane column of a global overflow
 // buffer, so LDS use -- and with it occupancy -- is set by the common case, not the worst case.
-// (`col` != kNoCol: `over_col` is the buffer's uniform base and the lane's column index comes as a 32-bit offset --
-// one VGPR instead of a 64-bit per-lane pointer)
-constexpr unsigned kNoCol = 0xffffffffu;
-__device__ __forceinline__ void stack_push(int *lds_col, int *over_col, int &sp, int cap, int v, unsigned col = kNoCol) {
+__device__ __forceinline__ void stack_push(int *lds_col, int *over_col, int &sp, int cap, int v) {
     if (sp < cap) lds_col[sp * kBlock] = v;
-    else if (col != kNoCol) over_col[col + (unsigned)(sp - cap) * (unsigned)kOverStride] = v;
     else over_col[(size_t)(sp - cap) * kOverStride] = v;
     sp++;
 }
-__device__ __forceinline__ int stack_pop(int *lds_col, int *over_col, int &sp, int cap, unsigned col = kNoCol) {
+__device__ __forceinline__ int stack_pop(int *lds_col, int *over_col, int &sp, int cap) {
     sp--;
-    if (col != kNoCol) {
-        int v = lds_col[min(sp, cap - 1) * kBlock];
-        if (sp >= cap) {
-            v = over_col[col + (unsigned)(sp - cap) * (unsigned)kOverStride];
-            __asm__ volatile("" ::: "memory");
-        }
-        return v;
-    }
     // always read the LDS column (clamped) and patch from the overflow only when needed: written as a
     // select of two pointers, the compiler merges the paths into one FLAT load, which is slower
     int v = lds_col[min(sp, cap - 1) * kBlock];
@@ -779,8 +767,7 @@ __device__ __forceinline__ int leaf_ref(int first, int count) { return ~((first 
 // in LDS by the caller; nullptr / 0 otherwise.
 template <bool WIDE>
 __device__ __forceinline__ void inner_step(const DScene &sc, V3 o, V3 inv, float tmax, int &cur, int &sp, int *stack,
-                                           int *over, int stack_cap, const float4 *top = nullptr, int top_n = 0,
-                                           unsigned over_col = kNoCol) {
+                                           int *over, int stack_cap, const float4 *top = nullptr, int top_n = 0) {
     // (2-wide records) the top of the LDS part of the stack, in case this step ends in a pop: see below
     const int spec_top = WIDE ? 0 : stack[max(min(sp - 1, stack_cap - 1), 0) * kBlock];
     float4 q0, q1, q2, q3;
@@ -828,14 +815,13 @@ __device__ __forceinline__ void inner_step(const DScene &sc, V3 o, V3 inv, float
         const bool left_first = !(el > er);
         int popped = sp > 0 ? spec_top : kEntryDone;
         if (none && sp > stack_cap) {  // rare: the entry lives in the global overflow part
-            popped = over_col != kNoCol ? over[over_col + (unsigned)(sp - 1 - stack_cap) * (unsigned)kOverStride]
-                                        : over[(size_t)(sp - 1 - stack_cap) * kOverStride];
+            popped = over[(size_t)(sp - 1 - stack_cap) * kOverStride];
             __asm__ volatile("" ::: "memory");
         }
         const int entered = (hl && (!hr || left_first)) ? cl : cr;
         cur = none ? popped : entered;
         sp -= (none && sp > 0) ? 1 : 0;
-        if (both) stack_push(stack, over, sp, stack_cap, left_first ? cr : cl, over_col);
+        if (both) stack_push(stack, over, sp, stack_cap, left_first ? cr : cl);
     }
     if (WIDE) {
         const unsigned exps = __float_as_uint(q0.w);
@@ -1623,428 +1609,6 @@ k_paths(DScene sc, DPools p, Camera cam_arg, AdvanceParams ap_arg, float *__rest
     row_add(rows, v);
 }
 
-// ============================================================================ k_flow
-// The asynchronous part of a frame as a persistent launch again, but with the binding between LANES and path SLOTS
-// removed: a wave is a small wavefront machine of its own.
-//   * The wave owns S slot POSITIONS (S = 96 or 128, i.e. 1.5x - 2x more paths than lanes) out of its share of the
-//     shard's slots; a position's persistent state (bounces, pixel, generation, RNG, beta: what the reference keeps in
-//     PathRayPayload + curandState, render.cuh:10-18,52) lives in the wave's LDS area, structure-of-arrays by position.
-//   * Two wave-local FIFO rings replace the reference's four global queues + CUB compactions (render.cuh:33-46,
-//     348-364): `adv` (positions whose path ray has come back and now need init() + mat() / gen()) and `ray`
-//     (rays ready to be traced: a position's shadow ray and its path ray are separate entries, so they are traced
-//     by two lanes at the same time).  Both are filled and drained with ballot + mbcnt prefix sums; head, tail and
-//     count are wave-uniform scalars.  No atomics, no barriers: nothing is shared between waves.
-//   * Rays in the `ray` ring wait in a 64-byte record per position in global memory (written and read by this wave
-//     only: it stays in the CU's L1 / the XCD's L2); a lane copies a ray into registers when it picks it up.
-//   * Every iteration the wave issues ONE block for all its lanes:
-//       ADV      advance_core (init + mat + gen) for up to 64 positions popped from the `adv` ring -- always a
-//                (nearly) full wave, whatever the lanes were doing, because the work comes from the ring;
-//       TURN     lanes whose ray has finished hand the result back (hit record -> position, position -> `adv` ring;
-//                unoccluded shadow ray -> framebuffer) and idle lanes take the next rays from the `ray` ring;
-//       NODE / TRI  as in k_paths: up to 8 node steps / 2 triangle tests, the more popular of the two.
-//     Since there are more positions than lanes, a lane that finishes a ray normally finds another one waiting: the
-//     idle lanes of k_paths (a lane there waits while ITS slot waits for the ADV block) do not exist, and the shading
-//     block runs at 64 lanes instead of ~34.
-// What is unchanged: the estimator (advance_core, gen_core, inner_step, tri_intersect are the same functions), the
-// slot <-> camera ray <-> RNG stream relation (a position holds one slot for that slot's whole frame, then takes the
-// wave's next slot), the lockstep final generation (slots park at last_gen and go back to the pools).
-template <bool LDS_TABLES, int S, int MIN_WAVES>
-__global__ void __launch_bounds__(kBlock, MIN_WAVES)
-k_flow(DScene sc, DPools p, Camera cam_arg, AdvanceParams ap_arg, float *__restrict__ fb, DWaveRow *__restrict__ rows,
-       int stack_cap, int *overflow, float4 *__restrict__ ray_buf, int adv_batch, int turn_at, int debug_no_deposit,
-       int prio_period, int rot_wave, int rot_set, unsigned long long *prof) {
-    constexpr int kCold = 16;                          // dword arrays per position: see the enum below
-    constexpr int kWaveDwords = (kCold + 1) * S + S / 2 + S;  // cold + slot_of + adv ring (u16) + ray ring (u16, 2S entries)
-    enum { F_BOUNCES, F_PIXEL, F_GEN, F_RD, F_R0, F_R1, F_R2, F_R3, F_R4, F_BX, F_BY, F_BZ, F_SPARE, F_L0, F_L1, F_L2 };
-    // F_L0..F_L2: radiance of the position's queued shadow ray until a lane picks it up; then (the `ray` ring is FIFO
-    // and a position's shadow ray is queued before its path ray) the hit record {triangle, u, v} of the path ray
-    extern __shared__ int s_lds[];
-    int *stack = s_lds + threadIdx.x;
-    const unsigned over_col = (blockIdx.x * kBlock + threadIdx.x) % (unsigned)kOverStride;  // this lane's overflow column
-    const unsigned lane = lane_id();
-    const int wave_in_block = (int)(threadIdx.x >> 6);
-    int *wl = s_lds + stack_cap * kBlock + wave_in_block * kWaveDwords;  // this wave's area
-    int *cold = wl;                                       // field f of position q at cold[f * S + q]
-    int *slot_of = wl + kCold * S;                        // local slot index held by position q, -1 = none
-    unsigned short *adv_q = (unsigned short *)(wl + (kCold + 1) * S);          // S entries
-    unsigned short *ray_q = (unsigned short *)(wl + (kCold + 1) * S + S / 2);  // 2S entries: position | kind << 15
-    float *s_tab = (float *)(s_lds + stack_cap * kBlock + 4 * kWaveDwords);
-    const float *tab = sc.tables;
-    if (LDS_TABLES) {
-        for (int k = threadIdx.x; k < sc.tab_dwords; k += kBlock) s_tab[k] = sc.tables[k];
-        tab = s_tab;
-    }
-    struct Uniforms {
-        Camera cam;
-        AdvanceParams ap;
-    };
-    static_assert(sizeof(Uniforms) % 4 == 0, "dword copy");
-    Uniforms *s_uni = (Uniforms *)(s_tab + (LDS_TABLES ? ((sc.tab_dwords + 3) & ~3) : 0));
-    {
-        Uniforms u;
-        u.cam = cam_arg;
-        u.ap = ap_arg;
-        const int *srcw = (const int *)&u;
-        for (int k = threadIdx.x; k < (int)(sizeof(Uniforms) / 4); k += kBlock) ((int *)s_uni)[k] = srcw[k];
-    }
-    __syncthreads();  // (the only barrier: tables and uniforms; from here on the waves of a block never meet again)
-    const Camera &cam = s_uni->cam;
-    const AdvanceParams &ap = s_uni->ap;
-    const int ap_n = ap_arg.n, ap_fb_fixed = ap_arg.fb_fixed;
-    // ---- this wave's slots: the same blocks of 64 consecutive slots, spread over the pixel-column lattices in the
-    // same way, as in k_paths; list index j -> local slot
-    const int lanes_in_grid = (int)(gridDim.x * blockDim.x);
-    const unsigned wave_in_grid = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int n_list = (ap_n / lanes_in_grid) * 64;  // slots of this wave (the host makes lanes_in_grid divide n)
-    auto list_slot = [&](int j) {
-        const unsigned set = (unsigned)j >> 6;
-        const unsigned b = (wave_in_grid + (wave_in_grid & 3u) * (unsigned)rot_wave + set * (unsigned)rot_set) &
-                           (((unsigned)lanes_in_grid >> 6) - 1u);
-        return (int)(set * (unsigned)lanes_in_grid + b * 64u + ((unsigned)j & 63u));
-    };
-    float4 *rb = ray_buf + (size_t)wave_in_grid * S * 4;  // 4 x float4 per position
-    // one float4 per LANE behind the records: {radiance, pixel} of the shadow ray the lane is tracing (kept out of
-    // the registers: only an unoccluded shadow ray reads it back, when it deposits)
-    const unsigned keep_at = (unsigned)(lanes_in_grid >> 6) * (unsigned)(S * 4) + (blockIdx.x * kBlock + threadIdx.x);
-    // rings (wave-uniform)
-    int adv_head = 0, adv_count = 0, ray_head = 0, ray_count = 0, next_j = 0;
-    auto adv_push = [&](bool want, int q) {  // appends the positions of the lanes with `want`
-        const unsigned long long m = wave_ballot(want);
-        if (want) {
-            int at = adv_head + adv_count + (int)prefix_popc(m);
-            at = at >= S ? at - S : at;
-            adv_q[at] = (unsigned short)q;
-        }
-        adv_count += (int)__popcll(m);
-    };
-    auto ray_push = [&](bool want, int q, int kind) {
-        const unsigned long long m = wave_ballot(want);
-        if (want) {
-            int at = ray_head + ray_count + (int)prefix_popc(m);
-            at = at >= 2 * S ? at - 2 * S : at;
-            ray_q[at] = (unsigned short)(q | (kind << 15));
-        }
-        ray_count += (int)__popcll(m);
-    };
-    // ---- initial fill: positions 0 .. S-1 take the first slots of the list; every one of them needs gen() first
-    for (int q0 = 0; q0 < S; q0 += 64) {  // (every lane runs every iteration: the ring bookkeeping is wave-uniform)
-        const int q = q0 + (int)lane;
-        const bool have = q < S && q < n_list;
-        if (q < S) slot_of[q] = have ? list_slot(q) : -1;
-        if (have) {
-            const int k = list_slot(q);
-            cold[F_BOUNCES * S + q] = p.bounces(k);
-            cold[F_PIXEL * S + q] = p.pixel(k);
-            cold[F_GEN * S + q] = p.gen(k);
-            cold[F_RD * S + q] = (int)p.rd(k);
-            cold[F_R0 * S + q] = (int)p.r0(k);
-            cold[F_R1 * S + q] = (int)p.r1(k);
-            cold[F_R2 * S + q] = (int)p.r2(k);
-            cold[F_R3 * S + q] = (int)p.r3(k);
-            cold[F_R4 * S + q] = (int)p.r4(k);
-            cold[F_BX * S + q] = __float_as_int(p.br(k));
-            cold[F_BY * S + q] = __float_as_int(p.bg(k));
-            cold[F_BZ * S + q] = __float_as_int(p.bb(k));
-            cold[F_L0 * S + q] = -1;  // "hit record": a miss
-        }
-        const int b0 = have ? cold[F_BOUNCES * S + q] : kDone;
-        adv_push(have && b0 != kDone && b0 != kParked, q);
-    }
-    next_j = min(S, n_list);
-    // ---- per-lane ray state.  pos < 0: the lane has no ray.  `tri`: best hit so far / excluded triangle; `hu` doubles as
-    // the occluded flag of a shadow ray (as in k_trace)
-    // `pos`: position | kind << 15 (kind 1 = shadow ray)
-    constexpr int kAnyBit = 1 << 15;
-    int pos = -1, cur = kEntryDone, sp = 0, tri = -1;
-    V3 o = mk(0, 0, 0), d = mk(0, 0, 0), inv = mk(0, 0, 0);
-    float tmax = 0.f, hu = 0.f, hv = 0.f;
-    unsigned long long n_gen = 0, n_shade = 0, n_traced = 0, n_shadow = 0, n_emit = 0, n_deposit = 0, n_rr = 0;
-    unsigned prio_tick = 0;
-    const unsigned prio_rank = (4u * blockIdx.x) / gridDim.x;
-#ifdef RT_TRACE_PROFILE
-    // [0] ADV blocks [1] ADV lanes [2] node blocks [3] node lanes [4] tri blocks [5] tri lanes [6] TURN blocks [7] lanes finalised
-    // [8] lanes refilled [9] ADV cycles [10] node cycles [11] tri cycles [12] TURN cycles [13] total cycles [14] waves
-    // [15] idle lanes (no ray) summed over node + tri blocks [16] finished lanes waiting, summed over node + tri blocks
-    unsigned long long pf[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    const unsigned long long pf_t0 = __builtin_readcyclecounter();
-#endif
-    while (true) {
-        if (prio_period && (prio_tick++ & ((1u << prio_period) - 1u)) == 0u) {
-            unsigned lvl = ((prio_tick >> prio_period) + prio_rank) & 3u;
-            lvl = max(lvl, prio_rank >> 1);
-            switch (lvl) {
-                case 0: __builtin_amdgcn_s_setprio(0); break;
-                case 1: __builtin_amdgcn_s_setprio(1); break;
-                case 2: __builtin_amdgcn_s_setprio(2); break;
-                default: __builtin_amdgcn_s_setprio(3); break;
-            }
-        }
-        const bool busy = pos >= 0 && cur != kEntryDone;
-        const bool want_node = busy && cur >= 0;
-        const bool want_tri = busy && cur < 0;
-        const int n_node = wave_count(want_node), n_tri = wave_count(want_tri);
-        const int n_busy = n_node + n_tri;
-        const int n_fin = wave_count(pos >= 0 && cur == kEntryDone);
-        if (n_busy == 0 && n_fin == 0 && adv_count == 0 && ray_count == 0) break;
-        // ---------------- ADV block: a full batch is waiting, or nothing else can make progress
-        if (adv_count >= adv_batch || (adv_count > 0 && n_busy == 0 && n_fin == 0 && ray_count == 0)) {
-            const int m = min(adv_count, 64);
-#ifdef RT_TRACE_PROFILE
-            pf[0]++; pf[1] += m;
-            const unsigned long long pf_ta = __builtin_readcyclecounter();
-#endif
-            const bool mine = (int)lane < m;
-            int at = adv_head + (int)lane;
-            at = at >= S ? at - S : at;
-            const int q = mine ? (int)adv_q[at] : 0;
-            adv_head += m;
-            adv_head = adv_head >= S ? adv_head - S : adv_head;
-            adv_count -= m;
-            AdvanceOut out;
-            out.did_gen = out.did_shade = out.has_shadow = out.did_emit = out.new_ray = false;
-            out.rr_draws = 0;
-            bool retired = false;
-            int my_slot = 0;
-            if (mine) {
-                SlotState st;
-                my_slot = slot_of[q];
-                st.bounces = cold[F_BOUNCES * S + q];
-                st.pixel = cold[F_PIXEL * S + q];
-                st.gen = cold[F_GEN * S + q];
-                st.rs = Rng{(uint32_t)cold[F_RD * S + q], (uint32_t)cold[F_R0 * S + q], (uint32_t)cold[F_R1 * S + q],
-                            (uint32_t)cold[F_R2 * S + q], (uint32_t)cold[F_R3 * S + q], (uint32_t)cold[F_R4 * S + q]};
-                st.beta = mk(__int_as_float(cold[F_BX * S + q]), __int_as_float(cold[F_BY * S + q]), __int_as_float(cold[F_BZ * S + q]));
-                const int h_tri = cold[F_L0 * S + q];
-                const float h_u = __int_as_float(cold[F_L1 * S + q]), h_v = __int_as_float(cold[F_L2 * S + q]);
-                const float4 r0 = rb[q * 4 + 0];  // {d, o.x}: the direction of the path ray that came back = wo
-                st.wo = mk(r0.x, r0.y, r0.z);
-                st.hit_info = -1;
-                st.isect_p = st.isect_n = mk(0, 0, 0);
-                if (h_tri >= 0) {  // hit record in the form mat() consumes (render.cuh:152-153, 311-316)
-                    Tri tr = load_tri(sc.tris, h_tri);
-                    float4 sh = sc.tri_shade[(unsigned)h_tri];
-                    st.isect_p = tri_point(tr, h_u, h_v);
-                    st.isect_n = mk(sh.x, sh.y, sh.z);
-                    st.hit_info = __float_as_int(sh.w);
-                }
-                advance_core<false>(sc, tab, cam, ap, ap.slot_lo + my_slot, st, out, fb);
-                cold[F_BOUNCES * S + q] = st.bounces;
-                cold[F_PIXEL * S + q] = st.pixel;
-                cold[F_GEN * S + q] = st.gen;
-                cold[F_RD * S + q] = (int)st.rs.d;
-                cold[F_R0 * S + q] = (int)st.rs.v0;
-                cold[F_R1 * S + q] = (int)st.rs.v1;
-                cold[F_R2 * S + q] = (int)st.rs.v2;
-                cold[F_R3 * S + q] = (int)st.rs.v3;
-                cold[F_R4 * S + q] = (int)st.rs.v4;
-                cold[F_BX * S + q] = __float_as_int(st.beta.x);
-                cold[F_BY * S + q] = __float_as_int(st.beta.y);
-                cold[F_BZ * S + q] = __float_as_int(st.beta.z);
-                if (out.has_shadow) {
-                    rb[q * 4 + 2] = make_float4(out.s_o.x, out.s_o.y, out.s_o.z, out.s_d.x);
-                    rb[q * 4 + 3] = make_float4(out.s_d.y, out.s_d.z, out.s_tmax, __int_as_float(out.s_target));
-                    cold[F_L0 * S + q] = __float_as_int(out.s_L.x);
-                    cold[F_L1 * S + q] = __float_as_int(out.s_L.y);
-                    cold[F_L2 * S + q] = __float_as_int(out.s_L.z);
-                }
-                if (out.new_ray) {
-                    rb[q * 4 + 0] = make_float4(out.ray_d.x, out.ray_d.y, out.ray_d.z, out.ray_o.x);
-                    rb[q * 4 + 1] = make_float4(out.ray_o.y, out.ray_o.z, 0.f, 0.f);
-                } else {
-                    // the slot is out of camera rays, or parked for the lockstep final generation: back to the pools
-                    retired = true;
-                    const int k = my_slot;
-                    p.bounces(k) = st.bounces;
-                    p.pixel(k) = st.pixel;
-                    p.gen(k) = st.gen;
-                    p.hit_info(k) = -1;
-                    p.stmax(k) = -1.f;
-                    p.br(k) = st.beta.x;
-                    p.bg(k) = st.beta.y;
-                    p.bb(k) = st.beta.z;
-                    p.rd(k) = st.rs.d;
-                    p.r0(k) = st.rs.v0;
-                    p.r1(k) = st.rs.v1;
-                    p.r2(k) = st.rs.v2;
-                    p.r3(k) = st.rs.v3;
-                    p.r4(k) = st.rs.v4;
-                }
-            }
-            // a position's shadow ray enters the ring BEFORE its path ray (see F_L0)
-            ray_push(out.has_shadow, q, 1);
-            ray_push(out.new_ray, q, 0);
-            // retired positions take the wave's next slots
-            {
-                const unsigned long long rm = wave_ballot(retired);
-                if (rm != 0) {
-                    const int j = next_j + (int)prefix_popc(rm);
-                    const bool refill = retired && j < n_list;
-                    if (retired) slot_of[q] = refill ? list_slot(j) : -1;
-                    if (refill) {
-                        const int k = list_slot(j);
-                        cold[F_BOUNCES * S + q] = p.bounces(k);
-                        cold[F_PIXEL * S + q] = p.pixel(k);
-                        cold[F_GEN * S + q] = p.gen(k);
-                        cold[F_RD * S + q] = (int)p.rd(k);
-                        cold[F_R0 * S + q] = (int)p.r0(k);
-                        cold[F_R1 * S + q] = (int)p.r1(k);
-                        cold[F_R2 * S + q] = (int)p.r2(k);
-                        cold[F_R3 * S + q] = (int)p.r3(k);
-                        cold[F_R4 * S + q] = (int)p.r4(k);
-                        cold[F_BX * S + q] = __float_as_int(p.br(k));
-                        cold[F_BY * S + q] = __float_as_int(p.bg(k));
-                        cold[F_BZ * S + q] = __float_as_int(p.bb(k));
-                        cold[F_L0 * S + q] = -1;
-                    }
-                    const int b0 = refill ? cold[F_BOUNCES * S + q] : kDone;
-                    adv_push(refill && b0 != kDone && b0 != kParked, q);
-                    next_j = min(n_list, next_j + (int)__popcll(rm));
-                }
-            }
-            n_gen += wave_count(out.did_gen);
-            n_shade += wave_count(out.did_shade);
-            n_traced += wave_count(out.new_ray);
-            n_shadow += wave_count(out.has_shadow);
-            n_emit += wave_count(out.did_emit);
-            int rr = out.rr_draws;
-            if (wave_ballot(rr != 0)) {
-                for (int off = 32; off > 0; off >>= 1) rr += __shfl_xor(rr, off);
-                n_rr += (unsigned long long)rr;
-            }
-#ifdef RT_TRACE_PROFILE
-            pf[9] += __builtin_readcyclecounter() - pf_ta;
-#endif
-            continue;
-        }
-        // ---------------- TURN block: hand finished rays back, take new ones.  Runs when enough lanes have nothing to
-        // trace (and there is something to take or to hand back), or when no lane traces at all.
-        if ((n_busy <= turn_at && (n_fin > 0 || ray_count > 0)) || (n_busy == 0 && (n_fin > 0 || ray_count > 0))) {
-            const bool fin = pos >= 0 && cur == kEntryDone;
-            const bool is_any = (pos & kAnyBit) != 0;
-#ifdef RT_TRACE_PROFILE
-            pf[6]++; pf[7] += n_fin;
-            const unsigned long long pf_tt = __builtin_readcyclecounter();
-#endif
-            if (fin) {
-                if (is_any) {
-                    if (hu == 0.f && !debug_no_deposit) {  // unoccluded: render.cuh:291-293
-                        const float4 kp = ray_buf[keep_at];
-                        deposit(fb, ap_fb_fixed, __float_as_int(kp.w), kp.x, kp.y, kp.z);
-                    }
-                } else {  // hit record of the path ray -> the position (render.cuh:311-316)
-                    cold[F_L0 * S + pos] = tri;
-                    cold[F_L1 * S + pos] = __float_as_int(hu);
-                    cold[F_L2 * S + pos] = __float_as_int(hv);
-                }
-            }
-            n_deposit += wave_count(fin && is_any && hu == 0.f);
-            adv_push(fin && !is_any, pos);
-            if (fin) pos = -1;
-            const unsigned long long idle = wave_ballot(pos < 0);
-            const int take = min((int)__popcll(idle), ray_count);
-            const int r = (int)prefix_popc(idle);
-            if (pos < 0 && r < take) {
-                int at = ray_head + r;
-                at = at >= 2 * S ? at - 2 * S : at;
-                const unsigned e = ray_q[at];
-                pos = (int)e;
-                const int q = (int)(e & 0x7fffu);
-                if (e & (unsigned)kAnyBit) {
-                    const float4 a = rb[q * 4 + 2], b = rb[q * 4 + 3];
-                    o = mk(a.x, a.y, a.z);
-                    d = mk(a.w, b.x, b.y);
-                    tmax = b.z;
-                    tri = __float_as_int(b.w);
-                    ray_buf[keep_at] = make_float4(__int_as_float(cold[F_L0 * S + q]), __int_as_float(cold[F_L1 * S + q]),
-                                        __int_as_float(cold[F_L2 * S + q]), __int_as_float(cold[F_PIXEL * S + q]));
-                } else {
-                    const float4 a = rb[q * 4 + 0], b = rb[q * 4 + 1];
-                    d = mk(a.x, a.y, a.z);
-                    o = mk(a.w, b.x, b.y);
-                    tmax = kFltMax;
-                    tri = -1;
-                }
-                inv = inv_dir(d);
-                cur = 0;
-                sp = 0;
-                hu = 0.f;
-            }
-            ray_head += take;
-            ray_head = ray_head >= 2 * S ? ray_head - 2 * S : ray_head;
-            ray_count -= take;
-#ifdef RT_TRACE_PROFILE
-            pf[8] += take;
-            pf[12] += __builtin_readcyclecounter() - pf_tt;
-#endif
-            continue;
-        }
-#ifdef RT_TRACE_PROFILE
-        pf[15] += 64 - n_busy - n_fin; pf[16] += n_fin;
-        const unsigned long long pf_tn = __builtin_readcyclecounter();
-#endif
-        // ---------------- node steps
-        if (n_node > 0 && n_node >= n_tri) {
-#ifdef RT_TRACE_PROFILE
-            pf[2]++; pf[3] += n_node;
-#endif
-            if (want_node) {
-#pragma unroll
-                for (int rep = 0; rep < kNodePerStep; rep++)
-                    if (cur >= 0) inner_step<false>(sc, o, inv, tmax, cur, sp, stack, overflow, stack_cap, nullptr, 0, over_col);
-            }
-#ifdef RT_TRACE_PROFILE
-            pf[10] += __builtin_readcyclecounter() - pf_tn;
-#endif
-        } else if (n_tri > 0) {
-            // ---------------- triangle tests (triangle.cuh:39-58): the leaf reference is the cursor
-#ifdef RT_TRACE_PROFILE
-            pf[4]++; pf[5] += n_tri;
-#endif
-            if (want_tri) {
-                const bool is_any = (pos & kAnyBit) != 0;
-                bool stop = false;
-                int reps = 0;
-                do {
-                    int ref = ~cur;
-                    int k = ref >> 3, count = ref & 7;
-                    Tri tr = load_tri(sc.tris, k);
-                    float t, u, v;
-                    if (tri_intersect(tr, o, d, tmax, t, u, v)) {
-                        if (is_any) {
-                            if (k != tri) {  // bvh.cuh:243: first accepted hit that is not the excluded triangle
-                                hu = 1.f;
-                                stop = true;
-                            }
-                        } else if (closest_hit_wins(sc, t, tmax, k, tri)) {  // bvh.cuh:227-231 (t <= tmax)
-                            tmax = t;
-                            hu = u;
-                            hv = v;
-                            tri = k;
-                        }
-                    }
-                    if (stop) cur = kEntryDone;
-                    else if (count > 1) cur = leaf_ref(k + 1, count - 1);
-                    else if (sp > 0) cur = stack_pop(stack, overflow, sp, stack_cap, over_col);
-                    else cur = kEntryDone;
-                    reps++;
-                } while (reps < kTriPerStep && cur != kEntryDone && cur < 0 && !stop);
-            }
-#ifdef RT_TRACE_PROFILE
-            pf[11] += __builtin_readcyclecounter() - pf_tn;
-#endif
-        }
-    }
-#ifdef RT_TRACE_PROFILE
-    if (prof && lane == 0) {
-        pf[13] = __builtin_readcyclecounter() - pf_t0;
-        pf[14] = 1;
-        for (int k = 0; k < 20; k++) atomicAdd(&prof[k], pf[k]);
-    }
-#endif
-    unsigned long long v[C_COUNT] = {n_gen, n_shade, n_traced, n_shadow, n_emit, n_deposit, n_rr, 0ull};
-    row_add(rows, v);
-}
-
 // post_process_framebuffer (render.cuh:330-338): c = sqrt(c * (1/spp))
 __global__ void k_post_process(float *fb, int n_values, float inv_spp) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2465,8 +2029,6 @@ struct Context {
     std::vector<hipEvent_t> timing_events;
     int *d_over = nullptr;  // overflow part of the traversal stacks of this context's grids (ensure_overflow)
     int over_levels = 0;
-    float4 *d_ray_buf = nullptr;  // k_flow: 64-byte ray record per slot position of every wave
-    size_t ray_buf_records = 0;
     std::mutex busy;  // a context (pools, counters, events) serves one render at a time
 };
 std::mutex g_ctx_mutex;
@@ -2755,62 +2317,6 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
         }
         if (const char *e = getenv("RT_PRIO_ROTATE")) prio_rotate = atoi(e);
         HIP_TRY(hipEventRecord(c.ev_a, st));
-        // RT_FLOW=<S>: the wave-local wavefront kernel k_flow with S slot positions per wave (96: 4 workgroups per CU;
-        // 128: 3).  Full shards, 2-wide records only; everything else stays on k_paths.
-        int flow_s = 0;
-        if (const char *e = getenv("RT_FLOW")) flow_s = atoi(e);
-        if (flow_s != 96 && flow_s != 128) flow_s = 0;
-        if (few_blocks || scene->wide || !lds_tables) flow_s = 0;
-        if (flow_s) {
-            int flow_blocks = paths_blocks;  // lanes of the grid must divide n; every workgroup resident
-            const int per_cu = flow_s == 96 ? 4 : 3;
-            while (flow_blocks > per_cu * dev_cus_paths && flow_blocks % 2 == 0) flow_blocks /= 2;
-            if (const char *e = getenv("RT_FLOW_BLOCKS")) flow_blocks = std::max(1, atoi(e));
-            if (n % (flow_blocks * kBlock) != 0) return fail("rt_render_shard: RT_FLOW grid does not divide the shard");
-            // 4 float4 per position + 1 float4 per lane (see k_flow: `keep`), counted in 64-byte records
-            const size_t records = (size_t)flow_blocks * (kBlock / 64) * (size_t)flow_s + (size_t)flow_blocks * kBlock / 4 + 1;
-            if (c.ray_buf_records < records) {
-                if (c.d_ray_buf) (void)hipFree(c.d_ray_buf);
-                c.d_ray_buf = nullptr;
-                c.ray_buf_records = 0;
-                HIP_TRY(hipMalloc((void **)&c.d_ray_buf, records * 64));
-                c.ray_buf_records = records;
-            }
-            const int wave_dwords = 17 * flow_s + flow_s / 2 + flow_s;
-            const size_t lds_flow = sizeof(int) * ((size_t)kBlock * paths_cap + 4 * (size_t)wave_dwords) +
-                                    sizeof(float) * (size_t)((scene->tab_dwords + 3) & ~3) + sizeof(Camera) + sizeof(AdvanceParams);
-            int flow_adv = flow_s == 96 ? 48 : 64, flow_turn = 44;
-            if (const char *e = getenv("RT_FLOW_ADV")) flow_adv = std::max(1, std::min(64, atoi(e)));
-            if (const char *e = getenv("RT_FLOW_TURN")) flow_turn = std::max(0, std::min(63, atoi(e)));
-            // the slot blocks of a wave follow the same lattice rotation as in k_paths, over THIS grid's waves
-            int fr_wave = rot_wave, fr_set = rot_set;
-            {
-                const int waves = flow_blocks * (kBlock / 64);
-                if (fr_wave >= waves || fr_set >= waves) { fr_wave = (waves / 32) & ~3; fr_set = waves / 32 + waves / 128; }
-            }
-            if (flow_s == 96)
-                hipLaunchKernelGGL((k_flow<true, 96, 4>), dim3(flow_blocks), block, lds_flow, st, sc, c.pools, cam, ap, d_sum, c.d_rows,
-                                   paths_cap, d_over2, c.d_ray_buf, flow_adv, flow_turn, dbg, prio_rotate, fr_wave, fr_set, paths_prof);
-            else
-                hipLaunchKernelGGL((k_flow<true, 128, 3>), dim3(flow_blocks), block, lds_flow, st, sc, c.pools, cam, ap, d_sum, c.d_rows,
-                                   paths_cap, d_over2, c.d_ray_buf, flow_adv, flow_turn, dbg, prio_rotate, fr_wave, fr_set, paths_prof);
-#ifdef RT_TRACE_PROFILE
-            {
-                HIP_TRY(hipStreamSynchronize(st));
-                unsigned long long h[24];
-                HIP_TRY(hipMemcpy(h, paths_prof, 192, hipMemcpyDeviceToHost));
-                const double tot = (double)h[13];
-                fprintf(stderr, "k_flow waves %llu | ADV blocks %llu avg lanes %.1f (%.1f%% of wave time, %.0f cyc/block) | node blocks %llu avg lanes %.1f (%.1f%%, %.0f) | "
-                                "tri blocks %llu avg lanes %.1f (%.1f%%, %.0f) | TURN blocks %llu fin %.1f refilled %.1f per block (%.1f%%, %.0f) | rest %.1f%% | in node+tri blocks: idle lanes %.1f, finished-waiting lanes %.1f\n",
-                        h[14], h[0], h[0] ? (double)h[1] / h[0] : 0.0, 100.0 * h[9] / tot, h[0] ? (double)h[9] / h[0] : 0.0, h[2], h[2] ? (double)h[3] / h[2] : 0.0,
-                        100.0 * h[10] / tot, h[2] ? (double)h[10] / h[2] : 0.0, h[4], h[4] ? (double)h[5] / h[4] : 0.0, 100.0 * h[11] / tot,
-                        h[4] ? (double)h[11] / h[4] : 0.0, h[6], h[6] ? (double)h[7] / h[6] : 0.0, h[6] ? (double)h[8] / h[6] : 0.0, 100.0 * h[12] / tot,
-                        h[6] ? (double)h[12] / h[6] : 0.0, 100.0 * (tot - h[9] - h[10] - h[11] - h[12]) / tot,
-                        (h[2] + h[4]) ? (double)h[15] / (h[2] + h[4]) : 0.0, (h[2] + h[4]) ? (double)h[16] / (h[2] + h[4]) : 0.0);
-                HIP_TRY(hipMemset(paths_prof, 0, 192));
-            }
-#endif
-        } else {
 // MIN_WAVES: 4 waves per SIMD (128 VGPRs, some spills) when the grid fills the chip, 2 (256 VGPRs, no
         // spills) when the shard is so small that only 2 workgroups per CU exist anyway (8-GPU runs)
 #define RT_LAUNCH_PATHS(T, WD, MJ)                                                                                     \
@@ -2834,7 +2340,6 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
             else RT_LAUNCH_PATHS(false, false, false);
         }
 #undef RT_LAUNCH_PATHS
-        }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(c.ev_b, st));
         HIP_TRY(hipEventSynchronize(c.ev_b));

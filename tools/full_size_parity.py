@@ -24,7 +24,7 @@ out = {"frame": f"{variant} {w}x{h}x{spp}", "samples": w * h * spp}
 pairs = (("shade_events", "sum_mat"), ("any_rays", "sum_ah"), ("emission_adds", "emission_adds"),
          ("shadow_adds", "ah_adds"), ("rr_draws", "rr_draws"))
 imgs = {}
-for name, env in (("k_paths", {}), ("k_flow", {"RT_FLOW": "96"})):
+for name, env in (("k_paths", {}),):
     for k, v in env.items():
         os.environ[k] = v
     img, st = gpu.render(api.make_camera(aspect=w / h), w, h, spp)
@@ -41,7 +41,7 @@ cores = min(os.cpu_count() or 8, 16)
 oimg, _, ost = osc.render(orc.camera((0.5, 0.5, 1.5), (0.5, 0.5, 0.0), (0.0, 1.0, 0.0), 37.8, w / h), w, h, spp, threads=cores)
 out["oracle_watertight"] = {g: int(ost[o]) for g, o in pairs}
 out["oracle_seconds"] = time.time() - t
-for name in ("k_paths", "k_flow"):
+for name in ("k_paths",):
     a = imgs[name]
     m = ~(np.isnan(a) | np.isnan(oimg))
     out[name]["events_equal"] = all(out[name][g] == out["oracle_watertight"][g] for g, _ in pairs)
