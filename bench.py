@@ -115,49 +115,42 @@ def main():
     flags = (0 if args.no_kernel_timing else api.FLAG_TIME_KERNELS) | args.debug_flags
     last_stats = {}
 
-    def step():
+    def render_local():
         if args.deterministic:
-            fb_fixed.zero_()
-            st = scene.render_shard_fixed(cam, w, h, spp, rank, world, fb_fixed.data_ptr(), max_bounces=args.max_bounces,
-                                          seed=1, flags=flags, stream=stream)
-            rtdist.reduce_raw_sums(fb_fixed, dst=0)
-            if rank == 0:
-                api.post_process_fixed(fb_fixed.data_ptr(), fb.data_ptr(), w * h, spp, stream=stream)
+            return scene.render_shard_fixed(cam, w, h, spp, rank, world, fb_fixed.data_ptr(), max_bounces=args.max_bounces,
+                                            seed=1, flags=flags, stream=stream)
+        return scene.render_shard(cam, w, h, spp, rank, world, fb.data_ptr(), max_bounces=args.max_bounces, seed=1,
+                                  flags=flags, stream=stream)
+
+    def post():
+        if args.deterministic:
+            api.post_process_fixed(fb_fixed.data_ptr(), fb.data_ptr(), w * h, spp, stream=stream)
         else:
-            fb.zero_()
-            st = scene.render_shard(cam, w, h, spp, rank, world, fb.data_ptr(), max_bounces=args.max_bounces, seed=1,
-                                    flags=flags, stream=stream)
-            rtdist.reduce_raw_sums(fb, dst=0)
-            if rank == 0:
-                api.post_process(fb.data_ptr(), w * h, spp, stream=stream)
-        last_stats.update(st)
+            api.post_process(fb.data_ptr(), w * h, spp, stream=stream)
 
-    def fence():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
+    local_sum = fb_fixed if args.deterministic else fb
     agg = {"seconds_trace": 0.0, "closest_rays": 0, "launches_trace": 0,
            "seconds_advance": 0.0, "seconds_render": 0.0, "any_rays": 0, "shade_events": 0}
     rays_per_rank = w * h * spp // world  # (every rank owns W / world slots; with spp | W / world exactly this many)
-    for _ in range(args.steps):
+    timed = {"on": False}
+
+    def step():
+        # one frame: zero -> this rank's slot shard -> ONE sum-reduce (RCCL) -> post-process on rank 0 (rtcuda_amd/dist.py)
+        st = rtdist.frame_step(local_sum.zero_, render_local, local_sum, post, rank)
+        last_stats.update(st)
+        if timed["on"]:
+            if world == 1 and st["camera_rays"] != w * h * spp:
+                raise SystemExit(f"timed step traced {st['camera_rays']} camera rays, expected {w * h * spp}")
+            if world > 1 and abs(st["camera_rays"] - rays_per_rank) > (1 << 20) // world:
+                raise SystemExit(f"rank {rank}: timed step traced {st['camera_rays']} camera rays, expected ~{rays_per_rank}")
+            for k in agg:
+                agg[k] += st[k]
+
+    # warm-up outside, then K timed steps between barrier + synchronize, MAX over ranks (the driver's contract)
+    for _ in range(args.warmup):
         step()
-        if world == 1 and last_stats["camera_rays"] != w * h * spp:
-            raise SystemExit(f"timed step traced {last_stats['camera_rays']} camera rays, expected {w * h * spp}")
-        if world > 1 and abs(last_stats["camera_rays"] - rays_per_rank) > (1 << 20) // world:
-            raise SystemExit(f"rank {rank}: timed step traced {last_stats['camera_rays']} camera rays, expected ~{rays_per_rank}")
-        for k in agg:
-            agg[k] += last_stats[k]
-    fence()
-    elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    timed["on"] = True
+    elapsed = rtdist.timed_frames(step, args.steps, 0, device_sync=torch.cuda.synchronize)
 
     if rank == 0:
         samples = float(w) * h * spp * args.steps

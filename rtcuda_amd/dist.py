@@ -34,3 +34,48 @@ def reduce_raw_sums(local_sum, dst: int = 0, group=None):
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.reduce(local_sum, dst=dst, op=dist.ReduceOp.SUM, group=group)
     return local_sum
+
+
+def frame_step(zero, render_local, local_sum, post_process, rank: int, dst: int = 0, group=None):
+    """One frame of the N-rank path, as bench.py runs it: zero the rank's raw-sum buffer, render the rank's slot shard
+    into it, ONE sum-reduce to ``dst``, and ``post_process`` (sqrt(sum / spp), render.cuh:330-338) on ``dst`` only.
+    The callables hide where the buffer lives (HBM with the HIP library, host memory with the CPU oracle in the tests).
+    Returns whatever ``render_local`` returns (the shard's statistics)."""
+    zero()
+    stats = render_local()
+    reduce_raw_sums(local_sum, dst=dst, group=group)
+    if rank == dst:
+        post_process()
+    return stats
+
+
+def timed_frames(step, steps: int, warmup: int, device_sync=None, group=None) -> float:
+    """bench.py's timing contract: ``warmup`` untimed steps, then exactly ``steps`` steps bracketed by a barrier and a
+    device synchronisation on both sides; returns the MAX over ranks of the elapsed seconds (every rank gets it)."""
+    import time
+
+    import torch
+    import torch.distributed as dist
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+
+    def fence():
+        if multi:
+            dist.barrier(group=group)
+        if device_sync is not None:
+            device_sync()
+
+    for _ in range(warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if multi:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        if dist.get_backend(group) == "nccl":
+            t = t.cuda()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        elapsed = float(t.item())
+    return elapsed

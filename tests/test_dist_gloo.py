@@ -48,6 +48,72 @@ def _worker(rank, world, port, w, h, spp, out_path):
     dist.destroy_process_group()
 
 
+def _bench_worker(rank, world, port, w, h, spp, out_dir):
+    """The N > 1 branch of bench.py -- rtdist.frame_step inside rtdist.timed_frames -- with the CPU oracle as the
+    per-rank renderer and host tensors as the raw-sum buffers (gloo)."""
+    sys.path.insert(0, ROOT)
+    import time
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle.oracle import Oracle
+    from rtcuda_amd import dist as rtdist
+    from rtcuda_amd import scenes
+    orc = Oracle("pinned")
+    sc = orc.scene(scenes.cornell_bunny("matte", bunny=False))
+    cam = orc.camera((0.5, 0.5, 1.5), (0.5, 0.5, 0.0), (0.0, 1.0, 0.0), 37.8, w / h)
+    lo, hi = rtdist.shard_range(rank, world)
+    local = torch.zeros(h, w, 3, dtype=torch.float32)
+    calls = {"render": 0, "post": 0}
+    rays = []
+
+    def render_local():
+        calls["render"] += 1
+        if rank == 1:
+            time.sleep(0.05)  # the slower rank: the reported time must be ITS time
+        _, part, st = sc.render(cam, w, h, spp, slot_lo=lo, slot_hi=hi, threads=2)
+        local.add_(torch.from_numpy(part))
+        rays.append(st["sum_gen"])
+        return st
+
+    def post():
+        calls["post"] += 1
+        local.mul_(1.0 / spp).sqrt_()  # post_process_framebuffer (render.cuh:330-338)
+
+    def step():
+        rtdist.frame_step(local.zero_, render_local, local, post, rank)
+
+    t0 = time.perf_counter()
+    elapsed = rtdist.timed_frames(step, steps=2, warmup=1)
+    wall = time.perf_counter() - t0
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), image=local.numpy(), elapsed=elapsed, wall=wall,
+             renders=calls["render"], posts=calls["post"])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_multi_rank_step_and_timing_contract(tmp_path, oracle):
+    """bench.py with N > 1: every rank renders its slot shard, ONE sum-reduce, rank 0 alone post-processes; K timed
+    steps after W warm-up steps, the MAX over ranks of the elapsed time on every rank."""
+    import torch.multiprocessing as mp
+    from rtcuda_amd import scenes
+    w, h, spp = 32, 20, 8
+    mp.spawn(_bench_worker, args=(2, _free_port(), w, h, spp, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    assert int(r0["renders"]) == int(r1["renders"]) == 3          # 1 warm-up + 2 timed steps on both ranks
+    assert int(r0["posts"]) == 3 and int(r1["posts"]) == 0         # post-process on rank 0 only
+    assert float(r0["elapsed"]) == float(r1["elapsed"])            # all_reduce(MAX): the same number everywhere
+    assert float(r0["elapsed"]) >= 2 * 0.05                        # ... and it is the slower rank's
+    assert float(r0["elapsed"]) <= float(r0["wall"]) + 1e-3        # only the timed steps are inside
+    sc = oracle.scene(scenes.cornell_bunny("matte", bunny=False))
+    cam = oracle.camera((0.5, 0.5, 1.5), (0.5, 0.5, 0.0), (0.0, 1.0, 0.0), 37.8, w / h)
+    full, _, _ = sc.render(cam, w, h, spp, threads=4)
+    assert np.allclose(r0["image"], full, rtol=1e-5, atol=1e-6)    # rank 0 holds the whole post-processed frame
+    assert full.sum() > 0
+
+
 def test_two_rank_shards_reduce_to_the_full_frame(tmp_path, oracle):
     import torch.multiprocessing as mp
     from rtcuda_amd import scenes
