@@ -250,12 +250,21 @@ void *rt_hostwalk_create(const float *verts, int n) {
 void rt_hostwalk_destroy(void *h) { delete (HostWalk *)h; }
 // mode 0: closest hit -> out_i = original triangle index or -1, out_t = t;  mode 1: any hit excluding excluded[i]
 // (original index or -1) -> out_i = 0 / 1
+// work counters of the walks since the last reset: [0] rays [1] node steps [2] triangle tests [3] leaves visited
+static long long g_walk_stats[4] = {0, 0, 0, 0};
+void rt_hostwalk_stats(long long *out4, int reset) {
+    for (int k = 0; k < 4; k++) {
+        out4[k] = g_walk_stats[k];
+        if (reset) g_walk_stats[k] = 0;
+    }
+}
 int rt_hostwalk_trace(void *h, int mode, int n_rays, const float *o3, const float *d3, const float *tmax_in, const int *excluded,
                       int *out_i, float *out_t) {
     const HostWalk &w = *(const HostWalk *)h;
     const rtbvh::Result &r = w.r;
     int failures = 0;
-#pragma omp parallel for schedule(dynamic, 1024) reduction(+ : failures)
+    long long st_nodes = 0, st_tris = 0, st_leaves = 0;
+#pragma omp parallel for schedule(dynamic, 1024) reduction(+ : failures, st_nodes, st_tris, st_leaves)
     for (int i = 0; i < n_rays; i++) {
         std::vector<int> pstack(r.pair_depth + 8);
         V3 o{o3[3 * i], o3[3 * i + 1], o3[3 * i + 2]}, d{d3[3 * i], d3[3 * i + 1], d3[3 * i + 2]};
@@ -269,6 +278,7 @@ int rt_hostwalk_trace(void *h, int mode, int n_rays, const float *o3, const floa
         while (cur != rtbvh::kNoChild && !occluded) {
             if (++steps > 1000000) { failures++; break; }
             if (cur >= 0) {
+                st_nodes++;
                 const rtbvh::Pair &p = r.pairs[cur];
                 float el, er;
                 bool hl = box_hit(o, inv, p.lbox, p.lbox + 3, tmax, el) && p.llink != rtbvh::kNoChild;
@@ -283,7 +293,9 @@ int rt_hostwalk_trace(void *h, int mode, int n_rays, const float *o3, const floa
                 else cur = sp > 0 ? pstack[--sp] : rtbvh::kNoChild;
             } else {
                 int ref = ~cur, first = ref >> 3, count = ref & 7;
-                for (int k = first; k < first + count; k++)
+                st_leaves++;
+                for (int k = first; k < first + count; k++) {
+                    st_tris++;
                     if (tri_hit(w.tris[k], o, d, tmax, t)) {
                         if (mode == 1) {
                             if (k != excl) { occluded = true; break; }
@@ -292,6 +304,7 @@ int rt_hostwalk_trace(void *h, int mode, int n_rays, const float *o3, const floa
                             best = k;
                         }
                     }
+                }
                 cur = sp > 0 ? pstack[--sp] : rtbvh::kNoChild;
             }
         }
@@ -302,6 +315,10 @@ int rt_hostwalk_trace(void *h, int mode, int n_rays, const float *o3, const floa
             out_t[i] = best >= 0 ? tmax : 0.f;
         }
     }
+    g_walk_stats[0] += n_rays;
+    g_walk_stats[1] += st_nodes;
+    g_walk_stats[2] += st_tris;
+    g_walk_stats[3] += st_leaves;
     return failures;
 }
 }
