@@ -382,59 +382,6 @@ __device__ __forceinline__ void acc_flush(float *acc, float *__restrict__ fb, in
         acc[2 * kBlock] = 0.f;
     }
 }
-// The same flush for the lanes of a GEN block TOGETHER.  A wave's 64 slots are 64 consecutive camera rays: with
-// spp >= 64 the lanes that end a camera ray in the same block nearly always end it on the same pixel, so their sums are
-// first added up in three words of LDS (`wacc`, per wave: LDS atomics) and ONE lane issues the global atomic triple --
-// a tenth of the fabric transactions again.  Lanes on another pixel (another generation) deposit by themselves.
-// Fixed-point mode adds the lanes' already-converted 64-bit sums, so it stays exact and independent of the grouping.
-__device__ __forceinline__ void acc_flush_wave(float *acc, unsigned long long *wacc, float *__restrict__ fb, int fixed, int pixel) {
-    const float r = acc[0 * kBlock], g = acc[1 * kBlock], b = acc[2 * kBlock];
-    const bool have = r != 0.f || g != 0.f || b != 0.f;
-    if (have) {
-        acc[0 * kBlock] = 0.f;
-        acc[1 * kBlock] = 0.f;
-        acc[2 * kBlock] = 0.f;
-    }
-    const unsigned long long hm = wave_ballot(have);
-    if (hm == 0) return;
-    const int lead = (int)__builtin_ctzll(hm);
-    const int lead_pixel = __builtin_amdgcn_readlane(pixel, lead);
-    const bool grp = have && pixel == lead_pixel;
-    if (__popcll(wave_ballot(grp)) >= 2) {
-        if (grp) {
-            if (fixed) {
-                atomicAdd(&wacc[0], (unsigned long long)to_fixed(r));
-                atomicAdd(&wacc[1], (unsigned long long)to_fixed(g));
-                atomicAdd(&wacc[2], (unsigned long long)to_fixed(b));
-            } else {
-                float *wf = (float *)wacc;
-                atomicAdd(&wf[0], r);
-                atomicAdd(&wf[1], g);
-                atomicAdd(&wf[2], b);
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (LDS operations of one wave complete in order)
-        if (have && (int)lane_id() == lead) {
-            const unsigned k = (unsigned)(3 * pixel);
-            if (fixed) {
-                unsigned long long *f = (unsigned long long *)fb;
-                atomicAdd(&f[k + 0], wacc[0]);
-                atomicAdd(&f[k + 1], wacc[1]);
-                atomicAdd(&f[k + 2], wacc[2]);
-            } else {
-                const float *wf = (const float *)wacc;
-                atomicAdd(&fb[k + 0], wf[0]);
-                atomicAdd(&fb[k + 1], wf[1]);
-                atomicAdd(&fb[k + 2], wf[2]);
-            }
-            wacc[0] = wacc[1] = wacc[2] = 0ull;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        if (have && !grp) deposit(fb, fixed, pixel, r, g, b);
-    } else if (have) {
-        deposit(fb, fixed, pixel, r, g, b);
-    }
-}
 
 struct SlotState {
     int bounces, hit_info, pixel, gen;
@@ -1211,9 +1158,7 @@ k_paths(DScene sc, DPools p, Camera cam_arg, AdvanceParams ap_arg, float *__rest
     int *over = overflow + (blockIdx.x * kBlock + threadIdx.x) % kOverStride;
     int *cold = s_lds + (stack_cap + 9) * kBlock + threadIdx.x;  // element k at cold[k * kBlock]
     float *acc = (float *)(s_lds + (stack_cap + 22) * kBlock) + threadIdx.x;  // sample accumulator (acc_add / acc_flush)
-    // (per wave: three 64-bit words for acc_flush_wave, behind the accumulators)
-    unsigned long long *wacc = (unsigned long long *)(s_lds + (stack_cap + 25) * kBlock) + 4 * (threadIdx.x >> 6);
-    float *s_tab = (float *)(s_lds + (stack_cap + 25) * kBlock + 32);
+    float *s_tab = (float *)(s_lds + (stack_cap + 25) * kBlock);
     const float *tab = sc.tables;
     // small shards (MIN_WAVES == 2: at most 2 workgroups per CU, LDS to spare, latency-bound): the top of
     // the BVH is staged in LDS, so the first levels of every traversal do not leave the CU
@@ -1332,7 +1277,6 @@ k_paths(DScene sc, DPools p, Camera cam_arg, AdvanceParams ap_arg, float *__rest
     // an occluder is an occluder whenever it is found; the price is a few node visits a fresher tmax would have culled.
     int pend = kEntryDone;
     acc[0 * kBlock] = acc[1 * kBlock] = acc[2 * kBlock] = 0.f;
-    if (lane_id() < 3) wacc[lane_id()] = 0ull;
     if (i < ap_n) {
         load_slot(i);
         phase = (bounces != kDone && bounces != kParked) ? (SPLIT_GEN ? PH_GEN : PH_ADV) : PH_IDLE;  // (untouched slots: bounces = INT_MAX)
@@ -1407,7 +1351,7 @@ k_paths(DScene sc, DPools p, Camera cam_arg, AdvanceParams ap_arg, float *__rest
                 st.pixel = 0;
                 st.beta = mk(0, 0, 0);
                 int pxy = cold[12 * kBlock];
-                acc_flush_wave(acc, wacc, fb, ap_fb_fixed, cold[1 * kBlock]);  // the camera ray that ended: its sum -> its pixel
+                acc_flush(acc, fb, ap_fb_fixed, cold[1 * kBlock]);  // the camera ray that ended: its sum -> its pixel
                 gen_core(cam, ap, ap.slot_lo + i, st, out, &pxy);
                 if (out.new_ray) {
                     cold[12 * kBlock] = pxy;
@@ -2321,7 +2265,7 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
         if (const char *e = getenv("RT_ADV_BATCH")) adv_batch = std::max(1, std::min(64, atoi(e)));
         const int paths_cap = std::min(8, std::max(1, scene->stack_bound));
         int *const d_over2 = d_over;
-        size_t lds_paths = sizeof(int) * ((size_t)kBlock * (size_t)(paths_cap + 25) + 32) + (lds_tables ? sizeof(float) * (size_t)((scene->tab_dwords + 3) & ~3) : 0) +
+        size_t lds_paths = sizeof(int) * (size_t)kBlock * (size_t)(paths_cap + 25) + (lds_tables ? sizeof(float) * (size_t)((scene->tab_dwords + 3) & ~3) : 0) +
                            sizeof(Camera) + sizeof(AdvanceParams);
         bool majority = true;
         if (const char *e = getenv("RT_MAJORITY")) majority = atoi(e) != 0;

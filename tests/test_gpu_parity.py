@@ -209,6 +209,8 @@ def test_error_paths(api, bunny_matte):
         sc.render(api.make_camera(), 0, 10, 1)
     with pytest.raises(api.RtError):  # beyond the reference's int32 camera-ray range
         sc.render(api.make_camera(), 8192, 8192, 64)
+    with pytest.raises(api.RtError):  # more pixels than 32-bit framebuffer indexing reaches (3 * pixel < 2^31): ADVICE r1
+        sc.render(api.make_camera(), 32767, 32767, 1)
 
 
 GOLDEN = np.load(__import__("os").path.join(__import__("os").path.dirname(__file__), "golden", "render_goldens.npz"))
