@@ -160,7 +160,7 @@ int rt_xorwow_states(uint64_t seed, uint32_t first, uint32_t count, int draws, u
 int rt_measure_copy_bandwidth(int64_t bytes, int reps, double *out_bytes_per_s);
 
 /* Measured vector-ALU roof in lane-operations/s: `waves_per_simd` waves on every SIMD of the chip, each issuing
- * iters x 16 independent v_fma_f32 (best of 3 timed launches).  The render kernels are bound by VALU issue, not
+ * iters x 16 independent v_fma_f32 (best of 6 timed launches).  The render kernels are bound by VALU issue, not
  * by HBM, so this -- next to the 157.3 TFLOP/s = 78.6 T lane-FMA/s spec -- is what bench.py's roofline divides by.
  * out_wave_instr (may be NULL): v_fma_f32 wave-instructions of one launch, for calibrating PMC counters.
  * No reference counterpart (the reference measures nothing). */

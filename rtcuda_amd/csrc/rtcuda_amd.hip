@@ -3000,7 +3000,7 @@ int rt_calibrate_valu(int waves_per_simd, int iters, double *out_lane_ops_per_s,
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
     double best = 0.0;
-    for (int r = 0; r < 4; r++) {
+    for (int r = 0; r < 7; r++) {  // (first launch untimed; clocks ramp: the best of six)
         HIP_TRY(hipEventRecord(e0, nullptr));
         hipLaunchKernelGGL(k_valu_calibrate, dim3(blocks), dim3(256), 0, nullptr, d_out, iters, 1.f);
         HIP_TRY(hipEventRecord(e1, nullptr));

@@ -3,7 +3,11 @@
 
 Run plainly it prints the rates; run under `rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES
 SQ_WAVE_CYCLES GRBM_GUI_ACTIVE` its k_valu_calibrate dispatches show what those counters read at a KNOWN issue rate
--- which settles how `VALUBusy = 4 x SQ_ACTIVE_INST_VALU / (SIMDs x cycles)` of the render kernels is to be read."""
+-- which settles how `VALUBusy = 4 x SQ_ACTIVE_INST_VALU / (SIMDs x cycles)` of the render kernels is to be read.
+
+Short bursts on purpose (1.6 ms per launch, best of six): a pure FMA stream held for many milliseconds runs into the
+power limit and the clock drops (100 000 iterations: 44 - 52 instead of 55 T lane-op/s at 4 waves per SIMD); the render
+kernel itself runs at 2.4 GHz for its whole 160 ms (GRBM_GUI_ACTIVE / duration)."""
 import json
 import os
 import sys
