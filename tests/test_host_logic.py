@@ -229,3 +229,54 @@ def test_full_pool_k_paths_build_does_not_spill_vector_registers():
             assert int(m_spill.group(1)) == 0, block
             found = True
     assert found, "k_paths<true, false, true, 4> not in the resource remarks"
+
+
+def test_bench_refuses_debug_flags_without_allow_invalid():
+    """--debug-flags changes what the kernels do (0x100 drops the framebuffer deposits): bench.py must not produce a
+    number from such a run unless told to, and then marks the line (VERDICT r1 weak #8)."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--debug-flags", "256"], capture_output=True, text=True)
+    assert r.returncode != 0 and "allow-invalid" in (r.stderr + r.stdout)
+
+
+def test_bvh_optimisation_keeps_every_hit_and_saves_node_steps(oracle, bunny_matte):
+    """rt_bvh.h optimize_reinsert: the insertion-based pass after the SAH sweep changes the topology only.  Same closest
+    hits (triangle and t) on the CPU walk with and without it, fewer node steps per ray with it."""
+    import ctypes
+    import subprocess
+    import sys
+    code = r'''
+import ctypes, sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from rtcuda_amd import scenes
+import raygen
+from oracle.oracle import Oracle
+orc = Oracle("pinned")
+a = scenes.cornell_bunny("matte")
+cam = orc.camera((0.5, 0.5, 1.5), (0.5, 0.5, 0.0), (0.0, 1.0, 0.0), 37.8, 16 / 9)
+o, d = raygen.camera_rays(cam, 1920, 1080, 60000, seed=77)
+H = ctypes.CDLL(%r)
+H.rt_hostwalk_create.restype = ctypes.c_void_p
+H.rt_hostwalk_create.argtypes = [ctypes.c_void_p, ctypes.c_int]
+H.rt_hostwalk_trace.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 6
+H.rt_hostwalk_stats.argtypes = [ctypes.c_void_p, ctypes.c_int]
+tris = np.ascontiguousarray(a.tris, np.float32)
+h = H.rt_hostwalk_create(tris.ctypes.data, len(tris))
+n = len(o); tri = np.zeros(n, np.int32); t = np.zeros(n, np.float32); tm = np.full(n, 3.4028234663852886e38, np.float32)
+st = np.zeros(4, np.int64)
+H.rt_hostwalk_stats(st.ctypes.data, 1)
+assert H.rt_hostwalk_trace(h, 0, n, o.ctypes.data, d.ctypes.data, tm.ctypes.data, None, tri.ctypes.data, t.ctypes.data) == 0
+H.rt_hostwalk_stats(st.ctypes.data, 1)
+np.savez(sys.argv[1], tri=tri, t=t, nodes=st[1], rays=st[0])
+''' % (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "rtcuda_amd", "librt_hostcheck.so"))
+    import tempfile
+    out = {}
+    with tempfile.TemporaryDirectory() as td:
+        for passes in ("0", "2"):  # (the pass count is read once per process: one process per setting)
+            path = os.path.join(td, f"walk{passes}.npz")
+            subprocess.check_call([sys.executable, "-c", code, path], env=dict(os.environ, RT_BVH_OPT=passes))
+            out[passes] = dict(np.load(path))
+    assert np.array_equal(out["0"]["tri"], out["2"]["tri"]) and np.array_equal(out["0"]["t"], out["2"]["t"])
+    assert (out["0"]["tri"] >= 0).mean() > 0.4
+    assert out["2"]["nodes"] < 0.97 * out["0"]["nodes"]  # measured: -7 % on these primary rays, -10 % over whole paths
