@@ -19,9 +19,11 @@
 //
 // Kernels:
 //   k_paths      everything before the final generation, ONE persistent launch per frame.  A lane
-//                owns a slot (then its next one); init+mat+gen, the shadow ray and the path ray are
+//                owns a slot (then its next one); init+mat, gen, the shadow ray and the path ray are
 //                PHASES of the lane; the wave issues, per iteration, the one block most of its lanes
-//                wait for.  Rays, hit records and queues never leave registers / LDS.
+//                wait for.  Rays, hit records and queues never leave registers / LDS; a camera
+//                ray's contributions are summed in LDS and reach the framebuffer as one atomic triple;
+//                traversal is speculative (a leaf reached inside a node block is set aside).
 //   k_advance    init() + mat() + gen() for all slots of a round (render.cuh:84-275), state in the
 //   k_trace      SoA pools; ch() + ah() of a round (render.cuh:278-328) with persistent waves, ballot +
 //                mbcnt compaction into a per-wave LDS queue instead of flag arrays + CUB select
@@ -30,7 +32,11 @@
 //   advance_core / inner_step / tri_intersect / box_hit are the shared device functions: one copy of
 //   the estimator and of the traversal for both pipelines.
 //   * BVH: 64-byte node records -- 2-wide with exact padded boxes (default) or 4-wide with 8-bit
-//     quantised boxes -- and 48-byte {p0,e1,e2,n} triangle records in leaf order (rt_bvh.h).
+//     quantised boxes -- and 48-byte {p0,e1,e2,n} triangle records in leaf order (rt_bvh.h: SAH sweep
+//     + insertion-based optimisation).
+//   * Two results that depend, in the reference, on the shape of its own tree are defined by the triangle
+//     list alone here: an accepted hit is never culled (conservative box test), and hits at exactly equal
+//     t go to the larger caller index (closest_hit_wins).  Traversal ORDER therefore never matters.
 //   * There are no host read-backs inside a frame except one 16-byte poll per lockstep round (the
 //     reference does four blocking 4-byte read-backs per iteration: render.cuh:433-434,444-445).
 //

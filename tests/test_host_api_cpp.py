@@ -236,3 +236,27 @@ int main() {
 }
 ''')
     subprocess.check_call(["g++", "-std=c++14", "-fsyntax-only", "-Wall", "-I", os.path.join(ROOT, "include"), str(src)])
+
+
+def test_c_abi_header_is_plain_c(tmp_path):
+    """include/rtcuda_amd.h is the drop-in boundary: opaque handles, plain pointers and sizes -- it must compile as C
+    (a cgo / JNI / N-API binding sees it as C), and a C caller written against it must type-check."""
+    src = tmp_path / "caller.c"
+    src.write_text(r'''
+#include "rtcuda_amd.h"
+#include <stddef.h>
+int run(const float *verts, int n, const int32_t *tri_mat, const int32_t *tri_light, const rt_material *mats, int n_mats,
+        const rt_light *lights, int n_lights, float *rgb, int w, int h) {
+    rt_scene *sc = NULL;
+    rt_camera cam;
+    rt_stats st;
+    float from[3] = {0.5f, 0.5f, 1.5f}, at[3] = {0.5f, 0.5f, 0.f}, up[3] = {0.f, 1.f, 0.f};
+    if (rt_scene_create(verts, n, tri_mat, tri_light, mats, n_mats, lights, n_lights, &sc)) return 1;
+    if (rt_camera_make(from, at, up, 37.8f, (float)w / (float)h, &cam)) return 2;
+    if (rt_render(sc, &cam, w, h, 256, 10, 1u, RT_FLAG_DETERMINISTIC, rgb, &st)) return 3;
+    rt_scene_destroy(sc);
+    return st.camera_rays == (int64_t)w * h * 256 ? 0 : 4;
+}
+''')
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"),
+                           str(src)])
