@@ -41,7 +41,7 @@ inline bool box_hit(V3 o, V3 inv, const float *lo, const float *hi, float tmax, 
     float t_out = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
     entry = t_in;
     t_out = t_out * 1.000001f;  // (as box_hit in rtcuda_amd.hip; the kernels' 1 / d is v_rcp_f32, 1 ulp, here an exact division)
-    return t_in <= t_out && t_out >= 0.f && t_in <= tmax;
+    return t_in <= t_out && t_out >= 0.f && t_in <= tmax * 1.000001f;
 }
 inline void child_box(const rtbvh::Node4 &nd, int k, float *lo, float *hi) {
     for (int a = 0; a < 3; a++) {

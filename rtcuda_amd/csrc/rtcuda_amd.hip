@@ -730,7 +730,7 @@ __device__ __forceinline__ bool box_hit(V3 o, V3 inv, float lox, float loy, floa
     float t_out = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
     entry = t_in;
     t_out = t_out * 1.000001f;
-    return t_in <= t_out && t_out >= 0.f && t_in <= tmax;
+    return t_in <= t_out && t_out >= 0.f && t_in <= tmax * 1.000001f;  // (tmax widened like t_out: see inner_step)
 }
 
 typedef float v2f __attribute__((ext_vector_type(2)));  // packed fp32 (v_pk_*_f32 on gfx950)
@@ -809,8 +809,12 @@ __device__ __forceinline__ void inner_step(const DScene &sc, V3 o, V3 inv, float
         v2f t_out = {fminf(fminf(fmaxf(ax.x, bx.x), fmaxf(ay.x, by.x)), fmaxf(az.x, bz.x)),
                      fminf(fminf(fmaxf(ax.y, bx.y), fmaxf(ay.y, by.y)), fmaxf(az.y, bz.y))};
         t_out = t_out * v2f{1.000001f, 1.000001f};
-        bool hl = el <= t_out.x && t_out.x >= 0.f && el <= tmax && cl != kEntryDone;
-        bool hr = er <= t_out.y && t_out.y >= 0.f && er <= tmax && cr != kEntryDone;
+        // (tmax is widened like the exit distance: the entry distance carries the same few ulps of rounding, and a
+        // shadow ray that ends ON a triangle coplanar with an occluder -- light quads -- has entry = t = tmax to the
+        // last bit; unwidened, the full-size audit of the sixteen-light scene lost 1 occluder in 9.8e8 shadow rays)
+        const float tmax_w = tmax * 1.000001f;
+        bool hl = el <= t_out.x && t_out.x >= 0.f && el <= tmax_w && cl != kEntryDone;
+        bool hr = er <= t_out.y && t_out.y >= 0.f && er <= tmax_w && cr != kEntryDone;
         // What comes next, with as little divergent control flow as the three outcomes allow (every divergent branch
         // costs the wave an exec-mask save / restore pair and a jump, a dozen scalar instructions per step before):
         //   one child entered  -> it becomes the cursor;
