@@ -1297,7 +1297,7 @@ k_paths(DScene sc, DPools p, Camera cam_arg, AdvanceParams ap_arg, float *__rest
     unsigned long long n_gen = 0, n_shade = 0, n_traced = 0, n_shadow = 0, n_emit = 0, n_deposit = 0, n_rr = 0;
 #ifdef RT_TRACE_PROFILE
     unsigned long long pf[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned long long pf_gen_cycles = 0;
+    unsigned long long pf_gen_cycles = 0, pf_fin_cycles = 0, pf_fin_lanes = 0, pf_fin_iters = 0;
     const unsigned long long pf_t0 = __builtin_readcyclecounter();
 #endif
 
@@ -1583,6 +1583,11 @@ k_paths(DScene sc, DPools p, Camera cam_arg, AdvanceParams ap_arg, float *__rest
         }
         // ---------------- finished rays
         const bool fin = trav && cur == kEntryDone && (!kSpeculate || pend == kEntryDone);
+#ifdef RT_TRACE_PROFILE
+        const unsigned long long pf_tf = __builtin_readcyclecounter();
+        pf_fin_lanes += wave_count(fin);
+        pf_fin_iters += wave_ballot(fin) != 0 ? 1 : 0;
+#endif
         n_deposit += wave_count((fin && is_any && hu == 0.f));
         if (fin) {
             if (is_any) {
@@ -1604,8 +1609,12 @@ k_paths(DScene sc, DPools p, Camera cam_arg, AdvanceParams ap_arg, float *__rest
                 phase = (SPLIT_GEN && (tri < 0 || (b >= ap_max_bounces && b > 0))) ? PH_GEN : PH_ADV;
             }
         }
+#ifdef RT_TRACE_PROFILE
+        pf_fin_cycles += __builtin_readcyclecounter() - pf_tf;
+#endif
     }
 #ifdef RT_TRACE_PROFILE
+    if (prof && lane_id() == 0) { atomicAdd(&prof[17], pf_fin_cycles); atomicAdd(&prof[18], pf_fin_lanes); atomicAdd(&prof[19], pf_fin_iters); }
     if (prof && lane_id() == 0)
         { pf[11] = __builtin_readcyclecounter() - pf_t0; for (int k = 0; k < 16; k++) atomicAdd(&prof[k], pf[k]); atomicMax(&prof[13], pf[11]); atomicAdd(&prof[14], 1ull); atomicAdd(&prof[16], pf_gen_cycles);
           // per-wave record: where it ran and for how long
@@ -2365,6 +2374,8 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
                     h[12] ? (double)h[15] / h[12] : 0.0, 100.0 * h[16] / h[11], h[12] ? (double)h[16] / h[12] : 0.0);
             fprintf(stderr, "k_paths waves: %llu, mean lifetime %.0f cycles, longest %.0f cycles (x%.3f)\n", h[14], (double)h[11] / h[14], (double)h[13],
                     (double)h[13] * h[14] / h[11]);
+            fprintf(stderr, "k_paths fin section: %.1f %% of wave time, entered in %llu iterations (avg %.1f finished lanes), %.0f cycles each\n",
+                    100.0 * h[17] / h[11], h[19], h[19] ? (double)h[18] / h[19] : 0.0, h[19] ? (double)h[17] / h[19] : 0.0);
             fprintf(stderr, "k_paths profile: ADV blocks %llu avg lanes %.1f | node steps %llu avg lanes %.1f (ADV-waiting %.1f) | tri steps %llu avg lanes %.1f (ADV-waiting %.1f)\n",
                     h[0], h[0] ? (double)h[1] / h[0] : 0.0, h[2], h[2] ? (double)h[3] / h[2] : 0.0, h[2] ? (double)h[6] / h[2] : 0.0, h[4],
                     h[4] ? (double)h[5] / h[4] : 0.0, h[4] ? (double)h[7] / h[4] : 0.0);
