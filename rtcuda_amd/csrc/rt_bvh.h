@@ -104,6 +104,8 @@ struct BinNode {
 struct Result {
     std::vector<Node4> nodes;    // 4-wide quantised records
     std::vector<Pair> pairs;     // 2-wide full-precision records (same binary tree)
+    std::vector<Pair> quads;     // 4-wide full-precision nodes of the collapsed tree: node j = records 2j (children 0, 1)
+                                 // and 2j + 1 (children 2, 3); inner links are RECORD indices (2 x node), see build()
     int pair_depth = 0;          // depth of the pair tree (= binary depth - 1, root pair = 1)
     std::vector<int32_t> order;  // leaf order -> original triangle index
     int max_depth = 0;           // depth of the 4-wide tree (root = 1)
@@ -454,6 +456,7 @@ inline Result build(const float *verts, int n) {
         memset(&ep, 0, sizeof(ep));
         ep.llink = ep.rlink = kNoChild;
         res.pairs.push_back(ep);
+        res.quads.assign(2, ep);
         res.max_depth = 1;
         res.pair_depth = 1;
         res.stack_bound = 1;
@@ -462,6 +465,10 @@ inline Result build(const float *verts, int n) {
     struct Task {
         int bin_node, out_node, depth;
     };
+    struct WideBoxes {
+        Box b[4];
+    };
+    std::vector<WideBoxes> wide_boxes(1);  // exact child boxes of every 4-wide node (for the full-precision records)
     res.nodes.push_back(empty_node());
     std::vector<Task> stack;
     stack.push_back(Task{0, 0, 1});
@@ -506,11 +513,16 @@ inline Result build(const float *verts, int n) {
             } else {
                 int child = (int)res.nodes.size();
                 res.nodes.push_back(empty_node());
+                wide_boxes.push_back(WideBoxes());
                 nd.link[k] = child;
                 stack.push_back(Task{kids[k], child, t.depth + 1});
             }
         }
         res.nodes[t.out_node] = nd;
+        for (int k = 0; k < 4; k++) {
+            if (k < nk) wide_boxes[t.out_node].b[k] = cb[k];
+            else wide_boxes[t.out_node].b[k].reset();
+        }
     }
     res.stack_bound = 3 * res.max_depth + 1;
     // ---- 2-wide records from the same binary tree
@@ -623,14 +635,35 @@ inline Result build(const float *verts, int n) {
                         order_new.push_back(i);
                     }
                 std::vector<Node4> old = res.nodes;
+                std::vector<WideBoxes> old_boxes = wide_boxes;
                 for (int i = 0; i < n_rec; i++) {
                     Node4 nd = old[i];
                     for (int k = 0; k < 4; k++)
                         if (nd.link[k] >= 0) nd.link[k] = new_of[nd.link[k]];
                     res.nodes[new_of[i]] = nd;
+                    wide_boxes[new_of[i]] = old_boxes[i];
                 }
             }
         }
+    }
+    // ---- the same 4-wide tree with full-precision boxes: two pair-style records per node
+    {
+        Pair empty;
+        memset(&empty, 0, sizeof(empty));
+        empty.llink = empty.rlink = kNoChild;
+        res.quads.assign(2 * res.nodes.size(), empty);
+        for (size_t j = 0; j < res.nodes.size(); j++)
+            for (int k = 0; k < 4; k++) {
+                const int32_t link = res.nodes[j].link[k];
+                if (link == kNoChild) continue;
+                Pair &rec = res.quads[2 * j + (k >> 1)];
+                float *dst = (k & 1) ? rec.rbox : rec.lbox;
+                for (int a = 0; a < 3; a++) {
+                    dst[a] = pad_down(wide_boxes[j].b[k].lo[a], 2);
+                    dst[3 + a] = pad_up(wide_boxes[j].b[k].hi[a], 2);
+                }
+                ((k & 1) ? rec.rlink : rec.llink) = link >= 0 ? 2 * link : link;
+            }
     }
     return res;
 }

@@ -775,7 +775,7 @@ template <bool WIDE>
 __device__ __forceinline__ void inner_step(const DScene &sc, V3 o, V3 inv, float tmax, int &cur, int &sp, int *stack,
                                            int *over, int stack_cap, const float4 *top = nullptr, int top_n = 0) {
     // (2-wide records) the top of the LDS part of the stack, in case this step ends in a pop: see below
-    const int spec_top = WIDE ? 0 : stack[max(min(sp - 1, stack_cap - 1), 0) * kBlock];
+    const int spec_top = stack[max(min(sp - 1, stack_cap - 1), 0) * kBlock];
     float4 q0, q1, q2, q3;
     if (top_n > 0 && cur < top_n) {
         const float4 *q = top + 4 * cur;
@@ -834,49 +834,59 @@ __device__ __forceinline__ void inner_step(const DScene &sc, V3 o, V3 inv, float
         if (both) stack_push(stack, over, sp, stack_cap, left_first ? cr : cl);
     }
     if (WIDE) {
-        const unsigned exps = __float_as_uint(q0.w);
-        const float cx = __uint_as_float((exps & 0xffu) << 23);
-        const float cy = __uint_as_float(((exps >> 8) & 0xffu) << 23);
-        const float cz = __uint_as_float(((exps >> 16) & 0xffu) << 23);
-        const unsigned lox = __float_as_uint(q2.x), loy = __float_as_uint(q2.y), loz = __float_as_uint(q2.z);
-        const unsigned hix = __float_as_uint(q2.w), hiy = __float_as_uint(q3.x), hiz = __float_as_uint(q3.y);
-        const int links[4] = {__float_as_int(q1.x), __float_as_int(q1.y), __float_as_int(q1.z), __float_as_int(q1.w)};
-        // (entry distance, link) of every child the ray may enter; a miss sorts last
-        unsigned key[4];
-        int lnk[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int sh = 8 * k;
-            // bound = origin + float(q) * cell : the expression the builder verified (rt_bvh.h)
-            float bx0 = q0.x + (float)((lox >> sh) & 0xffu) * cx, bx1 = q0.x + (float)((hix >> sh) & 0xffu) * cx;
-            float by0 = q0.y + (float)((loy >> sh) & 0xffu) * cy, by1 = q0.y + (float)((hiy >> sh) & 0xffu) * cy;
-            float bz0 = q0.z + (float)((loz >> sh) & 0xffu) * cz, bz1 = q0.z + (float)((hiz >> sh) & 0xffu) * cz;
-            float e;
-            bool h = box_hit(o, inv, bx0, by0, bz0, bx1, by1, bz1, tmax, e) && links[k] != kEntryDone;
-            key[k] = h ? __float_as_uint(fmaxf(e, 0.f)) : 0xffffffffu;
-            lnk[k] = links[k];
+        // 4-wide node = two pair-style records (children 0, 1 | children 2, 3) with full-precision boxes: half the
+        // dependent fetches of the 2-wide walk for the same box arithmetic.  The nearest child the ray may enter becomes
+        // the cursor, the others go onto the stack in record order (measured on the CPU walk: sorting them as well
+        // saves 0.3 % of the steps), nothing entered -> the speculative top of the stack.
+        const float4 *qb = (const float4 *)((const char *)sc.nodes + ((unsigned)cur << 6)) + 4;
+        const float4 r0 = qb[0], r1 = qb[1], r2 = qb[2], r3 = qb[3];
+        const int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y), c2 = __float_as_int(r3.x), c3 = __float_as_int(r3.y);
+        const v2f ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z};
+        const v2f ix = {inv.x, inv.x}, iy = {inv.y, inv.y}, iz = {inv.z, inv.z};
+        const float tmax_w = tmax * 1.000001f;
+        float e[4];
+        bool h[4];
+        {
+            v2f ax = (v2f{q0.x, q0.y} - ox) * ix, ay = (v2f{q0.z, q0.w} - oy) * iy, az = (v2f{q1.x, q1.y} - oz) * iz;
+            v2f bx = (v2f{q1.z, q1.w} - ox) * ix, by = (v2f{q2.x, q2.y} - oy) * iy, bz = (v2f{q2.z, q2.w} - oz) * iz;
+            e[0] = fmaxf(fmaxf(fminf(ax.x, bx.x), fminf(ay.x, by.x)), fminf(az.x, bz.x));
+            e[1] = fmaxf(fmaxf(fminf(ax.y, bx.y), fminf(ay.y, by.y)), fminf(az.y, bz.y));
+            v2f t_out = {fminf(fminf(fmaxf(ax.x, bx.x), fmaxf(ay.x, by.x)), fmaxf(az.x, bz.x)),
+                         fminf(fminf(fmaxf(ax.y, bx.y), fmaxf(ay.y, by.y)), fmaxf(az.y, bz.y))};
+            t_out = t_out * v2f{1.000001f, 1.000001f};
+            h[0] = e[0] <= t_out.x && t_out.x >= 0.f && e[0] <= tmax_w && c0 != kEntryDone;
+            h[1] = e[1] <= t_out.y && t_out.y >= 0.f && e[1] <= tmax_w && c1 != kEntryDone;
         }
-        // sorting network on 4 (key, link) pairs, ascending by entry distance
-#define RT_CSWAP(a, b)                                                     \
-    {                                                                      \
-        bool sw = key[b] < key[a];                                         \
-        unsigned ka = sw ? key[b] : key[a], kb = sw ? key[a] : key[b];     \
-        int la = sw ? lnk[b] : lnk[a], lb = sw ? lnk[a] : lnk[b];          \
-        key[a] = ka; key[b] = kb; lnk[a] = la; lnk[b] = lb;                \
-    }
-        RT_CSWAP(0, 1) RT_CSWAP(2, 3) RT_CSWAP(0, 2) RT_CSWAP(1, 3) RT_CSWAP(1, 2)
-#undef RT_CSWAP
-        // far children first onto the stack, nearest becomes the current entry
-        if (key[3] != 0xffffffffu) { stack_push(stack, over, sp, stack_cap, lnk[3]); }
-        if (key[2] != 0xffffffffu) { stack_push(stack, over, sp, stack_cap, lnk[2]); }
-        if (key[1] != 0xffffffffu) { stack_push(stack, over, sp, stack_cap, lnk[1]); }
-        if (key[0] != 0xffffffffu) {
-            cur = lnk[0];
-        } else if (sp > 0) {
-            cur = stack_pop(stack, over, sp, stack_cap);
-        } else {
-            cur = kEntryDone;
+        {
+            v2f ax = (v2f{r0.x, r0.y} - ox) * ix, ay = (v2f{r0.z, r0.w} - oy) * iy, az = (v2f{r1.x, r1.y} - oz) * iz;
+            v2f bx = (v2f{r1.z, r1.w} - ox) * ix, by = (v2f{r2.x, r2.y} - oy) * iy, bz = (v2f{r2.z, r2.w} - oz) * iz;
+            e[2] = fmaxf(fmaxf(fminf(ax.x, bx.x), fminf(ay.x, by.x)), fminf(az.x, bz.x));
+            e[3] = fmaxf(fmaxf(fminf(ax.y, bx.y), fminf(ay.y, by.y)), fminf(az.y, bz.y));
+            v2f t_out = {fminf(fminf(fmaxf(ax.x, bx.x), fmaxf(ay.x, by.x)), fmaxf(az.x, bz.x)),
+                         fminf(fminf(fmaxf(ax.y, bx.y), fmaxf(ay.y, by.y)), fmaxf(az.y, bz.y))};
+            t_out = t_out * v2f{1.000001f, 1.000001f};
+            h[2] = e[2] <= t_out.x && t_out.x >= 0.f && e[2] <= tmax_w && c2 != kEntryDone;
+            h[3] = e[3] <= t_out.y && t_out.y >= 0.f && e[3] <= tmax_w && c3 != kEntryDone;
         }
+        // nearest entered child (a child that is not entered counts as infinitely far)
+        const float f0 = h[0] ? e[0] : kFltMax, f1 = h[1] ? e[1] : kFltMax, f2 = h[2] ? e[2] : kFltMax, f3 = h[3] ? e[3] : kFltMax;
+        const bool a01 = !(f0 > f1), a23 = !(f2 > f3);       // winner of each record (ties: the lower index)
+        const float g01 = a01 ? f0 : f1, g23 = a23 ? f2 : f3;
+        const bool first = !(g01 > g23);
+        const int near_k = first ? (a01 ? 0 : 1) : (a23 ? 2 : 3);
+        const int near_link = first ? (a01 ? c0 : c1) : (a23 ? c2 : c3);
+        const bool any_hit = h[0] || h[1] || h[2] || h[3];
+        int popped = sp > 0 ? spec_top : kEntryDone;
+        if (!any_hit && sp > stack_cap) {
+            popped = over[(size_t)(sp - 1 - stack_cap) * kOverStride];
+            __asm__ volatile("" ::: "memory");
+        }
+        cur = any_hit ? near_link : popped;
+        sp -= (!any_hit && sp > 0) ? 1 : 0;
+        if (h[0] && near_k != 0) stack_push(stack, over, sp, stack_cap, c0);
+        if (h[1] && near_k != 1) stack_push(stack, over, sp, stack_cap, c1);
+        if (h[2] && near_k != 2) stack_push(stack, over, sp, stack_cap, c2);
+        if (h[3] && near_k != 3) stack_push(stack, over, sp, stack_cap, c3);
     }
 }
 
@@ -1141,7 +1151,11 @@ constexpr int kTriPerStep = RT_TRI_PER_STEP;  // triangle tests a lane makes per
 #ifndef RT_NODE_PER_STEP
 #define RT_NODE_PER_STEP 8
 #endif
-constexpr int kNodePerStep = RT_NODE_PER_STEP;  // node steps a lane makes per scheduled node block
+constexpr int kNodePerStep = RT_NODE_PER_STEP;  // node steps a lane makes per scheduled node block (2-wide records)
+#ifndef RT_NODE_PER_STEP_WIDE
+#define RT_NODE_PER_STEP_WIDE 2
+#endif
+constexpr int kNodePerStepWide = RT_NODE_PER_STEP_WIDE;  // ... with 4-wide nodes (measured: 3 649 / 3 620 / 3 539 / 3 391 Msamples/s at 2 / 3 / 4 / 5)
 #ifndef RT_SPECULATE
 #define RT_SPECULATE 1
 #endif
@@ -1519,7 +1533,7 @@ k_paths(DScene sc, DPools p, Camera cam_arg, AdvanceParams ap_arg, float *__rest
                 // a bounded while-while: up to kNodePerStep consecutive node steps (2 triangle tests in the
                 // triangle block) per scheduling decision -- measured best at 8 / 2 (+22 % over 1 / 1; 4 / 2: +20 %)
 #pragma unroll
-                for (int rep = 0; rep < kNodePerStep; rep++) {
+                for (int rep = 0; rep < (WIDE ? kNodePerStepWide : kNodePerStep); rep++) {
                     if (cur >= 0) {
                         inner_step<WIDE>(sc, o, inv, tmax, cur, sp, stack, over, stack_cap, s_top, top_n);
                     } else if (kSpeculate && cur != kEntryDone && pend == kEntryDone && sp > 0) {
@@ -1838,7 +1852,7 @@ struct rt_scene {
     int device = 0;
     int n_tris = 0, n_nodes = 0, max_depth = 0, stack_bound = 1, n_leaves = 0, n_lights = 0, n_mats = 0;
     float4 *d_nodes = nullptr;
-    bool wide = false;  // node records: 4-wide quantised (rtbvh::Node4) or 2-wide exact (rtbvh::Pair)
+    bool wide = false;  // node records: 4-wide (two pair-style records per node, rtbvh::Result::quads) or 2-wide (rtbvh::Pair)
     bool top_prefix = true;  // the first records are the top of the tree in level order (host builder)
     double build_seconds = 0.0;  // BVH build time (host wall clock, or device events for the LBVH)
     int builder = 0;             // 0 host SAH, 1 device LBVH
@@ -2313,6 +2327,7 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
                 top_n = scene->top_prefix ? std::max(0, std::min(std::min(768, atoi(e)), std::min(scene->n_nodes, (int)rtbvh::kTopPrefix))) : 0;
             lds_paths += (size_t)top_n * 64;
         }
+        if (scene->wide) top_n = 0;  // (the LDS copy of the top of the tree exists for 2-wide records only)
         int gen_batch = 6;  // lanes waiting for the GEN block before it runs (unless nothing else can); flat 5..8
         if (const char *e = getenv("RT_GEN_BATCH")) gen_batch = std::max(1, std::min(64, atoi(e)));
         int prio_rotate = 8;  // log2 of the priority-rotation period in scheduling decisions; 0 = off
@@ -2633,10 +2648,10 @@ int rt_scene_create(const float *tri_p0p1p2, int n_tris, const int32_t *tri_mate
     if ((sc->builder == 1 ? bvh.pair_depth + 1 : bvh.stack_bound) > kMaxStackBound)
         return fail("rt_scene_create: BVH depth " + std::to_string(bvh.max_depth) + " exceeds the traversal stack");
     sc->n_tris = n_tris;
-    sc->wide = false;  // 2-wide exact records: cheaper per test, and the trace kernel is VALU-bound
+    sc->wide = true;  // 4-wide nodes (two pair-style records each): half the dependent fetches per ray; RT_BVH_WIDE=0: 2-wide
     if (const char *e = getenv("RT_BVH_WIDE")) sc->wide = atoi(e) != 0;
     if (sc->builder == 1) sc->wide = false;  // the device builder emits 2-wide records only
-    sc->n_nodes = sc->wide ? (int)bvh.nodes.size() : (int)bvh.pairs.size();
+    sc->n_nodes = sc->wide ? (int)bvh.quads.size() : (int)bvh.pairs.size();  // 64-byte records
     sc->max_depth = sc->wide ? bvh.max_depth : bvh.pair_depth;
     sc->stack_bound = sc->wide ? bvh.stack_bound : bvh.pair_depth + 1;
     sc->n_leaves = bvh.num_leaves;
@@ -2676,12 +2691,14 @@ int rt_scene_create(const float *tri_p0p1p2, int n_tris, const int32_t *tri_mate
         //   (l.lo.x, r.lo.x, l.lo.y, r.lo.y | l.lo.z, r.lo.z, l.hi.x, r.hi.x | l.hi.y, r.hi.y, l.hi.z, r.hi.z | llink, rlink, 0, 0)
         // -- so that every (left, right) pair of bounds arrives in an aligned register pair and the slab
         // arithmetic of both children runs as packed fp32 (v_pk_add_f32 / v_pk_mul_f32), see inner_step
+        // (4-wide: a node is two such records back to back -- children 0, 1 and children 2, 3 -- rt_bvh.h `quads`)
         std::vector<float> inter;
-        const void *src = (const void *)bvh.nodes.data();
-        if (!sc->wide) {
-            inter.resize(16 * bvh.pairs.size());
-            for (size_t k = 0; k < bvh.pairs.size(); k++) {
-                const rtbvh::Pair &pr = bvh.pairs[k];
+        const std::vector<rtbvh::Pair> &recs = sc->wide ? bvh.quads : bvh.pairs;
+        const void *src = nullptr;
+        {
+            inter.resize(16 * recs.size());
+            for (size_t k = 0; k < recs.size(); k++) {
+                const rtbvh::Pair &pr = recs[k];
                 float *r = &inter[16 * k];
                 for (int a = 0; a < 6; a++) {
                     r[2 * a] = pr.lbox[a];
