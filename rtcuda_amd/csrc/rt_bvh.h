@@ -7,26 +7,18 @@
 //
 //   1. binary tree by full-sweep SAH over three index arrays kept sorted per axis (the quality class
 //      of the reference's builder), leaf cost model C_leaf = n_tris, C_split = 1 + SAH, <= 4 tris/leaf;
-//   2. collapsed to a 4-wide tree (the child with the largest surface area is opened until a node has
-//      four children), which halves the number of dependent node fetches per ray;
-//   3. every 4-wide node is ONE 64-byte record -- the traversal kernel is bound by the number of
-//      64-byte lines its divergent lanes pull through the texture-address path, so the four child
-//      boxes are stored as 8-bit offsets on a power-of-two grid anchored at the node's own box
-//      (6 bytes per child instead of 24):
-//
-//        w0..w2   float  origin = lower corner of the node's box
-//        w3       uint   grid exponents: ex | ey << 8 | ez << 16   (cell = 2^(e - 127) as an fp32 bit pattern)
-//        w4..w7   int    child links: >= 0 inner node index, < 0 leaf reference ~(first << 3 | count),
-//                        0x80000000 = no child
-//        w8..w10  uint   lower bounds x / y / z, one byte per child (child k in bits 8k..8k+7)
-//        w11..w13 uint   upper bounds x / y / z
-//        w14,w15  spare
-//
-//      decode (device and host use exactly this fp32 expression, no FMA):  bound = origin + float(q) * cell
-//      The builder verifies, with that same expression, that every decoded child box CONTAINS the child's
-//      exact box padded outward by 2 ulps, so the kernel's slab test stays conservative with respect to
-//      the exact triangle test (a box test must never cull a triangle the triangle test would accept).
-//   4. triangles are re-ordered so every leaf's triangles are contiguous ("leaf order").
+//   1b. insertion-based optimisation of that tree (optimize_reinsert): -10 % node steps per ray;
+//   2. written out in two formats made of the same 64-byte record -- two children's exact fp32 boxes, padded
+//      outward by 2 ulps so that the kernels' slab test stays conservative with respect to the exact triangle
+//      test (a box test must never cull a triangle the triangle test would accept), and their links
+//      (>= 0 inner record index, < 0 leaf reference ~(first << 3 | count), 0x80000000 = no child):
+//        `pairs`  the binary tree, one record per inner node;
+//        `quads`  the tree collapsed to 4-wide (the child with the largest surface area is opened until a node
+//                 has four children), TWO consecutive records per node (children 0, 1 | children 2, 3): half the
+//                 dependent node fetches per ray for the same box arithmetic -- the default of the kernels.
+//      (Round 1's 4-wide format squeezed a node into ONE record with 8-bit quantised boxes; decoding them cost
+//      more vector instructions than the halved fetches saved: 1.8 vs 3.0 Gsamples/s.  Removed.)
+//   3. triangles are re-ordered so every leaf's triangles are contiguous ("leaf order").
 #ifndef RT_BVH_H
 #define RT_BVH_H
 
@@ -62,29 +54,15 @@ struct Box {
 constexpr int32_t kNoChild = (int32_t)0x80000000;
 inline int32_t leaf_ref(int first, int count) { return ~((first << 3) | count); }
 
-struct Node4 {
-    float origin[3];
-    uint32_t exps;
-    int32_t link[4];
-    uint32_t qlo[3];
-    uint32_t qhi[3];
-    uint32_t spare[2];
+// A node of the collapsed 4-wide tree before it is written out as two pair-style records (see `quads`).
+struct WideNode {
+    int32_t link[4];  // child k: a node index (>= 0), a leaf reference (< 0) or kNoChild
+    Box box[4];       // exact (unpadded) child boxes
 };
-static_assert(sizeof(Node4) == 64, "wide node must be one 64-byte line");
 
-// decode exactly as the kernel does
-inline float cell_size(uint32_t exps, int axis) {
-    uint32_t bits = ((exps >> (8 * axis)) & 0xffu) << 23;
-    float f;
-    memcpy(&f, &bits, 4);
-    return f;
-}
-inline float decode(float origin, uint32_t q, float cell) { return origin + (float)q * cell; }
-
-// 2-wide alternative: both children's exact fp32 boxes (padded outward by 2 ulps) + both links in one
-// 64-byte record.  w0..w5 left box lo xyz / hi xyz, w6..w11 right box, w12 left link, w13 right link
-// (same link encoding as Node4), w14, w15 spare.  One node test costs ~1/3 of the VALU work of a
-// quantised 4-wide test, at about twice the number of 64-byte fetches per ray.
+// The 64-byte record both tree formats are made of: two children's exact fp32 boxes (padded outward by 2 ulps) and
+// their links.  w0..w5 left box lo xyz / hi xyz, w6..w11 right box, w12 left link, w13 right link, w14, w15 spare.
+// 2-wide tree: one record per inner node (`pairs`).  4-wide tree: two consecutive records per node (`quads`).
 struct Pair {
     float lbox[6];
     float rbox[6];
@@ -102,7 +80,7 @@ struct BinNode {
 };
 
 struct Result {
-    std::vector<Node4> nodes;    // 4-wide quantised records
+    std::vector<WideNode> nodes; // the collapsed 4-wide tree (host form; the kernels read `quads`)
     std::vector<Pair> pairs;     // 2-wide full-precision records (same binary tree)
     std::vector<Pair> quads;     // 4-wide full-precision nodes of the collapsed tree: node j = records 2j (children 0, 1)
                                  // and 2j + 1 (children 2, 3); inner links are RECORD indices (2 x node), see build()
@@ -367,62 +345,7 @@ inline void optimize_reinsert(std::vector<BinNode> &bin, int passes) {
         }
     }
 }
-// ---- steps 2 + 3: collapse to 4-wide, quantise
-inline bool quantise_node(Node4 &nd, const Box *child_boxes, int nchild) {
-    Box all;
-    all.reset();
-    Box padded[4];
-    for (int k = 0; k < nchild; k++) {
-        for (int a = 0; a < 3; a++) {
-            padded[k].lo[a] = pad_down(child_boxes[k].lo[a], 2);
-            padded[k].hi[a] = pad_up(child_boxes[k].hi[a], 2);
-        }
-        all.extend(padded[k]);
-    }
-    nd.exps = 0;
-    for (int a = 0; a < 3; a++) {
-        nd.origin[a] = all.lo[a];
-        nd.qlo[a] = 0;
-        nd.qhi[a] = 0;
-    }
-    for (int a = 0; a < 3; a++) {
-        double extent = (double)all.hi[a] - (double)all.lo[a];
-        int e = 1;  // biased exponent byte; cell = 2^(e - 127)
-        if (extent > 0) {
-            int ex;
-            std::frexp(extent / 255.0, &ex);  // extent/255 = m * 2^ex, m in [0.5, 1)  -> cell 2^ex >= extent/255
-            e = std::min(254, std::max(1, ex + 127));
-        }
-        for (;; e++) {
-            if (e > 254) return false;
-            uint32_t exps_try = (nd.exps & ~(0xffu << (8 * a))) | ((uint32_t)e << (8 * a));
-            float cell = cell_size(exps_try, a);
-            uint32_t lo_bytes = 0, hi_bytes = 0;
-            bool ok = true;
-            for (int k = 0; k < nchild && ok; k++) {
-                double ql = std::floor(((double)padded[k].lo[a] - (double)nd.origin[a]) / (double)cell);
-                double qh = std::ceil(((double)padded[k].hi[a] - (double)nd.origin[a]) / (double)cell);
-                long l = (long)std::max(0.0, std::min(255.0, ql));
-                long h = (long)std::max(0.0, std::min(255.0, qh));
-                while (l > 0 && decode(nd.origin[a], (uint32_t)l, cell) > padded[k].lo[a]) l--;
-                while (h < 255 && decode(nd.origin[a], (uint32_t)h, cell) < padded[k].hi[a]) h++;
-                if (decode(nd.origin[a], (uint32_t)l, cell) > padded[k].lo[a] ||
-                    decode(nd.origin[a], (uint32_t)h, cell) < padded[k].hi[a])
-                    ok = false;  // grid too fine for this extent: double the cell
-                lo_bytes |= (uint32_t)l << (8 * k);
-                hi_bytes |= (uint32_t)h << (8 * k);
-            }
-            if (ok) {
-                nd.exps = exps_try;
-                nd.qlo[a] = lo_bytes;
-                nd.qhi[a] = hi_bytes;
-                break;
-            }
-        }
-    }
-    return true;
-}
-
+// ---- step 2: collapse to 4-wide, write both record formats
 // verts: n x 9 floats (p0 p1 p2).  Deterministic for a given input.
 inline Result build(const float *verts, int n) {
     Result res;
@@ -444,10 +367,11 @@ inline Result build(const float *verts, int n) {
         }
     }
     auto empty_node = [] {
-        Node4 nd;
-        memset(&nd, 0, sizeof(nd));
-        for (int k = 0; k < 4; k++) nd.link[k] = kNoChild;
-        nd.exps = 0x010101u;
+        WideNode nd;
+        for (int k = 0; k < 4; k++) {
+            nd.link[k] = kNoChild;
+            nd.box[k].reset();
+        }
         return nd;
     };
     if (n == 0) {
@@ -465,10 +389,6 @@ inline Result build(const float *verts, int n) {
     struct Task {
         int bin_node, out_node, depth;
     };
-    struct WideBoxes {
-        Box b[4];
-    };
-    std::vector<WideBoxes> wide_boxes(1);  // exact child boxes of every 4-wide node (for the full-precision records)
     res.nodes.push_back(empty_node());
     std::vector<Task> stack;
     stack.push_back(Task{0, 0, 1});
@@ -499,10 +419,8 @@ inline Result build(const float *verts, int n) {
                 kids[nk++] = bin[opened].right;
             }
         }
-        Box cb[4];
-        Node4 nd = empty_node();
-        for (int k = 0; k < nk; k++) cb[k] = bin[kids[k]].box;
-        quantise_node(nd, cb, nk);
+        WideNode nd = empty_node();
+        for (int k = 0; k < nk; k++) nd.box[k] = bin[kids[k]].box;
         for (int k = 0; k < nk; k++) {
             const BinNode &c = bin[kids[k]];
             if (c.left < 0) {
@@ -513,16 +431,11 @@ inline Result build(const float *verts, int n) {
             } else {
                 int child = (int)res.nodes.size();
                 res.nodes.push_back(empty_node());
-                wide_boxes.push_back(WideBoxes());
                 nd.link[k] = child;
                 stack.push_back(Task{kids[k], child, t.depth + 1});
             }
         }
         res.nodes[t.out_node] = nd;
-        for (int k = 0; k < 4; k++) {
-            if (k < nk) wide_boxes[t.out_node].b[k] = cb[k];
-            else wide_boxes[t.out_node].b[k].reset();
-        }
     }
     res.stack_bound = 3 * res.max_depth + 1;
     // ---- 2-wide records from the same binary tree
@@ -634,14 +547,12 @@ inline Result build(const float *verts, int n) {
                         new_of[i] = (int)order_new.size();
                         order_new.push_back(i);
                     }
-                std::vector<Node4> old = res.nodes;
-                std::vector<WideBoxes> old_boxes = wide_boxes;
+                std::vector<WideNode> old = res.nodes;
                 for (int i = 0; i < n_rec; i++) {
-                    Node4 nd = old[i];
+                    WideNode nd = old[i];
                     for (int k = 0; k < 4; k++)
                         if (nd.link[k] >= 0) nd.link[k] = new_of[nd.link[k]];
                     res.nodes[new_of[i]] = nd;
-                    wide_boxes[new_of[i]] = old_boxes[i];
                 }
             }
         }
@@ -659,8 +570,8 @@ inline Result build(const float *verts, int n) {
                 Pair &rec = res.quads[2 * j + (k >> 1)];
                 float *dst = (k & 1) ? rec.rbox : rec.lbox;
                 for (int a = 0; a < 3; a++) {
-                    dst[a] = pad_down(wide_boxes[j].b[k].lo[a], 2);
-                    dst[3 + a] = pad_up(wide_boxes[j].b[k].hi[a], 2);
+                    dst[a] = pad_down(res.nodes[j].box[k].lo[a], 2);
+                    dst[3 + a] = pad_up(res.nodes[j].box[k].hi[a], 2);
                 }
                 ((k & 1) ? rec.rlink : rec.llink) = link >= 0 ? 2 * link : link;
             }

@@ -205,9 +205,10 @@ def test_camera_ray_ownership_is_a_round_robin_of_pixel_strips():
 
 
 def test_full_pool_k_paths_build_does_not_spill_vector_registers():
-    """The 4-waves-per-SIMD build of k_paths sits exactly at its 128-VGPR budget; source changes that tip the
-    register allocator into spilling cost 6 % and look like noise in a benchmark.  hipcc cross-compiles without a GPU:
-    its resource remarks must report no VGPR spill for that kernel."""
+    """The 4-waves-per-SIMD builds of k_paths live on a 128-VGPR budget; source changes that tip the register allocator
+    into spilling cost 4 - 6 % and look like noise in a benchmark (a spill inside the node loop: far more).  hipcc
+    cross-compiles without a GPU: its resource remarks must report no VGPR spill for the bench configuration (4-wide
+    nodes) and for the 2-wide alternative."""
     import shutil
     import subprocess
     hipcc = "/opt/rocm/bin/hipcc"
@@ -217,18 +218,18 @@ def test_full_pool_k_paths_build_does_not_spill_vector_registers():
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:]
     lines = r.stdout.splitlines()
-    found = False
+    found = 0
     for k, line in enumerate(lines):
-        # k_paths<LDS_TABLES = true, WIDE = false, MAJORITY = true, MIN_WAVES = 4>: the bench configuration
-        if "Function Name: _Z7k_pathsILb1ELb0ELb1ELi4E" in line:
+        # k_paths<LDS_TABLES = true, WIDE = true (bench) / false, MAJORITY = true, MIN_WAVES = 4>
+        if "Function Name: _Z7k_pathsILb1ELb1ELb1ELi4E" in line or "Function Name: _Z7k_pathsILb1ELb0ELb1ELi4E" in line:
             block = "\n".join(lines[k:k + 12])
             m_spill = re.search(r"VGPRs Spill: (\d+)", block)
             m_occ = re.search(r"Occupancy \[waves/SIMD\]: (\d+)", block)
             assert m_spill and m_occ, block
             assert int(m_occ.group(1)) == 4, block
             assert int(m_spill.group(1)) == 0, block
-            found = True
-    assert found, "k_paths<true, false, true, 4> not in the resource remarks"
+            found += 1
+    assert found == 2, "k_paths<true, {true, false}, true, 4> not in the resource remarks"
 
 
 def test_bench_refuses_debug_flags_without_allow_invalid():
