@@ -31,9 +31,10 @@
 //                generation, by the stage-level test entry points, and (RT_PERSISTENT=0) for whole frames.
 //   advance_core / inner_step / tri_intersect / box_hit are the shared device functions: one copy of
 //   the estimator and of the traversal for both pipelines.
-//   * BVH: 64-byte node records -- 2-wide with exact padded boxes (default) or 4-wide with 8-bit
-//     quantised boxes -- and 48-byte {p0,e1,e2,n} triangle records in leaf order (rt_bvh.h: SAH sweep
-//     + insertion-based optimisation).
+//   * BVH: 64-byte node records with full-precision padded boxes -- a 4-wide node as two consecutive
+//     records (default), or 2-wide nodes of one record (RT_BVH_WIDE=0, and always for the device LBVH) --
+//     and 48-byte {p0,e1,e2,n} triangle records in leaf order (rt_bvh.h: SAH sweep + insertion-based
+//     optimisation + collapse to 4-wide).
 //   * Two results that depend, in the reference, on the shape of its own tree are defined by the triangle
 //     list alone here: an accepted hit is never culled (conservative box test), and hits at exactly equal
 //     t go to the larger caller index (closest_hit_wins).  Traversal ORDER therefore never matters.
@@ -85,7 +86,7 @@ constexpr int kMaxStackBound = 160;    // deepest traversal stack a scene may ne
 
 // ============================================================================ device structures
 struct DScene {
-    const float4 *nodes;   // 4 x float4 per 4-wide node record (rt_bvh.h)
+    const float4 *nodes;   // 64-byte records (4 x float4): two per 4-wide node, one per 2-wide node (rt_bvh.h)
     const float4 *tris;    // 3 x float4 per triangle, leaf order
     const int2 *tri_info;  // leaf order: {material index, light index or -1}
     const float4 *tri_shade;  // leaf order: what mat() needs of a hit triangle besides the point -- the flipped unit

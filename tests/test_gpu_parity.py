@@ -287,8 +287,8 @@ def test_single_generation_frame_is_the_same_with_and_without_the_persistent_lau
 
 
 def test_both_node_formats_match_oracle(api, oracle, cpu_matte, bunny_matte, monkeypatch):
-    """2-wide exact records (default) and 4-wide quantised records are both conservative culling
-    structures over the same triangle test: same hits as the oracle."""
+    """2-wide nodes (RT_BVH_WIDE=0) and 4-wide nodes (two records each, the default) are both conservative
+    culling structures over the same triangle test: same hits as the oracle."""
     cam = default_camera(oracle, 16 / 9)
     o, d = raygen.camera_rays(cam, 1920, 1080, 150_000, seed=31)
     tmax = np.full(len(o), FLT_MAX, np.float32)
