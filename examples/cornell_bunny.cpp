@@ -4,7 +4,6 @@
 //
 //   make -C rtcuda_amd/csrc example
 //   examples/cornell_bunny [width height spp [bun_zipper.ply [image.ppm [matte|full_bsdf|four_bunnies|sixteen_lights]]]]
-#include <chrono>
 #include <cstdlib>
 #include <iostream>
 #include <string>
@@ -22,18 +21,24 @@ int main(int argc, char **argv) {
         CornellBunny::Variant v = variant == "full_bsdf" ? CornellBunny::FULL_BSDF
                                   : variant == "four_bunnies" ? CornellBunny::FOUR_BUNNIES
                                   : variant == "sixteen_lights" ? CornellBunny::SIXTEEN_LIGHTS : CornellBunny::MATTE;
-        CornellBunny recipe(ply, v);
-        std::cout << recipe.num_vertices << " vertices, " << recipe.num_faces << " faces" << std::endl;  // main.cu:63
+        // stage lines as the reference's driver prints them (main.cu:59-85,172-192; profiler.hpp), so the logs line up;
+        // the BVH stage is one line here (the reference's constructor prints five: bvh.cuh:36-218)
+        CornellBunny recipe(ply, v, true);
         Scene scene = recipe.scene();
+        profiler.start("Constructing BVH");
+        prepare(scene);
+        profiler.stop();
         Camera camera = CornellBunny::camera((float)width / (float)height);
         std::vector<Vec3> framebuffer;
         rt_stats st;
-        auto t0 = std::chrono::steady_clock::now();
+        profiler.start("Rendering");
         render(width, height, num_samples, max_bounces, camera, scene, framebuffer, 1, &st);
-        float ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
-        std::cout << "Rendering... done (" << ms << "ms), render loop " << st.seconds_render * 1e3 << " ms, "
+        profiler.stop();
+        std::cout << "render loop " << st.seconds_render * 1e3 << " ms, "
                   << (double)width * height * num_samples / st.seconds_render / 1e6 << " Msamples/s" << std::endl;
+        profiler.start("Writing image");
         rtcuda::write_ppm(out, width, height, framebuffer);
+        profiler.stop();
     } catch (const std::exception &e) {
         std::cerr << "error: " << e.what() << std::endl;
         return 1;

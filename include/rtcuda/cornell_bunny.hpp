@@ -21,6 +21,7 @@
 #include <string>
 #include <vector>
 
+#include "profiler.hpp"
 #include "rtcuda.hpp"
 
 namespace rtcuda {
@@ -31,7 +32,9 @@ public:
     enum { RED, GREEN, WHITE, BROWN, GLASS_BUNNY, MIRROR_WALL, NUM_MATERIALS };
 
     // ply_path empty: the bare box (no bunny)
-    explicit CornellBunny(const std::string &ply_path, Variant variant = MATTE) : variant_(variant) {
+    // log_stages: print the driver's stage lines ("Reading bunny... done (12.3ms)", main.cu:59-85) through `profiler`
+    explicit CornellBunny(const std::string &ply_path, Variant variant = MATTE, bool log_stages_ = false)
+        : log_stages(log_stages_), variant_(variant) {
         materials_.resize(NUM_MATERIALS);
         materials_[RED] = Material::make_matte(Vec3(0.65f, 0.05f, 0.05f));
         materials_[GREEN] = Material::make_matte(Vec3(0.12f, 0.45f, 0.15f));
@@ -64,6 +67,7 @@ public:
     const std::vector<int> &material_of() const { return material_of_; }  // per triangle: index into materials()
     const std::vector<int> &light_of() const { return light_of_; }        // per triangle: index into lights() or -1
     size_t num_vertices = 0, num_faces = 0;                               // of the PLY (0 for the bare box)
+    const bool log_stages;
 
 private:
     void add_triangle(const Vec3 &a, const Vec3 &b, const Vec3 &c, int material) {
@@ -73,22 +77,32 @@ private:
     }
 
     void add_bunnies(const std::string &ply_path) {
+        // (stage lines as the reference's driver prints them -- main.cu:59-85 -- when `log_stages` is set)
+        if (log_stages) profiler.start("Reading bunny");
         PlyMesh mesh(ply_path);
         const std::vector<std::array<double, 3>> rest = mesh.getVertexPositions();
         const std::vector<std::vector<size_t>> faces = mesh.getFaceIndices<size_t>();
         num_vertices = rest.size();
         num_faces = faces.size();
+        if (log_stages) profiler.stop();
+        if (log_stages) std::cout << num_vertices << " vertices, " << num_faces << " faces" << std::endl;
         static const float one[1][3] = {{0.3f, 0.f, -0.5f}};
         static const float four[4][3] = {{0.1f, 0.f, -0.3f}, {0.55f, 0.f, -0.3f}, {0.1f, 0.f, -0.62f}, {0.55f, 0.f, -0.62f}};
         const float(*places)[3] = variant_ == FOUR_BUNNIES ? four : one;
         const int copies = variant_ == FOUR_BUNNIES ? 4 : 1;
         const int material = variant_ == FULL_BSDF ? GLASS_BUNNY : BROWN;
+        if (log_stages) profiler.start("Transforming bunny");
+        std::vector<std::vector<std::array<double, 3>>> placed((size_t)copies, rest);
         for (int c = 0; c < copies; c++) {
             Transform t(Matrix4x4::Translate(0.0946899f, -0.0329874f, -0.0587997f));
             t.composite(Matrix4x4::Scale(2.f, 2.f, 2.f));
             t.composite(Matrix4x4::Translate(places[c][0], places[c][1], places[c][2]));
-            std::vector<std::array<double, 3>> v = rest;
-            for (auto &p : v) t.apply(p);
+            for (auto &p : placed[(size_t)c]) t.apply(p);
+        }
+        if (log_stages) profiler.stop();
+        Profiler::Stage converting(log_stages ? profiler : quiet_, "Converting bunny to triangles");
+        for (int c = 0; c < copies; c++) {
+            const std::vector<std::array<double, 3>> &v = placed[(size_t)c];
             for (const std::vector<size_t> &f : faces) {
                 if (f.size() != 3) throw std::runtime_error("CornellBunny: the mesh has a face that is not a triangle");
                 for (size_t k : f)
@@ -147,6 +161,7 @@ private:
     }
 
     Variant variant_;
+    Profiler quiet_{false};  // (a disabled profiler: Stage guards that print nothing)
     std::vector<Material> materials_;
     std::vector<Triangle> triangles_;
     std::vector<int> material_of_, light_of_;

@@ -34,6 +34,7 @@
 #include "../rtcuda_amd.h"
 #include "matrix4x4.hpp"
 #include "ply.hpp"
+#include "profiler.hpp"
 #include "transform.hpp"
 
 // vec3.cuh:4-147, host side.  Arithmetic forms are the reference's where they round differently from the obvious
@@ -223,6 +224,10 @@ inline rt_scene *realise(const Scene &scene) {
     return sh.h;
 }
 }  // namespace rtcuda_detail
+
+// The reference builds and uploads its BVH in the Bvh constructor (bvh.cuh:30-219); here the device scene is created
+// the first time a Scene is rendered.  prepare() does it ahead of time, so a driver can time the two apart.
+inline void prepare(const Scene &scene) { (void)rtcuda_detail::realise(scene); }
 
 // render.cuh:366-367.  `seed` is the reference's hard-coded RAND_SEED = 1 (render.cuh:417).
 inline void render(int width, int height, int num_samples, int max_bounces, Camera camera, Scene scene,

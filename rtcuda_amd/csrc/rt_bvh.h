@@ -70,6 +70,15 @@ struct Pair {
     int32_t spare[2];
 };
 static_assert(sizeof(Pair) == 64, "pair record must be one 64-byte line");
+// A record of the 4-wide format without children: links kNoChild and all-+inf boxes, which no ray enters (per axis the
+// slab distances of such a box are both +inf or both -inf), so the kernel's box test needs no look at the link.
+inline Pair absent_quad_record() {
+    Pair p;
+    memset(&p, 0, sizeof(p));
+    for (int a = 0; a < 6; a++) p.lbox[a] = p.rbox[a] = INFINITY;
+    p.llink = p.rlink = (int32_t)0x80000000;
+    return p;
+}
 
 struct BinNode {
     Box box;         // exact (unpadded) box of the subtree
@@ -380,7 +389,7 @@ inline Result build(const float *verts, int n) {
         memset(&ep, 0, sizeof(ep));
         ep.llink = ep.rlink = kNoChild;
         res.pairs.push_back(ep);
-        res.quads.assign(2, ep);
+        res.quads.assign(2, absent_quad_record());
         res.max_depth = 1;
         res.pair_depth = 1;
         res.stack_bound = 1;
@@ -559,9 +568,7 @@ inline Result build(const float *verts, int n) {
     }
     // ---- the same 4-wide tree with full-precision boxes: two pair-style records per node
     {
-        Pair empty;
-        memset(&empty, 0, sizeof(empty));
-        empty.llink = empty.rlink = kNoChild;
+        const Pair empty = absent_quad_record();
         res.quads.assign(2 * res.nodes.size(), empty);
         for (size_t j = 0; j < res.nodes.size(); j++)
             for (int k = 0; k < 4; k++) {

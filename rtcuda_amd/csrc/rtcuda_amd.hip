@@ -744,6 +744,36 @@ __device__ __forceinline__ void stack_push(int *lds_col, int *over_col, int &sp,
     else over_col[(size_t)(sp - cap) * kOverStride] = v;
     sp++;
 }
+// Pushes without divergent branches: a value is ALWAYS stored one above the current top of the LDS part and the stack
+// pointer moves only if the push is meant (what lies above the top is never read).  The LDS part has one row more than
+// `cap` (callers allocate cap + 1 rows), which takes the stores of lanes whose LDS part is full; only such lanes,
+// rarely, branch -- once per node step -- to the global overflow column.  Written as `if (push) ...`, each of the up
+// to 3 pushes of a 4-wide node step cost an exec-mask save / restore pair, two jumps and a 64-bit overflow address:
+// a third of the instructions of the step.
+__device__ __forceinline__ void push_if(int *lds_col, int *over_col, int &sp, int cap, int v, bool push) {
+    lds_col[min(sp, cap) * kBlock] = v;
+    if (push && sp >= cap) {
+        over_col[(size_t)(sp - cap) * kOverStride] = v;
+        __asm__ volatile("" ::: "memory");
+    }
+    sp += push ? 1 : 0;
+}
+__device__ __forceinline__ void push_if4(int *lds_col, int *over_col, int &sp, int cap, int v0, bool p0, int v1, bool p1,
+                                         int v2, bool p2, int v3, bool p3) {
+    const int s0 = sp, s1 = s0 + (p0 ? 1 : 0), s2 = s1 + (p1 ? 1 : 0), s3 = s2 + (p2 ? 1 : 0), s4 = s3 + (p3 ? 1 : 0);
+    lds_col[min(s0, cap) * kBlock] = v0;
+    lds_col[min(s1, cap) * kBlock] = v1;
+    lds_col[min(s2, cap) * kBlock] = v2;
+    lds_col[min(s3, cap) * kBlock] = v3;
+    if (s4 > cap) {  // rare: some of this lane's pushes belong in the overflow column
+        if (p0 && s0 >= cap) over_col[(size_t)(s0 - cap) * kOverStride] = v0;
+        if (p1 && s1 >= cap) over_col[(size_t)(s1 - cap) * kOverStride] = v1;
+        if (p2 && s2 >= cap) over_col[(size_t)(s2 - cap) * kOverStride] = v2;
+        if (p3 && s3 >= cap) over_col[(size_t)(s3 - cap) * kOverStride] = v3;
+        __asm__ volatile("" ::: "memory");
+    }
+    sp = s4;
+}
 __device__ __forceinline__ int stack_pop(int *lds_col, int *over_col, int &sp, int cap) {
     sp--;
     // always read the LDS column (clamped) and patch from the overflow only when needed: written as a
@@ -832,7 +862,7 @@ __device__ __forceinline__ void inner_step(const DScene &sc, V3 o, V3 inv, float
         const int entered = (hl && (!hr || left_first)) ? cl : cr;
         cur = none ? popped : entered;
         sp -= (none && sp > 0) ? 1 : 0;
-        if (both) stack_push(stack, over, sp, stack_cap, left_first ? cr : cl);
+        push_if(stack, over, sp, stack_cap, left_first ? cr : cl, both);
     }
     if (WIDE) {
         // 4-wide node = two pair-style records (children 0, 1 | children 2, 3) with full-precision boxes: half the
@@ -844,9 +874,13 @@ __device__ __forceinline__ void inner_step(const DScene &sc, V3 o, V3 inv, float
         const int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y), c2 = __float_as_int(r3.x), c3 = __float_as_int(r3.y);
         const v2f ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z};
         const v2f ix = {inv.x, inv.x}, iy = {inv.y, inv.y}, iz = {inv.z, inv.z};
-        const float tmax_w = tmax * 1.000001f;
+        // (clamped to a finite value: an absent child has an all-+inf box -- rt_bvh.h -- whose entry distance is +inf or
+        // whose exit distance is -inf whatever the ray, so the one comparison below rejects it without a look at its link)
+        const float tmax_w = fminf(tmax * 1.000001f, kFltMax);
         float e[4];
         bool h[4];
+        // entered <=> entry <= exit, exit >= 0, entry <= tmax: max(entry, 0) <= min(exit, tmax) -- one comparison per child
+        // instead of three and their scalar ANDs (tmax >= 0 always)
         {
             v2f ax = (v2f{q0.x, q0.y} - ox) * ix, ay = (v2f{q0.z, q0.w} - oy) * iy, az = (v2f{q1.x, q1.y} - oz) * iz;
             v2f bx = (v2f{q1.z, q1.w} - ox) * ix, by = (v2f{q2.x, q2.y} - oy) * iy, bz = (v2f{q2.z, q2.w} - oz) * iz;
@@ -855,8 +889,8 @@ __device__ __forceinline__ void inner_step(const DScene &sc, V3 o, V3 inv, float
             v2f t_out = {fminf(fminf(fmaxf(ax.x, bx.x), fmaxf(ay.x, by.x)), fmaxf(az.x, bz.x)),
                          fminf(fminf(fmaxf(ax.y, bx.y), fmaxf(ay.y, by.y)), fmaxf(az.y, bz.y))};
             t_out = t_out * v2f{1.000001f, 1.000001f};
-            h[0] = e[0] <= t_out.x && t_out.x >= 0.f && e[0] <= tmax_w && c0 != kEntryDone;
-            h[1] = e[1] <= t_out.y && t_out.y >= 0.f && e[1] <= tmax_w && c1 != kEntryDone;
+            h[0] = fmaxf(e[0], 0.f) <= fminf(t_out.x, tmax_w);
+            h[1] = fmaxf(e[1], 0.f) <= fminf(t_out.y, tmax_w);
         }
         {
             v2f ax = (v2f{r0.x, r0.y} - ox) * ix, ay = (v2f{r0.z, r0.w} - oy) * iy, az = (v2f{r1.x, r1.y} - oz) * iz;
@@ -866,8 +900,8 @@ __device__ __forceinline__ void inner_step(const DScene &sc, V3 o, V3 inv, float
             v2f t_out = {fminf(fminf(fmaxf(ax.x, bx.x), fmaxf(ay.x, by.x)), fmaxf(az.x, bz.x)),
                          fminf(fminf(fmaxf(ax.y, bx.y), fmaxf(ay.y, by.y)), fmaxf(az.y, bz.y))};
             t_out = t_out * v2f{1.000001f, 1.000001f};
-            h[2] = e[2] <= t_out.x && t_out.x >= 0.f && e[2] <= tmax_w && c2 != kEntryDone;
-            h[3] = e[3] <= t_out.y && t_out.y >= 0.f && e[3] <= tmax_w && c3 != kEntryDone;
+            h[2] = fmaxf(e[2], 0.f) <= fminf(t_out.x, tmax_w);
+            h[3] = fmaxf(e[3], 0.f) <= fminf(t_out.y, tmax_w);
         }
         // nearest entered child (a child that is not entered counts as infinitely far)
         const float f0 = h[0] ? e[0] : kFltMax, f1 = h[1] ? e[1] : kFltMax, f2 = h[2] ? e[2] : kFltMax, f3 = h[3] ? e[3] : kFltMax;
@@ -877,17 +911,17 @@ __device__ __forceinline__ void inner_step(const DScene &sc, V3 o, V3 inv, float
         const int near_k = first ? (a01 ? 0 : 1) : (a23 ? 2 : 3);
         const int near_link = first ? (a01 ? c0 : c1) : (a23 ? c2 : c3);
         const bool any_hit = h[0] || h[1] || h[2] || h[3];
-        int popped = sp > 0 ? spec_top : kEntryDone;
+        int spec = spec_top;
+        __asm__ volatile("" : "+v"(spec));  // the read stays where it was issued: the compiler otherwise sinks it into a branch
+        int popped = sp > 0 ? spec : kEntryDone;
         if (!any_hit && sp > stack_cap) {
             popped = over[(size_t)(sp - 1 - stack_cap) * kOverStride];
             __asm__ volatile("" ::: "memory");
         }
         cur = any_hit ? near_link : popped;
         sp -= (!any_hit && sp > 0) ? 1 : 0;
-        if (h[0] && near_k != 0) stack_push(stack, over, sp, stack_cap, c0);
-        if (h[1] && near_k != 1) stack_push(stack, over, sp, stack_cap, c1);
-        if (h[2] && near_k != 2) stack_push(stack, over, sp, stack_cap, c2);
-        if (h[3] && near_k != 3) stack_push(stack, over, sp, stack_cap, c3);
+        push_if4(stack, over, sp, stack_cap, c0, h[0] && near_k != 0, c1, h[1] && near_k != 1, c2, h[2] && near_k != 2, c3,
+                 h[3] && near_k != 3);
     }
 }
 
@@ -911,13 +945,13 @@ struct TraceParams {
 // (closest hit, ch()) and the shadow ray of every slot that spawned one (any hit, ah()).  A lane
 // carries its kind with its ray, so closest-hit and any-hit rays share waves; the two kinds differ
 // only in what a triangle hit does and in how the finished ray is finalised.
-// LDS layout (dynamic): [stack: stack_cap x kBlock ints][pending: kBlock ints]
+// LDS layout (dynamic): [stack: (stack_cap + 1) x kBlock ints (push_if)][pending: kBlock ints]
 template <int MODE, bool WIDE>
 __global__ void __launch_bounds__(kBlock, 8) k_trace(DScene sc, DPools p, TraceParams tp, int stack_cap, int *overflow) {
     extern __shared__ int s_lds[];
     int *stack = s_lds + threadIdx.x;
     int *over = overflow + (blockIdx.x * kBlock + threadIdx.x);
-    volatile int *pend = s_lds + stack_cap * kBlock + (threadIdx.x & ~63);  // this wave's 64 entries
+    volatile int *pend = s_lds + (stack_cap + 1) * kBlock + (threadIdx.x & ~63);  // this wave's 64 entries
     const int total = tp.total;
     const int n_chunks = (total + 63) >> 6;                            // chunks per ray kind
     const int all_chunks = MODE == MODE_POOL ? 2 * n_chunks : n_chunks;  // [closest chunks][any chunks]
@@ -1157,6 +1191,18 @@ constexpr int kNodePerStep = RT_NODE_PER_STEP;  // node steps a lane makes per s
 #define RT_NODE_PER_STEP_WIDE 2
 #endif
 constexpr int kNodePerStepWide = RT_NODE_PER_STEP_WIDE;  // ... with 4-wide nodes (measured: 3 649 / 3 620 / 3 539 / 3 391 Msamples/s at 2 / 3 / 4 / 5)
+// 4-wide node blocks are adaptive: kNodePerStepWide steps for every lane that has one to make, then -- if at least
+// kNodeCont lanes of the wave still do -- up to kNodeExtra more (a wave-uniform branch).  Measured on the four BASELINE
+// scenes against fixed 2 / 3 / 4 / 5 steps: fixed 4 is 8 % faster on the sixteen-light scene (its shadow rays make
+// 4.8 node steps against 2.2 in C2) and 5 % slower on the matte scene; 2 + 2 at >= 36 lanes is at least as fast as
+// fixed 2 on all four.  A `do ... while (enough lanes)` loop that is not unrolled loses 1 %.
+#ifndef RT_NODE_CONT
+#define RT_NODE_CONT 36
+#endif
+#ifndef RT_NODE_EXTRA
+#define RT_NODE_EXTRA 2
+#endif
+constexpr int kNodeCont = RT_NODE_CONT, kNodeExtra = RT_NODE_EXTRA;
 #ifndef RT_SPECULATE
 #define RT_SPECULATE 1
 #endif
@@ -1167,7 +1213,7 @@ constexpr bool kSpeculate = RT_SPECULATE != 0;  // k_paths: postpone a leaf reac
 // beta = 12 dwords) lives in the lane's LDS column and is only in registers inside the ADV block;
 // while a shadow ray is traced, the slot's path ray and the radiance to deposit wait in 9 more
 // dwords of LDS; the hit record is rebuilt from (tri, hu, hv) inside the ADV block.
-// LDS layout (dynamic): [stack: stack_cap x kBlock][parked ray: 9 x kBlock][slot state: 12 + 1 x kBlock][sample sum: 3 x kBlock][tables]
+// LDS layout (dynamic): [stack: (stack_cap + 1) x kBlock (push_if)][parked ray: 9 x kBlock][slot state: 12 + 1 x kBlock][sample sum: 3 x kBlock][tables]
 template <bool LDS_TABLES, bool WIDE, bool MAJORITY, int MIN_WAVES>
 __global__ void __launch_bounds__(kBlock, MIN_WAVES)
 k_paths(DScene sc, DPools p, Camera cam_arg, AdvanceParams ap_arg, float *__restrict__ fb, DWaveRow *__restrict__ rows,
@@ -1179,11 +1225,11 @@ k_paths(DScene sc, DPools p, Camera cam_arg, AdvanceParams ap_arg, float *__rest
     constexpr bool SPLIT_GEN = MIN_WAVES != 2;
     extern __shared__ int s_lds[];
     int *stack = s_lds + threadIdx.x;
-    float *park = (float *)(s_lds + stack_cap * kBlock) + threadIdx.x;  // element k at park[k * kBlock]
+    float *park = (float *)(s_lds + (stack_cap + 1) * kBlock) + threadIdx.x;  // element k at park[k * kBlock]
     int *over = overflow + (blockIdx.x * kBlock + threadIdx.x) % kOverStride;
-    int *cold = s_lds + (stack_cap + 9) * kBlock + threadIdx.x;  // element k at cold[k * kBlock]
-    float *acc = (float *)(s_lds + (stack_cap + 22) * kBlock) + threadIdx.x;  // sample accumulator (acc_add / acc_flush)
-    float *s_tab = (float *)(s_lds + (stack_cap + 25) * kBlock);
+    int *cold = s_lds + (stack_cap + 10) * kBlock + threadIdx.x;  // element k at cold[k * kBlock]
+    float *acc = (float *)(s_lds + (stack_cap + 23) * kBlock) + threadIdx.x;  // sample accumulator (acc_add / acc_flush)
+    float *s_tab = (float *)(s_lds + (stack_cap + 26) * kBlock);
     const float *tab = sc.tables;
     // small shards (MIN_WAVES == 2: at most 2 workgroups per CU, LDS to spare, latency-bound): the top of
     // the BVH is staged in LDS, so the first levels of every traversal do not leave the CU
@@ -1533,13 +1579,31 @@ k_paths(DScene sc, DPools p, Camera cam_arg, AdvanceParams ap_arg, float *__rest
             if (want_node) {
                 // a bounded while-while: up to kNodePerStep consecutive node steps (2 triangle tests in the
                 // triangle block) per scheduling decision -- measured best at 8 / 2 (+22 % over 1 / 1; 4 / 2: +20 %)
+                if (kNodeCont == 0 || !WIDE) {
 #pragma unroll
-                for (int rep = 0; rep < (WIDE ? kNodePerStepWide : kNodePerStep); rep++) {
-                    if (cur >= 0) {
-                        inner_step<WIDE>(sc, o, inv, tmax, cur, sp, stack, over, stack_cap, s_top, top_n);
-                    } else if (kSpeculate && cur != kEntryDone && pend == kEntryDone && sp > 0) {
-                        pend = cur;  // a leaf: set it aside, go on with the next entry
-                        cur = stack_pop(stack, over, sp, stack_cap);
+                    for (int rep = 0; rep < (WIDE ? kNodePerStepWide : kNodePerStep); rep++) {
+                        if (cur >= 0) {
+                            inner_step<WIDE>(sc, o, inv, tmax, cur, sp, stack, over, stack_cap, s_top, top_n);
+                        } else if (kSpeculate && cur != kEntryDone && pend == kEntryDone && sp > 0) {
+                            pend = cur;  // a leaf: set it aside, go on with the next entry
+                            cur = stack_pop(stack, over, sp, stack_cap);
+                        }
+                    }
+                } else {
+                    // adaptive: the fixed steps, then kNodeExtra more if enough lanes of the wave still have one to make
+                    auto step = [&]() {
+                        if (cur >= 0) {
+                            inner_step<WIDE>(sc, o, inv, tmax, cur, sp, stack, over, stack_cap, s_top, top_n);
+                        } else if (kSpeculate && cur != kEntryDone && pend == kEntryDone && sp > 0) {
+                            pend = cur;
+                            cur = stack_pop(stack, over, sp, stack_cap);
+                        }
+                    };
+#pragma unroll
+                    for (int rep = 0; rep < kNodePerStepWide; rep++) step();
+                    if (wave_count(cur >= 0) >= kNodeCont) {
+#pragma unroll
+                        for (int rep = 0; rep < kNodeExtra; rep++) step();
                     }
                 }
             }
@@ -2203,7 +2267,7 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
         HIP_TRY(hipStreamSynchronize(st));  // h_ctr[0] is reused as a snapshot slot below
     }
     const int stack_cap = std::min(kLdsStack, std::max(1, scene->stack_bound));
-    const size_t lds_bytes = sizeof(int) * (size_t)kBlock * (size_t)(stack_cap + 1);  // stack + pending
+    const size_t lds_bytes = sizeof(int) * (size_t)kBlock * (size_t)(stack_cap + 2);  // stack (+ 1 row: push_if) + pending
     // one buffer serves the context's k_trace and k_paths grids (never in flight together); k_paths keeps fewer
     // entries in LDS, so it needs the deeper overflow
     if (ensure_overflow(c.d_over, c.over_levels, scene->stack_bound - std::min(stack_cap, std::min(8, std::max(1, scene->stack_bound))))) return 1;
@@ -2299,7 +2363,7 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
         if (const char *e = getenv("RT_ADV_BATCH")) adv_batch = std::max(1, std::min(64, atoi(e)));
         const int paths_cap = std::min(8, std::max(1, scene->stack_bound));
         int *const d_over2 = d_over;
-        size_t lds_paths = sizeof(int) * (size_t)kBlock * (size_t)(paths_cap + 25) + (lds_tables ? sizeof(float) * (size_t)((scene->tab_dwords + 3) & ~3) : 0) +
+        size_t lds_paths = sizeof(int) * (size_t)kBlock * (size_t)(paths_cap + 26) + (lds_tables ? sizeof(float) * (size_t)((scene->tab_dwords + 3) & ~3) : 0) +
                            sizeof(Camera) + sizeof(AdvanceParams);
         bool majority = true;
         if (const char *e = getenv("RT_MAJORITY")) majority = atoi(e) != 0;
@@ -2915,7 +2979,7 @@ int rt_trace_closest(const rt_scene *scene, int n, const float *origin_xyz, cons
         tp.out_u = d_u;
         tp.out_v = d_v;
         DPools none{};
-        RT_LAUNCH_TRACE(MODE_TEST_CLOSEST, scene->wide, dim3(test_grid), sizeof(int) * kBlock * (size_t)(stack_cap + 1), nullptr,
+        RT_LAUNCH_TRACE(MODE_TEST_CLOSEST, scene->wide, dim3(test_grid), sizeof(int) * kBlock * (size_t)(stack_cap + 2), nullptr,
                         scene->dev(), none, tp, stack_cap, d_over);
     }
     HIP_TRY(hipGetLastError());
@@ -2963,7 +3027,7 @@ int rt_trace_any(const rt_scene *scene, int n, const float *origin_xyz, const fl
         tp.excluded = d_e;
         tp.out_i = d_occ;
         DPools none{};
-        RT_LAUNCH_TRACE(MODE_TEST_ANY, scene->wide, dim3(test_grid), sizeof(int) * kBlock * (size_t)(stack_cap + 1), nullptr,
+        RT_LAUNCH_TRACE(MODE_TEST_ANY, scene->wide, dim3(test_grid), sizeof(int) * kBlock * (size_t)(stack_cap + 2), nullptr,
                         scene->dev(), none, tp, stack_cap, d_over);
     }
     HIP_TRY(hipGetLastError());

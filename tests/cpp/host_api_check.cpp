@@ -122,6 +122,21 @@ static int unit() {
     return 0;
 }
 
+// the recipe's stage lines (profiler.hpp) on stdout, then one explicit stage and a scope guard
+int stages(const std::string &ply) {
+    rtcuda::CornellBunny cb(ply, rtcuda::CornellBunny::MATTE, true);
+    profiler.start("Explicit stage");
+    profiler.stop();
+    {
+        Profiler::Stage s(profiler, "Scoped stage");
+    }
+    profiler.enabled = false;
+    profiler.start("Silent stage");
+    profiler.stop();
+    printf("triangles=%zu last_ms_ok=%d\n", cb.triangles().size(), profiler.last_ms >= 0.f ? 1 : 0);
+    return 0;
+}
+
 // never called without a GPU: proves that the render path of the API compiles and links against the library
 int render_smoke(const std::string &ply) {
     rtcuda::CornellBunny cb(ply);
@@ -136,6 +151,7 @@ int main(int argc, char **argv) {
         if (mode == "dump" && argc == 5) return dump(argv[2], argv[3], argv[4]);
         if (mode == "ply" && argc == 4) return ply(argv[2], argv[3]);
         if (mode == "unit") return unit();
+        if (mode == "stages" && argc == 3) return stages(argv[2]);
         if (mode == "render" && argc == 3) return render_smoke(argv[2]) > 0 ? 0 : 1;
         fprintf(stderr, "usage: host_api_check dump <variant> <ply|-> <out> | ply <in> <out> | unit | render <ply>\n");
         return 64;

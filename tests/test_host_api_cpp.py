@@ -185,6 +185,18 @@ def test_cpp_vec3_matrix_transform_known_answers(exe):
     assert got["point_light"] == [0.0, 1.0]
 
 
+def test_stage_lines_have_the_reference_drivers_format(exe):
+    """profiler.hpp:14-28 prints "<name>... done (<ms>ms)"; the recipe prints the driver's three bunny stages
+    (main.cu:59-85) in that format when asked to, and nothing when not."""
+    import re
+    out = subprocess.check_output([exe, "stages", PLY], text=True).splitlines()
+    stage = re.compile(r"^(.+)\.\.\. done \(([0-9.eE+-]+)ms\)$")
+    names = [stage.match(ln).group(1) for ln in out if stage.match(ln)]
+    assert names == ["Reading bunny", "Transforming bunny", "Converting bunny to triangles", "Explicit stage", "Scoped stage"]
+    assert out[1] == "35947 vertices, 69451 faces"  # (the count line the driver prints after reading: main.cu:63)
+    assert out[-1] == "triangles=69463 last_ms_ok=1" and not any("Silent" in ln for ln in out)
+
+
 def test_reference_driver_lines_compile_against_the_headers(tmp_path):
     """A driver written the way main.cu is -- happly::PLYData, Transform, Vec3 arithmetic, Material / Light /
     Primitive / Bvh / Scene / Camera / render() -- compiles (syntax-only: no GPU, no link) against include/."""
