@@ -807,13 +807,19 @@ __device__ __forceinline__ void inner_step(const DScene &sc, V3 o, V3 inv, float
                                            int *over, int stack_cap, const float4 *top = nullptr, int top_n = 0) {
     // (2-wide records) the top of the LDS part of the stack, in case this step ends in a pop: see below
     const int spec_top = stack[max(min(sp - 1, stack_cap - 1), 0) * kBlock];
-    float4 q0, q1, q2, q3;
+    float4 q0, q1, q2, q3, r0, r1, r2, r3;  // (r*: the second record of a 4-wide node)
     if (top_n > 0 && cur < top_n) {
         const float4 *q = top + 4 * cur;
         q0 = q[0];
         q1 = q[1];
         q2 = q[2];
         q3 = q[3];
+        if (WIDE) {
+            r0 = q[4];
+            r1 = q[5];
+            r2 = q[6];
+            r3 = q[7];
+        }
         // keeps the two branches apart: merged into a select of pointers they become FLAT loads, which go
         // through the texture addresser like any global load and make the LDS copy pointless
         __asm__ volatile("" ::: "memory");
@@ -823,6 +829,12 @@ __device__ __forceinline__ void inner_step(const DScene &sc, V3 o, V3 inv, float
         q1 = q[1];
         q2 = q[2];
         q3 = q[3];
+        if (WIDE) {
+            r0 = q[4];
+            r1 = q[5];
+            r2 = q[6];
+            r3 = q[7];
+        }
     }
     if (!WIDE) {
         // 2-wide record: two exact boxes, near child first, far child onto the stack.  The bounds of the two
@@ -869,8 +881,6 @@ __device__ __forceinline__ void inner_step(const DScene &sc, V3 o, V3 inv, float
         // dependent fetches of the 2-wide walk for the same box arithmetic.  The nearest child the ray may enter becomes
         // the cursor, the others go onto the stack in record order (measured on the CPU walk: sorting them as well
         // saves 0.3 % of the steps), nothing entered -> the speculative top of the stack.
-        const float4 *qb = (const float4 *)((const char *)sc.nodes + ((unsigned)cur << 6)) + 4;
-        const float4 r0 = qb[0], r1 = qb[1], r2 = qb[2], r3 = qb[3];
         const int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y), c2 = __float_as_int(r3.x), c3 = __float_as_int(r3.y);
         const v2f ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z};
         const v2f ix = {inv.x, inv.x}, iy = {inv.y, inv.y}, iz = {inv.z, inv.z};
@@ -2359,8 +2369,6 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
     if (const char *e = getenv("RT_PERSISTENT")) persistent = atoi(e) != 0;
     float ms_paths = 0.f;
     if (persistent) {
-        int adv_batch = 30;  // lanes waiting for the ADV block before it runs (measured: flat 28..36)
-        if (const char *e = getenv("RT_ADV_BATCH")) adv_batch = std::max(1, std::min(64, atoi(e)));
         const int paths_cap = std::min(8, std::max(1, scene->stack_bound));
         int *const d_over2 = d_over;
         size_t lds_paths = sizeof(int) * (size_t)kBlock * (size_t)(paths_cap + 26) + (lds_tables ? sizeof(float) * (size_t)((scene->tab_dwords + 3) & ~3) : 0) +
@@ -2387,13 +2395,21 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
         const bool few_blocks = paths_blocks <= 2 * dev_cus_paths;
         int top_n = 0;
         if (few_blocks) {
-            top_n = scene->top_prefix ? std::min(384, std::min(scene->n_nodes, (int)rtbvh::kTopPrefix)) : 0;  // < 64 KB of LDS
-            if (const char *e = getenv("RT_TOP_NODES"))
-                top_n = scene->top_prefix ? std::max(0, std::min(std::min(768, atoi(e)), std::min(scene->n_nodes, (int)rtbvh::kTopPrefix))) : 0;
+            // records of the top of the tree kept in LDS (within the 64 KB of dynamic LDS a launch gets without further
+            // ado, ~36 KB of it slot state): 384 records of the binary tree.  For the 4-wide tree the copy buys nothing
+            // (1/8 shard of C2: 2 013 / 2 017 / 2 016 / 2 015 Msamples/s with 0 / 64 / 128 / 224 nodes in LDS -- the
+            // first levels are L2 hits the two waves' other work hides), so it is off unless RT_TOP_NODES asks for it
+            const int prefix = std::min(scene->n_nodes, (int)rtbvh::kTopPrefix * (scene->wide ? 2 : 1));
+            top_n = scene->top_prefix ? std::min(scene->wide ? 0 : 384, prefix) : 0;
+            if (const char *e = getenv("RT_TOP_NODES")) top_n = scene->top_prefix ? std::max(0, std::min(std::min(768, atoi(e)), prefix)) : 0;
+            if (scene->wide) top_n &= ~1;  // whole nodes
             lds_paths += (size_t)top_n * 64;
         }
-        if (scene->wide) top_n = 0;  // (the LDS copy of the top of the tree exists for 2-wide records only)
-        int gen_batch = 6;  // lanes waiting for the GEN block before it runs (unless nothing else can); flat 5..8
+        // lanes waiting for the ADV block before it runs: full pool flat 22..26 on the 4-wide tree (24 + GEN 8: +1.5 % over
+        // 30 + 6), the 2-waves-per-SIMD shards want 30 (24: -2.5 %)
+        int adv_batch = few_blocks ? 30 : 24;
+        if (const char *e = getenv("RT_ADV_BATCH")) adv_batch = std::max(1, std::min(64, atoi(e)));
+        int gen_batch = 8;  // lanes waiting for the GEN block before it runs (unless nothing else can); flat 6..10
         if (const char *e = getenv("RT_GEN_BATCH")) gen_batch = std::max(1, std::min(64, atoi(e)));
         int prio_rotate = 8;  // log2 of the priority-rotation period in scheduling decisions; 0 = off
         // period, in 64-slot blocks, after which slots repeat the same pixel-column lattice (see k_paths)
