@@ -2406,8 +2406,8 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
             lds_paths += (size_t)top_n * 64;
         }
         // lanes waiting for the ADV block before it runs: full pool flat 22..26 on the 4-wide tree (24 + GEN 8: +1.5 % over
-        // 30 + 6), the 2-waves-per-SIMD shards want 30 (24: -2.5 %)
-        int adv_batch = few_blocks ? 30 : 24;
+        // 30 + 6), the 2-waves-per-SIMD shards want 30..38 (24: -2.5 %)
+        int adv_batch = few_blocks ? 34 : 24;
         if (const char *e = getenv("RT_ADV_BATCH")) adv_batch = std::max(1, std::min(64, atoi(e)));
         int gen_batch = 8;  // lanes waiting for the GEN block before it runs (unless nothing else can); flat 6..10
         if (const char *e = getenv("RT_GEN_BATCH")) gen_batch = std::max(1, std::min(64, atoi(e)));
