@@ -2185,6 +2185,14 @@ int get_context(int n, int lane, Context **out) {
 
 int grid_for(int n) { return (n + kBlock - 1) / kBlock; }
 
+// Entries of a lane's traversal stack kept in LDS (the rest of scene->stack_bound goes to the global overflow column).
+// RT_STACK_CAP lowers it: a test knob that drives every traversal through the overflow path.
+static int lds_stack_cap(const rt_scene *scene, int limit) {
+    int cap = std::min(limit, std::max(1, scene->stack_bound));
+    if (const char *e = getenv("RT_STACK_CAP")) cap = std::max(1, std::min(cap, atoi(e)));
+    return cap;
+}
+
 // launches k_trace<MODE, wide?> -- the node format is a property of the scene
 #define RT_LAUNCH_TRACE(MODE, wide, grid, lds, stream, ...)                                                \
     do {                                                                                                   \
@@ -2276,11 +2284,11 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
         HIP_TRY(hipMemsetAsync(c.d_rows, 0, sizeof(DWaveRow) * (size_t)c.n_rows, st));
         HIP_TRY(hipStreamSynchronize(st));  // h_ctr[0] is reused as a snapshot slot below
     }
-    const int stack_cap = std::min(kLdsStack, std::max(1, scene->stack_bound));
+    const int stack_cap = lds_stack_cap(scene, kLdsStack);
     const size_t lds_bytes = sizeof(int) * (size_t)kBlock * (size_t)(stack_cap + 2);  // stack (+ 1 row: push_if) + pending
     // one buffer serves the context's k_trace and k_paths grids (never in flight together); k_paths keeps fewer
     // entries in LDS, so it needs the deeper overflow
-    if (ensure_overflow(c.d_over, c.over_levels, scene->stack_bound - std::min(stack_cap, std::min(8, std::max(1, scene->stack_bound))))) return 1;
+    if (ensure_overflow(c.d_over, c.over_levels, scene->stack_bound - std::min(stack_cap, lds_stack_cap(scene, 8)))) return 1;
     int *const d_over = c.d_over;
     hipLaunchKernelGGL(k_pool_init, dim3(grid_for(n)), dim3(kBlock), 0, st, c.pools, n, max_bounces);
     HIP_TRY(hipGetLastError());
@@ -2369,7 +2377,7 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
     if (const char *e = getenv("RT_PERSISTENT")) persistent = atoi(e) != 0;
     float ms_paths = 0.f;
     if (persistent) {
-        const int paths_cap = std::min(8, std::max(1, scene->stack_bound));
+        const int paths_cap = lds_stack_cap(scene, 8);
         int *const d_over2 = d_over;
         size_t lds_paths = sizeof(int) * (size_t)kBlock * (size_t)(paths_cap + 26) + (lds_tables ? sizeof(float) * (size_t)((scene->tab_dwords + 3) & ~3) : 0) +
                            sizeof(Camera) + sizeof(AdvanceParams);
@@ -2979,7 +2987,7 @@ int rt_trace_closest(const rt_scene *scene, int n, const float *origin_xyz, cons
     HIP_TRY(hipMemcpy(d_d, dir_xyz, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d_tm, tmax, sizeof(float) * (size_t)n, hipMemcpyHostToDevice));
     const int test_grid = std::min(grid_for(n), 2048);
-    const int stack_cap = std::min(kLdsStack, std::max(1, scene->stack_bound));
+    const int stack_cap = lds_stack_cap(scene, kLdsStack);
     int *d_over = nullptr;
     int over_levels = 0;
     if (ensure_overflow(d_over, over_levels, scene->stack_bound - stack_cap)) return 1;
@@ -3030,7 +3038,7 @@ int rt_trace_any(const rt_scene *scene, int n, const float *origin_xyz, const fl
     HIP_TRY(hipMemcpy(d_tm, tmax, sizeof(float) * (size_t)n, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d_e, excl.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice));
     const int test_grid = std::min(grid_for(n), 2048);
-    const int stack_cap = std::min(kLdsStack, std::max(1, scene->stack_bound));
+    const int stack_cap = lds_stack_cap(scene, kLdsStack);
     int *d_over = nullptr;
     int over_levels = 0;
     if (ensure_overflow(d_over, over_levels, scene->stack_bound - stack_cap)) return 1;

@@ -244,6 +244,29 @@ def test_concurrent_sub_shards_keep_their_own_overflow_stacks(api, oracle, monke
     assert _rms(img_1, img_2).max() < 2e-6
 
 
+def test_overflow_stack_path_gives_the_same_frame(api, oracle, monkeypatch):
+    """RT_STACK_CAP=2 leaves two traversal-stack entries per lane in LDS, so nearly every push and pop of the 4-wide walk
+    (up to three pushes per node step, stored without a branch: push_if4) goes through the global overflow column --
+    in the persistent kernel, in the lockstep rounds and in the stage-level trace.  Same events, same image."""
+    w, h, spp = 400, 300, 20
+    for variant in ("full_bsdf", "four_bunnies"):
+        gpu, cpu = _scenes(api, oracle, variant)
+        cam = api.make_camera(aspect=w / h)
+        img_1, st_1 = gpu.render(cam, w, h, spp)
+        monkeypatch.setenv("RT_STACK_CAP", "2")
+        img_2, st_2 = gpu.render(cam, w, h, spp)
+        monkeypatch.setenv("RT_BVH_WIDE", "0")  # (a new scene: the binary tree through the same two entries)
+        from rtcuda_amd import scenes
+        gpu_b = api.Scene(scenes.cornell_bunny(variant))
+        img_3, st_3 = gpu_b.render(cam, w, h, spp)
+        gpu_b.close()
+        monkeypatch.delenv("RT_BVH_WIDE")
+        monkeypatch.delenv("RT_STACK_CAP")
+        for k in ("camera_rays", "shade_events", "closest_rays", "any_rays", "emission_adds", "shadow_adds", "rr_draws"):
+            assert st_1[k] == st_2[k] == st_3[k], (variant, k)
+        assert _rms(img_1, img_2).max() < 2e-6 and _rms(img_1, img_3).max() < 2e-6
+
+
 GOLDEN = np.load(os.path.join(os.path.dirname(__file__), "golden", "render_goldens.npz"))
 
 
