@@ -2051,6 +2051,52 @@ bool validate_pairs(const std::vector<rtbvh::Pair> &pairs, int n_tris) {
     return visited == np && tris == n_tris;
 }
 
+// The same for the 4-wide format (two consecutive records per node; inner links are even record indices), plus the
+// invariant the kernels' box test rests on: a child is absent (link kNoChild) if and only if its box is all +inf -- the
+// one-comparison slab test of inner_step<true> never looks at links.
+bool validate_quads(const std::vector<rtbvh::Pair> &quads, int n_tris) {
+    const int nr = (int)quads.size();
+    if (nr < 2 || (nr & 1)) return false;
+    std::vector<char> seen_node((size_t)nr / 2, 0), seen_tri((size_t)std::max(n_tris, 1), 0);
+    std::vector<int> todo{0};
+    seen_node[0] = 1;
+    int visited = 0, tris = 0;
+    while (!todo.empty()) {
+        const int rec = todo.back();
+        todo.pop_back();
+        visited++;
+        for (int k = 0; k < 4; k++) {
+            const rtbvh::Pair &p = quads[(size_t)rec + (k >> 1)];
+            const int l = (k & 1) ? p.rlink : p.llink;
+            const float *b = (k & 1) ? p.rbox : p.lbox;
+            bool all_inf = true, finite = true;
+            for (int a = 0; a < 6; a++) {
+                all_inf = all_inf && b[a] == INFINITY;
+                finite = finite && std::isfinite(b[a]);
+            }
+            if (l == rtbvh::kNoChild) {
+                if (!all_inf) return false;
+                continue;
+            }
+            if (!finite || b[0] > b[3] || b[1] > b[4] || b[2] > b[5]) return false;
+            if (l >= 0) {
+                if ((l & 1) || l >= nr || seen_node[l / 2]) return false;
+                seen_node[l / 2] = 1;
+                todo.push_back(l);
+            } else {
+                const int ref = ~l, first = ref >> 3, count = ref & 7;
+                if (count <= 0 || first < 0 || first + count > n_tris) return false;
+                for (int t = first; t < first + count; t++) {
+                    if (seen_tri[t]) return false;
+                    seen_tri[t] = 1;
+                    tris++;
+                }
+            }
+        }
+    }
+    return visited == nr / 2 && tris == n_tris;
+}
+
 // Device LBVH build: returns the pair records and the leaf order on the host (the caller uploads them
 // like the host builder's output).  n >= 2.
 int build_lbvh_device(const float *verts_host, int n, std::vector<rtbvh::Pair> &pairs, std::vector<int32_t> &order,
@@ -2734,6 +2780,8 @@ int rt_scene_create(const float *tri_p0p1p2, int n_tris, const int32_t *tri_mate
         sc->build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     }
     if (!bvh.ok) return fail("rt_scene_create: BVH build produced an unreferenceable leaf");
+    if (sc->builder == 0 && n_tris > 0 && !validate_quads(bvh.quads, n_tris))
+        return fail("rt_scene_create: the 4-wide BVH is malformed (structure, or an absent child without its +inf box)");
     if ((sc->builder == 1 ? bvh.pair_depth + 1 : bvh.stack_bound) > kMaxStackBound)
         return fail("rt_scene_create: BVH depth " + std::to_string(bvh.max_depth) + " exceeds the traversal stack");
     sc->n_tris = n_tris;
