@@ -1628,43 +1628,44 @@ k_paths(DScene sc, DPools p, Camera cam_arg, AdvanceParams ap_arg, float *__rest
             const unsigned long long pf_tt = __builtin_readcyclecounter();
 #endif
             if (want_tri) {
+                // Straight-line bookkeeping: every outcome of a test is a select, not a branch (the merges of the branchy
+                // version cost the wave ~30 register moves per test: +1.1 % frame rate), the only branches left are the
+                // rare ones (a tie between two hits; a pop from the overflow column).  kTriPerStep tests per block also
+                // without MAJORITY.
                 bool stop = false;
-                int reps = 0;
-                do {
+#pragma unroll
+                for (int reps = 0; reps < kTriPerStep; reps++) {
+                    const bool leaf_cur = cur != kEntryDone && cur < 0;
                     const bool from_pend = kSpeculate && pend != kEntryDone;  // the postponed leaf first
-                    int ref = ~(from_pend ? pend : cur);
-                    int k = ref >> 3, count = ref & 7;
-                    Tri tr = load_tri(sc.tris, k);
-                    float t, u, v;
-                    if (tri_intersect(tr, o, d, tmax, t, u, v)) {
-                        if (is_any) {
-                            if (k != tri) {  // bvh.cuh:243: first accepted hit that is not the excluded triangle
-                                hu = 1.f;
-                                stop = true;
-                            }
-                        } else if (closest_hit_wins(sc, t, tmax, k, tri)) {  // bvh.cuh:227-231 (t <= tmax)
-                            tmax = t;
-                            hu = u;
-                            hv = v;
-                            tri = k;
-                        }
+                    const bool active = !stop && (leaf_cur || from_pend);
+                    if (active) {
+                        const int enc = from_pend ? pend : cur;  // ~((first << 3) | count)
+                        const int ref = ~enc;
+                        const int k = ref >> 3;
+                        const bool more = (ref & 7) > 1;
+                        Tri tr = load_tri(sc.tris, k);
+                        float t, u, v;
+                        const bool hit = tri_intersect(tr, o, d, tmax, t, u, v);
+                        // any-hit: the first accepted hit that is not the excluded triangle (bvh.cuh:243);
+                        // closest-hit: bvh.cuh:227-231 (t <= tmax), ties by closest_hit_wins
+                        const bool occluded = hit && is_any && k != tri;
+                        bool better = hit && !is_any;
+                        if (better && t == tmax && tri >= 0) better = sc.order[(unsigned)k] > sc.order[(unsigned)tri];
+                        tmax = better ? t : tmax;
+                        hu = occluded ? 1.f : (better ? u : hu);
+                        hv = better ? v : hv;
+                        tri = better ? k : tri;
+                        stop = occluded;
+                        // what this lane looks at next: the rest of the leaf (one triangle further: first + 1, count - 1 is
+                        // enc - 7), or -- when the leaf under the cursor is used up -- the next stack entry
+                        const int rest = more ? enc - 7 : kEntryDone;
+                        const bool pop = !occluded && !from_pend && !more;
+                        int popped = kEntryDone;
+                        if (pop && sp > 0) popped = stack_pop(stack, over, sp, stack_cap);
+                        pend = occluded ? kEntryDone : (from_pend ? rest : pend);
+                        cur = occluded ? kEntryDone : (from_pend ? cur : (more ? rest : popped));
                     }
-                    if (stop) {
-                        cur = kEntryDone;
-                        pend = kEntryDone;
-                    } else if (from_pend) {
-                        pend = count > 1 ? leaf_ref(k + 1, count - 1) : kEntryDone;
-                    } else if (count > 1) {
-                        cur = leaf_ref(k + 1, count - 1);
-                    } else if (sp > 0) {
-                        cur = stack_pop(stack, over, sp, stack_cap);
-                    } else {
-                        cur = kEntryDone;
-                    }
-                    reps++;
-                    // MAJORITY: kTriPerStep triangles per step; otherwise the whole leaf (and chained leaves) now
-                } while ((!MAJORITY || reps < kTriPerStep) && !stop &&
-                         ((cur != kEntryDone && cur < 0) || (kSpeculate && pend != kEntryDone)));
+                }
             }
 #ifdef RT_TRACE_PROFILE
             pf[10] += __builtin_readcyclecounter() - pf_tt;
