@@ -1344,12 +1344,33 @@ k_paths(DScene sc, DPools p, Camera cam_arg, AdvanceParams ap_arg, float *__rest
         beta = mk(__int_as_float(cold[9 * kBlock]), __int_as_float(cold[10 * kBlock]), __int_as_float(cold[11 * kBlock]));
     };
     int phase = PH_IDLE;
+    int tri = -1;
     // the ray being traced, and the traversal cursor (`tri`: best hit so far / excluded triangle;
     // `hu` doubles as the occluded flag of a shadow ray, exactly as in k_trace).  Between the end of
     // a closest-hit trace and the ADV block, (tri, hu, hv, d) ARE the hit record.
     V3 o = mk(0, 0, 0), d = mk(0, 0, 0), inv = mk(0, 0, 0);
     float tmax = 0.f, hu = 0.f, hv = 0.f;
-    int cur = kEntryDone, sp = 0, tri = -1;
+    int cur = kEntryDone, sp = 0;
+    // hand a slot that has no camera ray left (or is parked for the lockstep final generation) back to the pools and take
+    // the lane's next one; `first_phase`: what an untouched slot does first (its bounces = INT_MAX makes that a gen())
+    auto next_slot = [&](int first_phase) {
+        cold_load();
+        store_slot(i);
+        phase = PH_IDLE;
+        tri = -1;
+        slot_set++;
+        i = slot_of(slot_set);
+        if (i < ap_n) {
+            load_slot(i);
+            if (bounces != kDone && bounces != kParked) {
+                phase = first_phase;
+                cold_save();
+                cold[12 * kBlock] = -1;
+            } else {
+                i = ap_n;  // (cannot happen: untouched slots start alive)
+            }
+        }
+    };
     // Speculative traversal (kSpeculate): a lane that reaches a leaf inside a node block does not stop there -- it sets
     // the leaf aside in `pend` and goes on with the next stack entry, so the up-to-8 node steps of a block are used by
     // most lanes to the end (without it half of them idle from the middle of the block on), and the triangle block
@@ -1421,8 +1442,14 @@ k_paths(DScene sc, DPools p, Camera cam_arg, AdvanceParams ap_arg, float *__rest
             pf[12]++; pf[15] += n_genw;
             const unsigned long long pf_tg = __builtin_readcyclecounter();
 #endif
+            // (what the block changes in the lane's loop-carried registers is applied by selects after the divergent part,
+            // and the rare hand-back of a finished slot sits behind a wave-uniform branch: as assignments inside the
+            // branches these cost the wave ~45 register moves per GEN block at the merges)
             AdvanceOut out;
             out.did_gen = out.new_ray = false;
+            out.ray_o = o;
+            out.ray_d = d;
+            bool hand_back = false;
             if (phase == PH_GEN) {
                 SlotState st;
                 st.gen = cold[2 * kBlock];
@@ -1434,46 +1461,37 @@ k_paths(DScene sc, DPools p, Camera cam_arg, AdvanceParams ap_arg, float *__rest
                 int pxy = cold[12 * kBlock];
                 acc_flush(acc, fb, ap_fb_fixed, cold[1 * kBlock]);  // the camera ray that ended: its sum -> its pixel
                 gen_core(cam, ap, ap.slot_lo + i, st, out, &pxy);
+                // the slot state gen() leaves: bounces (0, or the kDone / kParked sentinel), gen, the RNG; a new path also
+                // has its pixel and beta = 1
+                cold[0 * kBlock] = st.bounces;
+                cold[2 * kBlock] = st.gen;
+                cold[3 * kBlock] = (int)st.rs.d;
+                cold[4 * kBlock] = (int)st.rs.v0;
+                cold[5 * kBlock] = (int)st.rs.v1;
+                cold[6 * kBlock] = (int)st.rs.v2;
+                cold[7 * kBlock] = (int)st.rs.v3;
+                cold[8 * kBlock] = (int)st.rs.v4;
                 if (out.new_ray) {
+                    cold[1 * kBlock] = st.pixel;
+                    cold[9 * kBlock] = __float_as_int(st.beta.x);
+                    cold[10 * kBlock] = __float_as_int(st.beta.y);
+                    cold[11 * kBlock] = __float_as_int(st.beta.z);
                     cold[12 * kBlock] = pxy;
-                    o = out.ray_o;
-                    d = out.ray_d;
-                    inv = inv_dir(d);
-                    phase = PH_CLOSEST;
-                    tmax = kFltMax;
-                    tri = -1;
-                    cur = 0;
-                    sp = 0;
-                    bounces = st.bounces;
-                    pixel = st.pixel;
-                    gen = st.gen;
-                    rs = st.rs;
-                    beta = st.beta;
-                    cold_save();
                 } else {
-                    // this slot is out of camera rays (or parked for the lockstep final generation): hand it back
-                    // (beta and pixel are dead there, bounces is the sentinel) and take the lane's next slot
-                    bounces = st.bounces;
-                    pixel = cold[1 * kBlock];
-                    gen = st.gen;
-                    rs = st.rs;
-                    beta = mk(__int_as_float(cold[9 * kBlock]), __int_as_float(cold[10 * kBlock]), __int_as_float(cold[11 * kBlock]));
-                    store_slot(i);
-                    phase = PH_IDLE;
-                    tri = -1;
-                    slot_set++;
-                    i = slot_of(slot_set);
-                    if (i < ap_n) {
-                        load_slot(i);
-                        if (bounces != kDone && bounces != kParked) {
-                            phase = PH_GEN;  // untouched slots start with bounces = INT_MAX: their first step is gen()
-                            cold_save();
-                            cold[12 * kBlock] = -1;
-                        } else {
-                            i = ap_n;  // (cannot happen: untouched slots start alive)
-                        }
-                    }
+                    hand_back = true;  // out of camera rays, or parked for the lockstep final generation
                 }
+            }
+            const bool nr = out.new_ray;
+            o = out.ray_o;
+            d = out.ray_d;
+            inv = inv_dir(d);  // (for every lane, as after the ADV block: the same value for the lanes that keep their ray)
+            phase = nr ? (int)PH_CLOSEST : phase;
+            tmax = nr ? kFltMax : tmax;
+            tri = nr ? -1 : tri;
+            cur = nr ? 0 : cur;
+            sp = nr ? 0 : sp;
+            if (wave_ballot(hand_back)) {  // rare (once per slot and frame): kept out of the merges above
+                if (hand_back) next_slot(PH_GEN);
             }
             n_gen += wave_count((out.did_gen));
             n_traced += wave_count((out.new_ray));
@@ -1541,23 +1559,16 @@ k_paths(DScene sc, DPools p, Camera cam_arg, AdvanceParams ap_arg, float *__rest
                     phase = PH_GEN;  // out.wants_gen: Russian roulette ended the path (its draws are in rs)
                     tri = -1;
                 } else {
-                    // this slot is out of camera rays (or parked for the lockstep final generation):
-                    // hand it back and take the lane's next slot
-                    store_slot(i);
-                    phase = PH_IDLE;
-                    tri = -1;
-                    slot_set++;
-                    i = slot_of(slot_set);
-                    if (i < ap_n) {
-                        load_slot(i);
-                        if (bounces != kDone && bounces != kParked) phase = PH_ADV;
-                        else i = ap_n;  // (cannot happen: untouched slots start alive)
-                    }
+                    // this slot is out of camera rays (or parked for the lockstep final generation)
+                    cold_save();
+                    next_slot(PH_ADV);
                 }
                 if (phase == PH_ANY || phase == PH_CLOSEST) {
                     cur = 0;
                     sp = 0;
                 }
+                // (the same treatment as in the GEN block -- selects after the divergent part -- was measured here and
+                // loses 1 %: the shading block's exits are three-way and the selects outnumber the moves they replace)
                 if (phase != PH_IDLE) cold_save();
             }
             // 1 / d for EVERY lane, also those that only sat through the block: three v_rcp_f32, and 1 / d does not have
