@@ -1430,9 +1430,10 @@ k_paths(DScene sc, DPools p, Camera cam_arg, AdvanceParams ap_arg, float *__rest
         // traversal blocks per iteration (one triangle per lane per iteration).
         bool run_adv = n_adv > 0 && (n_adv >= adv_batch || n_node + n_tri == 0);
         // (MAJORITY: the ADV lanes must also be at least half as many as the node and as the triangle lanes.  Requiring
-        // a full majority measured 1 % slower.  Dropping the condition is as fast in logic, but that source shape
-        // tips the register allocation of this kernel, which sits exactly at 128 VGPRs, into 21 spills: -6 %.
-        // `make resource-usage` after any edit here: "VGPRs Spill" of k_paths<..., 4> must stay 0.)
+        // a full majority measured 1 % slower.  Dropping the condition is as fast in logic, but when the kernel sat
+        // exactly at 128 VGPRs that source shape tipped the register allocation into 21 spills: -6 %.  The kernel has
+        // since come down to 115, but `make resource-usage` after any edit here all the same: "VGPRs Spill" of
+        // k_paths<..., 4> must stay 0 (a CPU test checks it).)
         if (MAJORITY) run_adv = n_adv > 0 && ((n_adv >= adv_batch && 2 * n_adv >= n_node && 2 * n_adv >= n_tri) || n_node + n_tri == 0);
         // ---------------- GEN block: gen() (render.cuh:250-275) for the lanes whose path certainly ended -- it missed
         // or ran out of bounces (a third of all ADV work), or the ADV block found it Russian-roulette-killed to the
@@ -1572,8 +1573,8 @@ k_paths(DScene sc, DPools p, Camera cam_arg, AdvanceParams ap_arg, float *__rest
                 if (phase != PH_IDLE) cold_save();
             }
             // 1 / d for EVERY lane, also those that only sat through the block: three v_rcp_f32, and 1 / d does not have
-            // to stay in registers across the ~1 500 instructions of the block -- those three registers are what
-            // decides between a build with and without spills at 128 VGPRs
+            // to stay in registers across the ~1 100 vector instructions of the block (three registers that decided
+            // between a build with and without spills when the kernel sat at 128 VGPRs)
             inv = inv_dir(d);
             if (!SPLIT_GEN) n_gen += wave_count((out.did_gen));
             n_shade += wave_count((out.did_shade));
@@ -2498,8 +2499,8 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
         }
         if (const char *e = getenv("RT_PRIO_ROTATE")) prio_rotate = atoi(e);
         HIP_TRY(hipEventRecord(c.ev_a, st));
-// MIN_WAVES: 4 waves per SIMD (128 VGPRs, some spills) when the grid fills the chip, 2 (256 VGPRs, no
-        // spills) when the shard is so small that only 2 workgroups per CU exist anyway (8-GPU runs)
+// MIN_WAVES: 4 waves per SIMD (at most 128 VGPRs) when the grid fills the chip, 2 (up to 256 VGPRs) when the
+        // shard is so small that only 2 workgroups per CU exist anyway (8-GPU runs)
 #define RT_LAUNCH_PATHS(T, WD, MJ)                                                                                     \
     do {                                                                                                               \
         if (few_blocks)                                                                                                \

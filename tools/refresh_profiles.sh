@@ -6,8 +6,6 @@ TAG=${1:-r02}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/$TAG
 mkdir -p $O
-timeout -k 10 400 python bench.py > $O/bench_n1.json 2> $O/bench_n1.err
-echo "bench done"; cut -c1-240 $O/bench_n1.json
 bash tools/profile_scene.sh $TAG full_bsdf 256
 bash tools/profile_scene.sh $TAG four_bunnies 256
 bash tools/profile_scene.sh $TAG sixteen_lights 256
@@ -27,3 +25,8 @@ timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VA
 python3 tools/pmc_summary.py $O/valu_pmc > $O/valu_calibration_pmc.json
 rm -rf $O/valu_pmc
 echo "calibration done"
+# the default bench line LAST, after the counters of this binary are in profiles/pmc_k_paths.json (bench.py's roofline
+# divides them by the launch time it measures itself): tools/update_profiles.py works on the box's copy of the repo too
+python3 tools/update_profiles.py $TAG > $O/update_profiles.log 2>&1 || echo "update_profiles failed on the box"
+timeout -k 10 400 python bench.py > $O/bench_n1.json 2> $O/bench_n1.err
+echo "bench done"; cut -c1-240 $O/bench_n1.json
