@@ -586,5 +586,60 @@ inline Result build(const float *verts, int n) {
     return res;
 }
 
+// The 4-wide format from ANY tree of pair records (the device LBVH builder emits `pairs` only): starting at the root,
+// the inner child with the largest surface area is opened until a node has four children; nodes are numbered breadth-
+// first.  Boxes are copied as they are (already padded).  Fills res.quads / max_depth / stack_bound.
+inline void quads_from_pairs(Result &res) {
+    const std::vector<Pair> &pairs = res.pairs;
+    struct Child {
+        int32_t link;
+        const float *box;
+    };
+    auto area = [](const float *b) {
+        const float e0 = b[3] - b[0], e1 = b[4] - b[1], e2 = b[5] - b[2];
+        return (e0 + e1) * e2 + e0 * e1;
+    };
+    res.quads.clear();
+    std::vector<int> pair_of{0}, depth_of{1};  // wide node -> the pair it was made from, its depth
+    res.max_depth = 1;
+    for (size_t j = 0; j < pair_of.size(); j++) {
+        std::vector<Child> ch;
+        auto add = [&](const Pair &p) {
+            if (p.llink != kNoChild) ch.push_back({p.llink, p.lbox});
+            if (p.rlink != kNoChild) ch.push_back({p.rlink, p.rbox});
+        };
+        add(pairs[(size_t)pair_of[j]]);
+        while (ch.size() < 4) {
+            int best = -1;
+            for (size_t k = 0; k < ch.size(); k++)
+                if (ch[k].link >= 0) {
+                    const Pair &cp = pairs[(size_t)ch[k].link];
+                    const int grows = (cp.llink != kNoChild) + (cp.rlink != kNoChild) - 1;
+                    if ((int)ch.size() + grows <= 4 && (best < 0 || area(ch[k].box) > area(ch[(size_t)best].box))) best = (int)k;
+                }
+            if (best < 0) break;
+            const Pair &cp = pairs[(size_t)ch[(size_t)best].link];
+            ch.erase(ch.begin() + best);
+            add(cp);
+        }
+        Pair rec[2] = {absent_quad_record(), absent_quad_record()};
+        for (size_t k = 0; k < ch.size(); k++) {
+            Pair &r = rec[k >> 1];
+            memcpy((k & 1) ? r.rbox : r.lbox, ch[k].box, 6 * sizeof(float));
+            int32_t link = ch[k].link;
+            if (link >= 0) {  // becomes a wide node of its own
+                pair_of.push_back(link);
+                depth_of.push_back(depth_of[j] + 1);
+                res.max_depth = std::max(res.max_depth, depth_of[j] + 1);
+                link = 2 * (int32_t)(pair_of.size() - 1);
+            }
+            ((k & 1) ? r.rlink : r.llink) = link;
+        }
+        res.quads.push_back(rec[0]);
+        res.quads.push_back(rec[1]);
+    }
+    res.stack_bound = 3 * res.max_depth + 1;
+}
+
 }  // namespace rtbvh
 #endif  // RT_BVH_H

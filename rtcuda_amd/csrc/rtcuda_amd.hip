@@ -32,7 +32,7 @@
 //   advance_core / inner_step / tri_intersect / box_hit are the shared device functions: one copy of
 //   the estimator and of the traversal for both pipelines.
 //   * BVH: 64-byte node records with full-precision padded boxes -- a 4-wide node as two consecutive
-//     records (default), or 2-wide nodes of one record (RT_BVH_WIDE=0, and always for the device LBVH) --
+//     records (default), or 2-wide nodes of one record (RT_BVH_WIDE=0) --
 //     and 48-byte {p0,e1,e2,n} triangle records in leaf order (rt_bvh.h: SAH sweep + insertion-based
 //     optimisation + collapse to 4-wide).
 //   * Two results that depend, in the reference, on the shape of its own tree are defined by the triangle
@@ -2784,6 +2784,7 @@ int rt_scene_create(const float *tri_p0p1p2, int n_tris, const int32_t *tri_mate
             seen[bvh.order[k]] = 1;
         }
         bvh.pair_depth = depth;
+        rtbvh::quads_from_pairs(bvh);  // (host, a few ms: the 4-wide format of the same tree)
         bvh.num_leaves = n_tris;
         sc->builder = 1;
         sc->top_prefix = false;
@@ -2793,14 +2794,14 @@ int rt_scene_create(const float *tri_p0p1p2, int n_tris, const int32_t *tri_mate
         sc->build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     }
     if (!bvh.ok) return fail("rt_scene_create: BVH build produced an unreferenceable leaf");
-    if (sc->builder == 0 && n_tris > 0 && !validate_quads(bvh.quads, n_tris))
+    if (n_tris > 0 && !bvh.quads.empty() && !validate_quads(bvh.quads, n_tris))
         return fail("rt_scene_create: the 4-wide BVH is malformed (structure, or an absent child without its +inf box)");
-    if ((sc->builder == 1 ? bvh.pair_depth + 1 : bvh.stack_bound) > kMaxStackBound)
-        return fail("rt_scene_create: BVH depth " + std::to_string(bvh.max_depth) + " exceeds the traversal stack");
     sc->n_tris = n_tris;
     sc->wide = true;  // 4-wide nodes (two pair-style records each): half the dependent fetches per ray; RT_BVH_WIDE=0: 2-wide
     if (const char *e = getenv("RT_BVH_WIDE")) sc->wide = atoi(e) != 0;
-    if (sc->builder == 1) sc->wide = false;  // the device builder emits 2-wide records only
+    if (sc->wide && sc->builder == 1 && bvh.stack_bound > kMaxStackBound) sc->wide = false;  // (a very deep LBVH: 1 entry per level)
+    if ((sc->wide ? bvh.stack_bound : bvh.pair_depth + 1) > kMaxStackBound)
+        return fail("rt_scene_create: BVH depth " + std::to_string(sc->wide ? bvh.max_depth : bvh.pair_depth) + " exceeds the traversal stack");
     sc->n_nodes = sc->wide ? (int)bvh.quads.size() : (int)bvh.pairs.size();  // 64-byte records
     sc->max_depth = sc->wide ? bvh.max_depth : bvh.pair_depth;
     sc->stack_bound = sc->wide ? bvh.stack_bound : bvh.pair_depth + 1;

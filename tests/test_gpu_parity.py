@@ -399,23 +399,40 @@ def test_deterministic_accumulation_is_bit_reproducible_and_shard_exact(api, ora
 
 
 def test_device_lbvh_builder_gives_the_same_image(api, oracle, cpu_matte, bunny_matte, monkeypatch):
-    """the optional GPU BVH build (RT_BVH_BUILDER=lbvh).  A different tree, the same hits."""
-    monkeypatch.setenv("RT_BVH_BUILDER", "lbvh")
-    sc = api.Scene(bunny_matte)
-    info = sc.info()
-    assert info["builder"] == "lbvh" and info["pairs"] == bunny_matte.n_tris - 1 and info["leaves"] == bunny_matte.n_tris
-    assert 0 < info["build_seconds"] < 0.5
-    monkeypatch.delenv("RT_BVH_BUILDER")
-    ref_info = api.Scene(bunny_matte).info()
+    """the optional GPU BVH build (RT_BVH_BUILDER=lbvh).  A different tree, the same hits -- as the binary
+    tree the device emits (RT_BVH_WIDE=0) and collapsed to the 4-wide format the kernels walk by default; the deep
+    LBVH also drives the persistent kernel's traversal stack into its overflow column."""
+    ref = api.Scene(bunny_matte)
+    ref_info = ref.info()
     assert ref_info["builder"] == "sah"
     cam = default_camera(oracle, 16 / 9)
     o, d = raygen.camera_rays(cam, 1920, 1080, 150_000, seed=61)
-    g, c, _ = _closest_compare(sc, cpu_matte, o, d, np.full(len(o), FLT_MAX, np.float32), 2e-5)
-    o2, d2 = raygen.bounce_rays(o, d, c[1], c[0] >= 0, seed=62)
-    _closest_compare(sc, cpu_matte, o2, d2, np.full(len(o2), FLT_MAX, np.float32), 2e-5)
-    w, h, spp = 64, 36, 8
-    img_c, _, st_c = cpu_matte.render(default_camera(oracle, w / h), w, h, spp, threads=8)
-    img_g, st_g = sc.render(api.make_camera(aspect=w / h), w, h, spp)
-    assert st_g["shade_events"] == st_c["sum_mat"] and st_g["any_rays"] == st_c["sum_ah"]
-    assert _rms(img_g, img_c).max() < 2e-6
-    print("LBVH build", info["build_seconds"], "s; host SAH build", ref_info["build_seconds"], "s")
+    w2, h2, spp2 = 400, 300, 20  # 2.29 generations: all but the last in k_paths
+    img_ref, st_ref = ref.render(api.make_camera(aspect=w2 / h2), w2, h2, spp2)
+    for wide in ("1", "0"):
+        monkeypatch.setenv("RT_BVH_BUILDER", "lbvh")
+        monkeypatch.setenv("RT_BVH_WIDE", wide)
+        sc = api.Scene(bunny_matte)
+        monkeypatch.delenv("RT_BVH_BUILDER")
+        monkeypatch.delenv("RT_BVH_WIDE")
+        info = sc.info()
+        assert info["builder"] == "lbvh" and info["leaves"] == bunny_matte.n_tris
+        if wide == "0":
+            assert info["pairs"] == bunny_matte.n_tris - 1
+        else:  # two records per 4-wide node, fewer nodes than the binary tree has
+            assert info["pairs"] % 2 == 0 and info["pairs"] // 2 < bunny_matte.n_tris - 1
+        assert 0 < info["build_seconds"] < 0.5
+        g, c, _ = _closest_compare(sc, cpu_matte, o, d, np.full(len(o), FLT_MAX, np.float32), 2e-5)
+        o2, d2 = raygen.bounce_rays(o, d, c[1], c[0] >= 0, seed=62)
+        _closest_compare(sc, cpu_matte, o2, d2, np.full(len(o2), FLT_MAX, np.float32), 2e-5)
+        w, h, spp = 64, 36, 8
+        img_c, _, st_c = cpu_matte.render(default_camera(oracle, w / h), w, h, spp, threads=8)
+        img_g, st_g = sc.render(api.make_camera(aspect=w / h), w, h, spp)
+        assert st_g["shade_events"] == st_c["sum_mat"] and st_g["any_rays"] == st_c["sum_ah"]
+        assert _rms(img_g, img_c).max() < 2e-6
+        img_m, st_m = sc.render(api.make_camera(aspect=w2 / h2), w2, h2, spp2)
+        for k in ("camera_rays", "shade_events", "closest_rays", "any_rays", "emission_adds", "shadow_adds", "rr_draws"):
+            assert st_m[k] == st_ref[k], (wide, k)
+        assert _rms(img_m, img_ref).max() < 2e-6
+        print("LBVH build", info["build_seconds"], "s (wide=%s); host SAH build" % wide, ref_info["build_seconds"], "s")
+        sc.close()
