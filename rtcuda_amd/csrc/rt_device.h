@@ -99,16 +99,14 @@ RT_DEV bool tri_intersect(const Tri &tr, V3 o, V3 d, float tmax, float &t_out, f
     float inv_det = 1.f / dot(d, tr.n);
     float u = inv_det * dot(tr.e2, r);
     float v = inv_det * dot(tr.e1, r);
-    if (u >= 0.0f && v >= 0.0f && (u + v) <= 1.0f) {
-        float t = inv_det * dot(c, tr.n);
-        if (0 < t && t <= tmax) {
-            t_out = t;
-            u_out = u;
-            v_out = v;
-            return true;
-        }
-    }
-    return false;
+    // (t for every lane, and one straight-line result: in a wave some lane nearly always passes the barycentric test, so
+    // the nested early exits of the reference's form save nothing here and cost two exec-mask regions and their merges;
+    // the values and the accept / reject decision are the same.  t, u, v are only meaningful when true is returned.)
+    float t = inv_det * dot(c, tr.n);
+    t_out = t;
+    u_out = u;
+    v_out = v;
+    return u >= 0.0f && v >= 0.0f && (u + v) <= 1.0f && 0 < t && t <= tmax;
 }
 RT_DEV V3 tri_point(const Tri &tr, float u, float v) { return add(sub(tr.p0, scale(tr.e1, u)), scale(tr.e2, v)); }
 RT_DEV float tri_area(const Tri &tr) { return 0.5f * len(tr.n); }  // 0.5 * x is exact in any precision
