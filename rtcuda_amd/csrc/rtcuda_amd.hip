@@ -409,14 +409,18 @@ struct AdvanceOut {
 // st.bounces = kDone (no camera ray left) / kParked (the final generation runs in lockstep) or a new path.
 // `pxy` (optional): the slot's previous pixel as (x | y << 16), or -1.  A slot's pixel index grows by W / spp per
 // generation, so with it the pixel coordinates follow by an add and a carry instead of two integer divisions.
+// NEVER_LOCKSTEP: the caller (k_paths) only ever runs with ap.lockstep == 0 -- known at compile time there, a value read
+// from LDS (and so a divergent branch with its merges, as far as the compiler can tell) otherwise.
+template <bool NEVER_LOCKSTEP = false>
 __device__ __forceinline__ void gen_core(const Camera &cam, const AdvanceParams &ap, int slot_global, SlotState &st,
                                          AdvanceOut &out, int *pxy = nullptr) {
+    const bool lockstep = NEVER_LOCKSTEP ? false : (ap.lockstep != 0);
     long long cid = (long long)st.gen * kW + slot_global;
     if (cid >= ap.cam_end) {
         st.bounces = kDone;
         return;
     }
-    if (!ap.lockstep && st.gen == ap.last_gen) {
+    if (!lockstep && st.gen == ap.last_gen) {
         st.bounces = kParked;
         return;
     }
@@ -449,10 +453,11 @@ __device__ __forceinline__ void gen_core(const Camera &cam, const AdvanceParams 
 }
 
 // `acc` (k_paths only): the lane's sample accumulator; nullptr = deposit straight into the framebuffer.
-template <bool DEFER_GEN>
+template <bool DEFER_GEN, bool NEVER_LOCKSTEP = false>
 __device__ __forceinline__ void advance_core(const DScene &sc, const float *tab, const Camera &cam,
                                              const AdvanceParams &ap, int slot_global, SlotState &st, AdvanceOut &out,
                                              float *__restrict__ fb, float *acc = nullptr) {
+    const bool lockstep = NEVER_LOCKSTEP ? false : (ap.lockstep != 0);
     const int off_ltri = tab_off_ltri(sc.num_mats, sc.num_lights);
     const int off_lpre = tab_off_lpre(sc.num_mats, sc.num_lights);
     out.did_gen = out.did_shade = out.has_shadow = out.did_emit = out.new_ray = out.wants_gen = false;
@@ -484,15 +489,15 @@ __device__ __forceinline__ void advance_core(const DScene &sc, const float *tab,
                     shade = true;
                     break;
                 }
-                if (ap.lockstep || !(st.bounces < ap.max_bounces)) break;
+                if (lockstep || !(st.bounces < ap.max_bounces)) break;
             }
         } else {
             st.bounces = st.bounces + 1;  // :126
         }
         if (shade) out.did_shade = true;
-        else if (ap.lockstep) return;  // killed this round; the next round rolls again
+        else if (lockstep) return;  // killed this round; the next round rolls again
     } else {
-        if (cont && ap.lockstep) {  // a miss idles: nothing but the counter moves (Appendix A.2)
+        if (cont && lockstep) {  // a miss idles: nothing but the counter moves (Appendix A.2)
             st.bounces = st.bounces + 1;
             return;
         }
@@ -504,7 +509,7 @@ __device__ __forceinline__ void advance_core(const DScene &sc, const float *tab,
             return;
         }
         if (acc) acc_flush(acc, fb, ap.fb_fixed, st.pixel);  // the camera ray that ends here: its sum -> its pixel
-        gen_core(cam, ap, slot_global, st, out);
+        gen_core<NEVER_LOCKSTEP>(cam, ap, slot_global, st, out);
         return;
     }
     // ---- mat() :139-248
@@ -1461,7 +1466,7 @@ k_paths(DScene sc, DPools p, Camera cam_arg, AdvanceParams ap_arg, float *__rest
                 st.beta = mk(0, 0, 0);
                 int pxy = cold[12 * kBlock];
                 acc_flush(acc, fb, ap_fb_fixed, cold[1 * kBlock]);  // the camera ray that ended: its sum -> its pixel
-                gen_core(cam, ap, ap.slot_lo + i, st, out, &pxy);
+                gen_core<true>(cam, ap, ap.slot_lo + i, st, out, &pxy);
                 // the slot state gen() leaves: bounces (0, or the kDone / kParked sentinel), gen, the RNG; a new path also
                 // has its pixel and beta = 1
                 cold[0 * kBlock] = st.bounces;
@@ -1528,7 +1533,7 @@ k_paths(DScene sc, DPools p, Camera cam_arg, AdvanceParams ap_arg, float *__rest
                     st.isect_n = mk(sh.x, sh.y, sh.z);
                     st.hit_info = __float_as_int(sh.w);
                 }
-                advance_core<SPLIT_GEN>(sc, tab, cam, ap, ap.slot_lo + i, st, out, fb, acc);
+                advance_core<SPLIT_GEN, true>(sc, tab, cam, ap, ap.slot_lo + i, st, out, fb, acc);
                 bounces = st.bounces;
                 pixel = st.pixel;
                 gen = st.gen;
