@@ -452,8 +452,8 @@ __device__ __forceinline__ void gen_core(const Camera &cam, const AdvanceParams 
     out.did_gen = true;
 }
 
-// `acc` (k_paths only): the lane's sample accumulator; nullptr = deposit straight into the framebuffer.
-template <bool DEFER_GEN, bool NEVER_LOCKSTEP = false>
+// `acc` (USE_ACC, k_paths only): the lane's sample accumulator; otherwise contributions go straight into the framebuffer.
+template <bool DEFER_GEN, bool NEVER_LOCKSTEP = false, bool USE_ACC = false>
 __device__ __forceinline__ void advance_core(const DScene &sc, const float *tab, const Camera &cam,
                                              const AdvanceParams &ap, int slot_global, SlotState &st, AdvanceOut &out,
                                              float *__restrict__ fb, float *acc = nullptr) {
@@ -470,7 +470,7 @@ __device__ __forceinline__ void advance_core(const DScene &sc, const float *tab,
     // along such a chain, so the chain is a tight loop of draws.  `lockstep`: exactly one init() per call.
     if (st.bounces == 0 && hit && light_of_hit >= 0) {  // :98-103 emission only at bounce 0
         Light l = tab_light(tab, sc.num_mats, light_of_hit);
-        if (acc) acc_add(acc, l.lx, l.ly, l.lz);
+        if (USE_ACC) acc_add(acc, l.lx, l.ly, l.lz);  // (k_paths; a compile-time choice: `if (acc)` is a per-lane pointer test)
         else deposit(fb, ap.fb_fixed, st.pixel, l.lx, l.ly, l.lz);
         out.did_emit = true;
     }
@@ -508,7 +508,7 @@ __device__ __forceinline__ void advance_core(const DScene &sc, const float *tab,
             out.wants_gen = true;
             return;
         }
-        if (acc) acc_flush(acc, fb, ap.fb_fixed, st.pixel);  // the camera ray that ends here: its sum -> its pixel
+        if (USE_ACC) acc_flush(acc, fb, ap.fb_fixed, st.pixel);  // the camera ray that ends here: its sum -> its pixel
         gen_core<NEVER_LOCKSTEP>(cam, ap, slot_global, st, out);
         return;
     }
@@ -1533,7 +1533,7 @@ k_paths(DScene sc, DPools p, Camera cam_arg, AdvanceParams ap_arg, float *__rest
                     st.isect_n = mk(sh.x, sh.y, sh.z);
                     st.hit_info = __float_as_int(sh.w);
                 }
-                advance_core<SPLIT_GEN, true>(sc, tab, cam, ap, ap.slot_lo + i, st, out, fb, acc);
+                advance_core<SPLIT_GEN, true, true>(sc, tab, cam, ap, ap.slot_lo + i, st, out, fb, acc);
                 bounces = st.bounces;
                 pixel = st.pixel;
                 gen = st.gen;
