@@ -166,6 +166,31 @@ int rt_measure_copy_bandwidth(int64_t bytes, int reps, double *out_bytes_per_s);
  * No reference counterpart (the reference measures nothing). */
 int rt_calibrate_valu(int waves_per_simd, int iters, double *out_lane_ops_per_s, double *out_wave_instr);
 
+/* Measurement tool for the design question "one persistent kernel, or the reference's stage split (render.cuh:428-449:
+ * init/mat/gen kernels and ah/ch kernels with dense queues between them)?".  Runs the round-per-launch pipeline of the
+ * frame from its start until `target_rays` rays have been traced, copying every round's rays (closest-hit and any-hit
+ * apart) and every round's shading inputs (by material kind) into dense device arrays; then times, on those arrays,
+ *   - the trace kernel alone (stage-level modes of the product's trace kernel) at 8 / 6 / 5 / 4 waves per SIMD,
+ *   - the shading code alone (the product's init() + mat()), one material kind per launch, every lane shading,
+ * each as the best of three launches (HIP events).  out[] is indexed by the RT_PROBE_* enum; times in seconds.
+ * No reference counterpart. */
+enum {
+    RT_PROBE_ROUNDS = 0,          /* rounds of the pipeline that were run and dumped */
+    RT_PROBE_CLOSEST_RAYS,        /* rays in the closest-hit array */
+    RT_PROBE_ANY_RAYS,            /* rays in the any-hit array */
+    RT_PROBE_S_ADVANCE_ROUND0,    /* k_advance of round 0: every slot runs gen() */
+    RT_PROBE_S_ADVANCE,           /* k_advance, rounds 1.. (sum) */
+    RT_PROBE_S_TRACE_POOL,        /* k_trace over the pools, all rounds (sum) */
+    RT_PROBE_S_TRACE_CLOSEST,     /* [4]: closest-hit array at 8 / 6 / 5 / 4 waves per SIMD */
+    RT_PROBE_S_TRACE_ANY = RT_PROBE_S_TRACE_CLOSEST + 4,            /* [4]: any-hit array */
+    RT_PROBE_TRACE_BLOCKS_PER_CU = RT_PROBE_S_TRACE_ANY + 4,        /* [4]: resident 256-thread blocks per CU of each build */
+    RT_PROBE_SHADES = RT_PROBE_TRACE_BLOCKS_PER_CU + 4,             /* [3]: shading records per kind (matte, mirror, glass) */
+    RT_PROBE_S_SHADE = RT_PROBE_SHADES + 3,                         /* [3]: shading-only launch per kind */
+    RT_PROBE_COUNT = RT_PROBE_S_SHADE + 3
+};
+int rt_split_probe(const rt_scene *scene, const rt_camera *camera, int width, int height, int num_samples,
+                   int max_bounces, uint64_t seed, int64_t target_rays, double *out, int n_out);
+
 const char *rt_last_error(void);
 const char *rt_version(void);
 

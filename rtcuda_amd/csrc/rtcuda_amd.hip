@@ -961,8 +961,10 @@ struct TraceParams {
 // carries its kind with its ray, so closest-hit and any-hit rays share waves; the two kinds differ
 // only in what a triangle hit does and in how the finished ray is finalised.
 // LDS layout (dynamic): [stack: (stack_cap + 1) x kBlock ints (push_if)][pending: kBlock ints]
-template <int MODE, bool WIDE>
-__global__ void __launch_bounds__(kBlock, 8) k_trace(DScene sc, DPools p, TraceParams tp, int stack_cap, int *overflow) {
+// MINW: minimum waves per SIMD the register budget is sized for (8 = 64 VGPRs: the renderer's build; the split probe
+// also times the builds with 80 / 96 / 128 VGPRs).
+template <int MODE, bool WIDE, int MINW = 8>
+__global__ void __launch_bounds__(kBlock, MINW) k_trace(DScene sc, DPools p, TraceParams tp, int stack_cap, int *overflow) {
     extern __shared__ int s_lds[];
     int *stack = s_lds + threadIdx.x;
     int *over = overflow + (blockIdx.x * kBlock + threadIdx.x);
@@ -1787,6 +1789,150 @@ __global__ void __launch_bounds__(256) k_valu_calibrate(float *__restrict__ out,
     }
     float r = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7)) + ((a8 + a9) + (a10 + a11)) + ((a12 + a13) + (a14 + a15));
     if (r == 12345.678f) out[blockIdx.x * blockDim.x + threadIdx.x] = r;  // (never true: keeps the chain alive)
+}
+
+// ============================================================================ split probe (rt_split_probe)
+// Measurement kernels for the question "would separate trace and shade kernels -- the reference's stage split
+// (render.cuh:428-449) with dense queues -- beat k_paths?".  The round pipeline's pools are copied, round after round,
+// into DENSE arrays: the rays k_trace is about to trace (closest-hit and any-hit apart), and the slot records
+// k_advance is about to shade (one bucket per material kind: a wave of the shading probe sees one material).
+// The trace side is then timed with k_trace's stage-level modes on those arrays, the shade side with k_probe_shade.
+constexpr int kProbeIn = 22;   // dwords of a shading record: bounces, hit_info, pixel, gen, rng 6, beta 3, wo 3, p 3, n 3
+constexpr int kProbeOut = 27;  // dwords a shade writes: ray 6, shadow ray 6 + tmax + L 3 + target, beta 3, rng 6, bounces
+__global__ void __launch_bounds__(kBlock)
+k_probe_dump_rays(DPools p, int n, float *__restrict__ c_o3, float *__restrict__ c_d3, float *__restrict__ c_tmax,
+                  float *__restrict__ a_o3, float *__restrict__ a_d3, float *__restrict__ a_tmax, int *__restrict__ a_excl,
+                  unsigned cap, unsigned *__restrict__ counts) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool in = i < n;
+    const int b = in ? p.bounces(i) : kDone;
+    const bool live = in && b != kDone && b != kParked;
+    const bool shadow = in && p.stmax(i) >= 0.f;
+    unsigned long long m = wave_ballot(live);
+    if (m) {
+        unsigned base = 0;
+        if (lane_id() == 0) base = atomicAdd(&counts[0], (unsigned)__popcll(m));
+        base = __builtin_amdgcn_readfirstlane(base);
+        const unsigned k = base + prefix_popc(m);
+        if (live && k < cap) {
+            c_o3[3 * (size_t)k + 0] = p.ox(i);
+            c_o3[3 * (size_t)k + 1] = p.oy(i);
+            c_o3[3 * (size_t)k + 2] = p.oz(i);
+            c_d3[3 * (size_t)k + 0] = p.dx(i);
+            c_d3[3 * (size_t)k + 1] = p.dy(i);
+            c_d3[3 * (size_t)k + 2] = p.dz(i);
+            c_tmax[k] = kFltMax;
+        }
+    }
+    m = wave_ballot(shadow);
+    if (m) {
+        unsigned base = 0;
+        if (lane_id() == 0) base = atomicAdd(&counts[1], (unsigned)__popcll(m));
+        base = __builtin_amdgcn_readfirstlane(base);
+        const unsigned k = base + prefix_popc(m);
+        if (shadow && k < cap) {
+            a_o3[3 * (size_t)k + 0] = p.sox(i);
+            a_o3[3 * (size_t)k + 1] = p.soy(i);
+            a_o3[3 * (size_t)k + 2] = p.soz(i);
+            a_d3[3 * (size_t)k + 0] = p.sdx(i);
+            a_d3[3 * (size_t)k + 1] = p.sdy(i);
+            a_d3[3 * (size_t)k + 2] = p.sdz(i);
+            a_tmax[k] = p.stmax(i);
+            a_excl[k] = p.starget(i);
+        }
+    }
+}
+// the slots the NEXT k_advance will shade (hit, bounce left: render.cuh:109,128-130), by material kind
+__global__ void __launch_bounds__(kBlock)
+k_probe_dump_shades(DScene sc, DPools p, int n, int max_bounces, float *__restrict__ rec, unsigned cap,
+                    unsigned *__restrict__ counts) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool in = i < n;
+    const int b = in ? p.bounces(i) : kDone;
+    const int hi = in ? p.hit_info(i) : -1;
+    const bool shade = in && b != kDone && b != kParked && hi >= 0 && b < max_bounces;
+    const int kind = shade ? __float_as_int(sc.tables[5 * (hi & 0xffff) + 4]) : -1;
+    for (int mk = 0; mk < 3; mk++) {
+        const bool mine = kind == mk;
+        const unsigned long long m = wave_ballot(mine);
+        if (!m) continue;
+        unsigned base = 0;
+        if (lane_id() == 0) base = atomicAdd(&counts[2 + mk], (unsigned)__popcll(m));
+        base = __builtin_amdgcn_readfirstlane(base);
+        const unsigned k = base + prefix_popc(m);
+        if (mine && k < cap) {
+            float *r = rec + (size_t)mk * kProbeIn * cap + k;  // array a of bucket mk at r[a * cap]
+            const float v[kProbeIn] = {__int_as_float(b), __int_as_float(hi), __int_as_float(p.pixel(i)), __int_as_float(p.gen(i)),
+                                       __uint_as_float(p.rd(i)), __uint_as_float(p.r0(i)), __uint_as_float(p.r1(i)),
+                                       __uint_as_float(p.r2(i)), __uint_as_float(p.r3(i)), __uint_as_float(p.r4(i)),
+                                       p.br(i), p.bg(i), p.bb(i), p.dx(i), p.dy(i), p.dz(i),
+                                       p.hpx(i), p.hpy(i), p.hpz(i), p.hnx(i), p.hny(i), p.hnz(i)};
+#pragma unroll
+            for (int a = 0; a < kProbeIn; a++) r[(size_t)a * cap] = v[a];
+        }
+    }
+}
+// init() + mat() (advance_core, the code k_advance and k_paths run) on a dense array of shading records: every lane
+// of every wave shades, one material kind per launch.  Reads kProbeIn dwords per shade, writes up to kProbeOut.
+template <bool LDS_TABLES>
+__global__ void __launch_bounds__(kBlock)
+k_probe_shade(DScene sc, Camera cam, AdvanceParams ap, const float *__restrict__ rec, unsigned cap, unsigned count,
+              float *__restrict__ outp, float *__restrict__ fb) {
+    __shared__ float s_tab[LDS_TABLES ? kTabDwordsMax : 1];
+    const float *tab = sc.tables;
+    if (LDS_TABLES) {
+        for (int k = threadIdx.x; k < sc.tab_dwords; k += kBlock) s_tab[k] = sc.tables[k];
+        __syncthreads();
+        tab = s_tab;
+    }
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const float *r = rec + i;
+    SlotState st;
+    st.bounces = __float_as_int(r[0 * (size_t)cap]);
+    st.hit_info = __float_as_int(r[1 * (size_t)cap]);
+    st.pixel = __float_as_int(r[2 * (size_t)cap]);
+    st.gen = __float_as_int(r[3 * (size_t)cap]);
+    st.rs = Rng{__float_as_uint(r[4 * (size_t)cap]), __float_as_uint(r[5 * (size_t)cap]), __float_as_uint(r[6 * (size_t)cap]),
+                __float_as_uint(r[7 * (size_t)cap]), __float_as_uint(r[8 * (size_t)cap]), __float_as_uint(r[9 * (size_t)cap])};
+    st.beta = mk(r[10 * (size_t)cap], r[11 * (size_t)cap], r[12 * (size_t)cap]);
+    st.wo = mk(r[13 * (size_t)cap], r[14 * (size_t)cap], r[15 * (size_t)cap]);
+    st.isect_p = mk(r[16 * (size_t)cap], r[17 * (size_t)cap], r[18 * (size_t)cap]);
+    st.isect_n = mk(r[19 * (size_t)cap], r[20 * (size_t)cap], r[21 * (size_t)cap]);
+    AdvanceOut out;
+    advance_core<true, true, false>(sc, tab, cam, ap, 0, st, out, fb);
+    float *w = outp + i;
+    if (out.new_ray) {
+        w[0 * (size_t)cap] = out.ray_o.x;
+        w[1 * (size_t)cap] = out.ray_o.y;
+        w[2 * (size_t)cap] = out.ray_o.z;
+        w[3 * (size_t)cap] = out.ray_d.x;
+        w[4 * (size_t)cap] = out.ray_d.y;
+        w[5 * (size_t)cap] = out.ray_d.z;
+    }
+    w[12 * (size_t)cap] = out.has_shadow ? out.s_tmax : -1.f;
+    if (out.has_shadow) {
+        w[6 * (size_t)cap] = out.s_o.x;
+        w[7 * (size_t)cap] = out.s_o.y;
+        w[8 * (size_t)cap] = out.s_o.z;
+        w[9 * (size_t)cap] = out.s_d.x;
+        w[10 * (size_t)cap] = out.s_d.y;
+        w[11 * (size_t)cap] = out.s_d.z;
+        w[13 * (size_t)cap] = out.s_L.x;
+        w[14 * (size_t)cap] = out.s_L.y;
+        w[15 * (size_t)cap] = out.s_L.z;
+        w[16 * (size_t)cap] = __int_as_float(out.s_target);
+    }
+    w[17 * (size_t)cap] = st.beta.x;
+    w[18 * (size_t)cap] = st.beta.y;
+    w[19 * (size_t)cap] = st.beta.z;
+    w[20 * (size_t)cap] = __uint_as_float(st.rs.d);
+    w[21 * (size_t)cap] = __uint_as_float(st.rs.v0);
+    w[22 * (size_t)cap] = __uint_as_float(st.rs.v1);
+    w[23 * (size_t)cap] = __uint_as_float(st.rs.v2);
+    w[24 * (size_t)cap] = __uint_as_float(st.rs.v3);
+    w[25 * (size_t)cap] = __uint_as_float(st.rs.v4);
+    w[26 * (size_t)cap] = __int_as_float(st.bounces);
 }
 
 // ============================================================================ device BVH build (LBVH)
@@ -2742,6 +2888,62 @@ int render_overlapped(const rt_scene *scene, const rt_camera *camera, int width,
 
 }  // namespace
 
+// ---- split probe: see the kernels (k_probe_*) for what is measured
+namespace {
+struct ProbeBufs {  // freed on every return path
+    std::vector<void *> ptrs;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    ~ProbeBufs() {
+        for (void *q : ptrs) (void)hipFree(q);
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+    }
+    template <typename T>
+    int alloc(T *&ptr, size_t count) {
+        void *raw = nullptr;
+        HIP_TRY(hipMalloc(&raw, std::max<size_t>(count, 1) * sizeof(T)));
+        ptrs.push_back(raw);
+        ptr = (T *)raw;
+        return 0;
+    }
+};
+template <int MODE, bool WIDE, int MINW>
+int probe_trace_once(const rt_scene *scene, const TraceParams &tp, int stack_cap, int *d_over, int cus, hipEvent_t e0,
+                     hipEvent_t e1, double *seconds, double *blocks_per_cu) {
+    const size_t lds = sizeof(int) * kBlock * (size_t)(stack_cap + 2);
+    int occ = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_trace<MODE, WIDE, MINW>, kBlock, lds));
+    occ = std::max(1, occ);
+    const int grid = std::max(1, std::min(grid_for(tp.total), cus * occ));
+    double best = 1e30;
+    DPools none{};
+    for (int rep = 0; rep < 3; rep++) {
+        HIP_TRY(hipEventRecord(e0, nullptr));
+        hipLaunchKernelGGL((k_trace<MODE, WIDE, MINW>), dim3(grid), dim3(kBlock), lds, nullptr, scene->dev(), none, tp,
+                           stack_cap, d_over);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(e1, nullptr));
+        HIP_TRY(hipEventSynchronize(e1));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+        best = std::min(best, (double)ms * 1e-3);
+    }
+    *seconds = best;
+    *blocks_per_cu = occ;
+    return 0;
+}
+template <int MODE, bool WIDE>
+int probe_trace(const rt_scene *scene, const TraceParams &tp, int stack_cap, int *d_over, int cus, hipEvent_t e0, hipEvent_t e1,
+                int minw, double *seconds, double *blocks_per_cu) {
+    switch (minw) {
+        case 8: return probe_trace_once<MODE, WIDE, 8>(scene, tp, stack_cap, d_over, cus, e0, e1, seconds, blocks_per_cu);
+        case 6: return probe_trace_once<MODE, WIDE, 6>(scene, tp, stack_cap, d_over, cus, e0, e1, seconds, blocks_per_cu);
+        case 5: return probe_trace_once<MODE, WIDE, 5>(scene, tp, stack_cap, d_over, cus, e0, e1, seconds, blocks_per_cu);
+        default: return probe_trace_once<MODE, WIDE, 4>(scene, tp, stack_cap, d_over, cus, e0, e1, seconds, blocks_per_cu);
+    }
+}
+}  // namespace
+
 // ============================================================================ C-ABI
 extern "C" {
 
@@ -3210,6 +3412,175 @@ int rt_calibrate_valu(int waves_per_simd, int iters, double *out_lane_ops_per_s,
     (void)hipFree(d_out);
     *out_lane_ops_per_s = best;
     if (out_wave_instr) *out_wave_instr = (double)blocks * 4.0 * 16.0 * (double)iters;  // v_fma_f32 wave-instructions per launch
+    return 0;
+}
+
+int rt_split_probe(const rt_scene *scene, const rt_camera *camera, int width, int height, int num_samples, int max_bounces,
+                   uint64_t seed, int64_t target_rays, double *out, int n_out) {
+    if (!scene || !camera || !out || n_out < RT_PROBE_COUNT) return fail("rt_split_probe: bad argument");
+    if (width <= 0 || height <= 0 || num_samples <= 0 || max_bounces < 0 || target_rays < 1 || target_rays > (1LL << 30))
+        return fail("rt_split_probe: bad dimensions");
+    const long long cam_end = (long long)width * height * num_samples;
+    if (cam_end + 13LL * kW >= (1LL << 31)) return fail("rt_split_probe: frame exceeds the int32 camera-ray range");
+    int dev = 0, cus = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev != scene->device) return fail("rt_split_probe: scene was created on another device");
+    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    for (int k = 0; k < n_out; k++) out[k] = 0.0;
+    const int n = kW;
+    Context *cp = nullptr;
+    if (get_context(n, 7, &cp)) return 1;  // (a context of its own: lane 7)
+    Context &c = *cp;
+    std::lock_guard<std::mutex> busy_lock(c.busy);
+    double rng_seconds = 0.0;
+    if (ensure_rng(c, seed, 0, nullptr, &rng_seconds)) return 1;
+    ProbeBufs pb;
+    HIP_TRY(hipEventCreate(&pb.e0));
+    HIP_TRY(hipEventCreate(&pb.e1));
+    const unsigned cap = (unsigned)(target_rays + 2 * (long long)kW);
+    float *c_o3, *c_d3, *c_tmax, *a_o3, *a_d3, *a_tmax, *rec, *outp, *fb, *o_t, *o_u, *o_v;
+    int *a_excl, *o_i;
+    unsigned *d_counts;
+    if (pb.alloc(c_o3, 3 * (size_t)cap) || pb.alloc(c_d3, 3 * (size_t)cap) || pb.alloc(c_tmax, cap) || pb.alloc(a_o3, 3 * (size_t)cap) ||
+        pb.alloc(a_d3, 3 * (size_t)cap) || pb.alloc(a_tmax, cap) || pb.alloc(a_excl, cap) || pb.alloc(rec, 3 * (size_t)kProbeIn * cap) ||
+        pb.alloc(outp, (size_t)kProbeOut * cap) || pb.alloc(fb, 3 * (size_t)width * height) || pb.alloc(o_i, cap) || pb.alloc(o_t, cap) ||
+        pb.alloc(o_u, cap) || pb.alloc(o_v, cap) || pb.alloc(d_counts, 8))
+        return 1;
+    HIP_TRY(hipMemset(d_counts, 0, sizeof(unsigned) * 8));
+    HIP_TRY(hipMemset(fb, 0, sizeof(float) * 3 * (size_t)width * height));
+    HIP_TRY(hipMemset(c.d_rows, 0, sizeof(DWaveRow) * (size_t)c.n_rows));
+    {
+        DCounters zero{};
+        zero.last_live_round = -1;
+        HIP_TRY(hipMemcpy(c.d_ctr, &zero, sizeof(DCounters), hipMemcpyHostToDevice));
+    }
+    DScene sc = scene->dev();
+    Camera cam;
+    memcpy(&cam, camera, sizeof(Camera));
+    AdvanceParams ap{};
+    ap.n = n;
+    ap.slot_lo = 0;
+    ap.width = width;
+    ap.height = height;
+    ap.spp = num_samples;
+    ap.max_bounces = max_bounces;
+    ap.cam_end = cam_end;
+    ap.last_gen = (int)((cam_end + kW - 1) / kW) - 1;
+    ap.batch_mask = 7;
+    ap.w_over_spp = (kW % num_samples == 0) ? kW / num_samples : 0;
+    ap.dpx = ap.w_over_spp % width;
+    ap.dpy = (ap.w_over_spp > 0 && width < 32768 && height < 32768) ? ap.w_over_spp / width : -1;
+    const bool lds_tables = scene->n_mats <= kLdsTable && scene->n_lights <= kLdsTable;
+    const int stack_cap = lds_stack_cap(scene, kLdsStack);
+    const size_t lds_bytes = sizeof(int) * (size_t)kBlock * (size_t)(stack_cap + 2);
+    if (ensure_overflow(c.d_over, c.over_levels, scene->stack_bound - std::min(stack_cap, lds_stack_cap(scene, 8)))) return 1;
+    int occ_c = 0;
+    if (scene->wide) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_c, k_trace<MODE_POOL, true>, kBlock, lds_bytes));
+    else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_c, k_trace<MODE_POOL, false>, kBlock, lds_bytes));
+    const dim3 grid(grid_for(n)), block(kBlock), grid_trace(std::min(grid_for(n), std::max(1, cus * std::max(1, occ_c))));
+    TraceParams tpp{};
+    tpp.total = n;
+    tpp.fb = fb;
+    tpp.rows = c.d_rows;
+    hipLaunchKernelGGL(k_pool_init, grid, block, 0, nullptr, c.pools, n, max_bounces);
+    HIP_TRY(hipGetLastError());
+    // ---- the round pipeline, with the dumps between its stages; every stage timed with events (synchronously: a probe)
+    unsigned h_counts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    double t_adv = 0.0, t_trace = 0.0, t_adv0 = 0.0;
+    int rounds = 0;
+    auto timed = [&](double &acc) -> int {
+        HIP_TRY(hipEventRecord(pb.e1, nullptr));
+        HIP_TRY(hipEventSynchronize(pb.e1));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, pb.e0, pb.e1));
+        acc += (double)ms * 1e-3;
+        return 0;
+    };
+    while ((long long)h_counts[0] + h_counts[1] < target_rays && rounds < 4096) {
+        ap.round = rounds;
+        double t = 0.0;
+        HIP_TRY(hipEventRecord(pb.e0, nullptr));
+        if (lds_tables) hipLaunchKernelGGL(k_advance<true>, grid, block, 0, nullptr, sc, c.pools, cam, ap, fb, c.d_ctr, c.d_rows);
+        else hipLaunchKernelGGL(k_advance<false>, grid, block, 0, nullptr, sc, c.pools, cam, ap, fb, c.d_ctr, c.d_rows);
+        if (timed(t)) return 1;
+        if (rounds == 0) t_adv0 = t;  // every slot generates: gen() alone
+        else t_adv += t;
+        hipLaunchKernelGGL(k_probe_dump_rays, grid, block, 0, nullptr, c.pools, n, c_o3, c_d3, c_tmax, a_o3, a_d3, a_tmax, a_excl, cap, d_counts);
+        HIP_TRY(hipEventRecord(pb.e0, nullptr));
+        RT_LAUNCH_TRACE(MODE_POOL, scene->wide, grid_trace, lds_bytes, nullptr, sc, c.pools, tpp, stack_cap, c.d_over);
+        if (timed(t_trace)) return 1;
+        hipLaunchKernelGGL(k_probe_dump_shades, grid, block, 0, nullptr, sc, c.pools, n, max_bounces, rec, cap, d_counts);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpy(h_counts, d_counts, sizeof(h_counts), hipMemcpyDeviceToHost));
+        rounds++;
+        if (h_counts[0] == 0) break;  // (frame exhausted)
+    }
+    c.rng_valid = false;  // the pools' RNG arrays have moved on
+    const unsigned n_c = std::min(h_counts[0], cap), n_a = std::min(h_counts[1], cap);
+    out[RT_PROBE_ROUNDS] = rounds;
+    out[RT_PROBE_CLOSEST_RAYS] = n_c;
+    out[RT_PROBE_ANY_RAYS] = n_a;
+    out[RT_PROBE_S_ADVANCE_ROUND0] = t_adv0;
+    out[RT_PROBE_S_ADVANCE] = t_adv;
+    out[RT_PROBE_S_TRACE_POOL] = t_trace;
+    // ---- trace only: the stage-level modes of k_trace on the dense ray arrays, at four register budgets
+    {
+        TraceParams tc{};
+        tc.total = (int)n_c;
+        tc.o3 = c_o3;
+        tc.d3 = c_d3;
+        tc.tmax = c_tmax;
+        tc.order = scene->d_order;
+        tc.out_i = o_i;
+        tc.out_t = o_t;
+        tc.out_u = o_u;
+        tc.out_v = o_v;
+        TraceParams ta{};
+        ta.total = (int)n_a;
+        ta.o3 = a_o3;
+        ta.d3 = a_d3;
+        ta.tmax = a_tmax;
+        ta.excluded = a_excl;
+        ta.out_i = o_i;
+        const int budgets[4] = {8, 6, 5, 4};
+        for (int v = 0; v < 4; v++) {
+            double sc_s = 0.0, sa_s = 0.0, bc = 0.0, ba = 0.0;
+            if (n_c > 0) {
+                if (scene->wide ? probe_trace<MODE_TEST_CLOSEST, true>(scene, tc, stack_cap, c.d_over, cus, pb.e0, pb.e1, budgets[v], &sc_s, &bc)
+                                : probe_trace<MODE_TEST_CLOSEST, false>(scene, tc, stack_cap, c.d_over, cus, pb.e0, pb.e1, budgets[v], &sc_s, &bc))
+                    return 1;
+            }
+            if (n_a > 0) {
+                if (scene->wide ? probe_trace<MODE_TEST_ANY, true>(scene, ta, stack_cap, c.d_over, cus, pb.e0, pb.e1, budgets[v], &sa_s, &ba)
+                                : probe_trace<MODE_TEST_ANY, false>(scene, ta, stack_cap, c.d_over, cus, pb.e0, pb.e1, budgets[v], &sa_s, &ba))
+                    return 1;
+            }
+            out[RT_PROBE_S_TRACE_CLOSEST + v] = sc_s;
+            out[RT_PROBE_S_TRACE_ANY + v] = sa_s;
+            out[RT_PROBE_TRACE_BLOCKS_PER_CU + v] = bc;
+        }
+    }
+    // ---- shade only: one launch per material kind, every lane shading
+    for (int mk = 0; mk < 3; mk++) {
+        const unsigned cnt = std::min(h_counts[2 + mk], cap);
+        out[RT_PROBE_SHADES + mk] = cnt;
+        if (cnt == 0) continue;
+        double best = 1e30;
+        for (int rep = 0; rep < 3; rep++) {
+            HIP_TRY(hipEventRecord(pb.e0, nullptr));
+            if (lds_tables)
+                hipLaunchKernelGGL(k_probe_shade<true>, dim3((cnt + kBlock - 1) / kBlock), block, 0, nullptr, sc, cam, ap,
+                                   rec + (size_t)mk * kProbeIn * cap, cap, cnt, outp, fb);
+            else
+                hipLaunchKernelGGL(k_probe_shade<false>, dim3((cnt + kBlock - 1) / kBlock), block, 0, nullptr, sc, cam, ap,
+                                   rec + (size_t)mk * kProbeIn * cap, cap, cnt, outp, fb);
+            HIP_TRY(hipGetLastError());
+            double t = 0.0;
+            if (timed(t)) return 1;
+            best = std::min(best, t);
+        }
+        out[RT_PROBE_S_SHADE + mk] = best;
+    }
     return 0;
 }
 

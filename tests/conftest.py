@@ -42,3 +42,27 @@ def bunny_full_bsdf():
 
 def default_camera(oracle, aspect):
     return oracle.camera((0.5, 0.5, 1.5), (0.5, 0.5, 0.0), (0.0, 1.0, 0.0), 37.8, aspect)
+
+
+# ---- oracle renders are the expensive part of the GPU suite: one per (oracle flavour, scene, frame, mode) and session
+_oracle_scene_cache = {}
+_oracle_render_cache = {}
+
+
+def oracle_scene(oracle, variant, watertight):
+    """The oracle's scene of a BASELINE variant in the given box-test mode (built once per session)."""
+    key = (oracle.flavour, variant, bool(watertight))
+    if key not in _oracle_scene_cache:
+        from rtcuda_amd import scenes
+        _oracle_scene_cache[key] = oracle.scene(scenes.cornell_bunny(variant)).set_watertight(bool(watertight))
+    return _oracle_scene_cache[key]
+
+
+def oracle_render(oracle, variant, w, h, spp, max_bounces=10, seed=1, watertight=True, slot_lo=0, slot_hi=1 << 20):
+    """(image, raw sums, stats) of an oracle render, computed once per session for each distinct argument tuple."""
+    key = (oracle.flavour, variant, w, h, spp, max_bounces, seed, bool(watertight), slot_lo, slot_hi)
+    if key not in _oracle_render_cache:
+        sc = oracle_scene(oracle, variant, watertight)
+        _oracle_render_cache[key] = sc.render(default_camera(oracle, w / h), w, h, spp, max_bounces=max_bounces, seed=seed,
+                                              slot_lo=slot_lo, slot_hi=slot_hi, threads=os.cpu_count() or 8)
+    return _oracle_render_cache[key]
