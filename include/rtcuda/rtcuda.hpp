@@ -6,7 +6,8 @@
 //   Vec3 + operators, dot, cross, ...     vec3.cuh:4-147       (everything but the device-only atomic_add)
 //   Matrix4x4, Transform                  matrix4x4.hpp, transform.hpp   (included below: rtcuda/matrix4x4.hpp, transform.hpp)
 //   PLY ingest                            happly.h (vendored)  -> rtcuda/ply.hpp (own reader, happly's two accessor names)
-//   Triangle(p0, p1, p2)                  triangle.cuh:6-7
+//   Triangle(p0, p1, p2) + p1() p2() center() bounding_box() p(u, v), members p0 e1 e2 n    triangle.cuh:4-37
+//   BoundingBox, Intersection, Ray        bounding_box.cuh:4-37, intersection.hpp:4-6, ray.cuh:4-25
 //   Material::make_matte/mirror/glass     material.cuh:25-44
 //   Light::make_point_light/area_light    light.cuh:70-84
 //   Primitive(tri*, mat*, light* = NULL)  primitive.cuh:6-7
@@ -27,6 +28,7 @@
 #include <cstdint>
 #include <cstring>
 #include <memory>
+#include <cfloat>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -85,10 +87,86 @@ inline Vec3 refract(const Vec3 &unit_v, const Vec3 &unit_n, double eta_ratio) {
     return refract(unit_v, unit_n, eta_ratio, (float)(double)-dot(unit_v, unit_n));
 }
 
+// bounding_box.cuh:4-37 -- bounds = [xmin, xmax, ymin, ymax, zmin, zmax]
+struct BoundingBox {
+    BoundingBox() {}
+    BoundingBox(float xmin, float xmax, float ymin, float ymax, float zmin, float zmax) {
+        const float b[6] = {xmin, xmax, ymin, ymax, zmin, zmax};
+        for (int k = 0; k < 6; k++) bounds[k] = b[k];
+    }
+    static BoundingBox Empty() { BoundingBox b; b.reset(); return b; }
+    void reset() {
+        for (int a = 0; a < 3; a++) {
+            bounds[2 * a] = FLT_MAX;
+            bounds[2 * a + 1] = -FLT_MAX;
+        }
+    }
+    void extend(const BoundingBox &other) {
+        for (int a = 0; a < 3; a++) {
+            bounds[2 * a] = fminf(bounds[2 * a], other.bounds[2 * a]);
+            bounds[2 * a + 1] = fmaxf(bounds[2 * a + 1], other.bounds[2 * a + 1]);
+        }
+    }
+    float half_area() const {  // (dx + dy) * dz + dx * dy, in that order (bounding_box.cuh:27-32)
+        const float dx = bounds[1] - bounds[0], dy = bounds[3] - bounds[2], dz = bounds[5] - bounds[4];
+        return (dx + dy) * dz + dx * dy;
+    }
+    float bounds[6];
+};
+
+// intersection.hpp:4-6
+struct Intersection {
+    float t, u, v;
+};
+
+// utility.cuh:31-47 on the host: the self-intersection offset of a spawned ray's origin (integer steps on the bit
+// pattern, or n / 65536 near the coordinate planes).  The device code (rt_device.h) is what renders; this is the same
+// function for drivers that spawn rays themselves.
+inline Vec3 offset_ray_origin(const Vec3 &p, const Vec3 &n) {
+    auto one = [](float pc, float nc) {
+        if (fabsf(pc) < 1.f / 32.f) return pc + (1.f / 65536.f) * nc;
+        int32_t bits, step = (int32_t)(256.f * nc);
+        memcpy(&bits, &pc, 4);
+        bits += pc < 0 ? -step : step;
+        float r;
+        memcpy(&r, &bits, 4);
+        return r;
+    };
+    return Vec3(one(p.x, n.x), one(p.y, n.y), one(p.z, n.z));
+}
+
+// ray.cuh:4-25
+struct Ray {
+    Ray() {}
+    Ray(const Vec3 &origin, const Vec3 &unit_d, float tmax = FLT_MAX) : origin(origin), unit_d(unit_d), tmax(tmax) {}
+    Vec3 at(float t) const { return origin + t * unit_d; }
+    static Ray spawn_offset_ray(const Vec3 &origin, const Vec3 &unit_n, const Vec3 &unit_d, float tmax = FLT_MAX) {
+        return Ray(offset_ray_origin(origin, unit_n), unit_d, tmax);
+    }
+    Vec3 origin, unit_d;
+    float tmax;
+};
+
+// triangle.cuh:4-37, host side: the reference's public members {p0, e1 = p0 - p1, e2 = p2 - p0, n = e1 x e2} and its
+// accessors.  Note p1() = p0 - e1 and p2() = p0 + e2 are the reference's ROUNDED reconstructions, not the constructor's
+// arguments; those are kept beside them (p1_, p2_) because the library derives its own e1, e2, n from the three
+// vertices with pinned fp32 arithmetic (rt_scene_create), exactly as the reference's constructor does on the host.
 struct Triangle {
     Triangle() {}
-    Triangle(const Vec3 &p0, const Vec3 &p1, const Vec3 &p2) : p0(p0), p1_(p1), p2_(p2) {}
-    Vec3 p0, p1_, p2_;  // the library derives e1, e2, n itself (triangle.cuh:7) with pinned fp32 arithmetic
+    Triangle(const Vec3 &p0, const Vec3 &p1, const Vec3 &p2)
+        : p0(p0), e1(p0 - p1), e2(p2 - p0), n(cross(e1, e2)), p1_(p1), p2_(p2) {}
+    Vec3 p1() const { return p0 - e1; }
+    Vec3 p2() const { return p0 + e2; }
+    Vec3 center() const { return (p0 + p1() + p2()) * (1.f / 3.f); }
+    Vec3 p(float u, float v) const { return p0 - u * e1 + v * e2; }  // triangle.cuh:15
+    float area() const { return 0.5f * n.length(); }                 // triangle.cuh:84-86
+    BoundingBox bounding_box() const {
+        const Vec3 a = p1(), b = p2();
+        return BoundingBox(fminf(p0.x, fminf(a.x, b.x)), fmaxf(p0.x, fmaxf(a.x, b.x)), fminf(p0.y, fminf(a.y, b.y)),
+                           fmaxf(p0.y, fmaxf(a.y, b.y)), fminf(p0.z, fminf(a.z, b.z)), fmaxf(p0.z, fmaxf(a.z, b.z)));
+    }
+    Vec3 p0, e1, e2, n;
+    Vec3 p1_, p2_;  // the constructor's second and third vertex, as given
 };
 
 enum MaterialType { MATTE, MIRROR, GLASS };

@@ -77,7 +77,8 @@ typedef struct rt_stats {
     int64_t launches_trace;  /* launches of each stage kernel (= iterations) */
     int64_t reserved[7];     /* reserved[0] = launches actually sampled by the event timer;
                                 reserved[1] = 1 when the frame ran as one persistent k_paths launch (then
-                                seconds_trace is that launch's duration and launches_trace is 1) */
+                                seconds_trace is that launch's duration and launches_trace is 1);
+                                reserved[2] = BVH node records that launch staged in LDS (small shards only) */
 } rt_stats;
 
 /* Flags for rt_render / rt_render_shard */
@@ -193,6 +194,9 @@ int rt_split_probe(const rt_scene *scene, const rt_camera *camera, int width, in
 
 const char *rt_last_error(void);
 const char *rt_version(void);
+/* Hash of the sources, compiler flags and experiment defines this library's device code was built from (csrc/Makefile).
+ * Measurement artefacts (profiles/pmc_k_paths.json) carry it, so counters are never priced against another build. */
+const char *rt_build_id(void);
 
 #ifdef __cplusplus
 }

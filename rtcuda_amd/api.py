@@ -27,7 +27,7 @@ FLAG_DETERMINISTIC = 2
 EXPORTS = [
     "rt_scene_create", "rt_scene_destroy", "rt_scene_info", "rt_scene_build_info", "rt_camera_make", "rt_render",
     "rt_render_shard", "rt_render_shard_fixed", "rt_post_process", "rt_post_process_fixed", "rt_trace_closest", "rt_trace_any", "rt_xorwow_states",
-    "rt_measure_copy_bandwidth", "rt_calibrate_valu", "rt_split_probe", "rt_last_error", "rt_version",
+    "rt_measure_copy_bandwidth", "rt_calibrate_valu", "rt_split_probe", "rt_last_error", "rt_version", "rt_build_id",
 ]
 
 
@@ -46,7 +46,9 @@ class RtStats(ctypes.Structure):
     ]
 
     def as_dict(self) -> dict:
-        return {n: getattr(self, n) for n, _ in self._fields_ if n != "reserved"}
+        d = {n: getattr(self, n) for n, _ in self._fields_ if n != "reserved"}
+        d["lds_top_records"] = int(self.reserved[2])  # BVH records the persistent kernel staged in LDS
+        return d
 
 
 def build(verbose: bool = False) -> str:
@@ -99,6 +101,7 @@ def lib():
     vp, ci, cf = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
     L.rt_last_error.restype = ctypes.c_char_p
     L.rt_version.restype = ctypes.c_char_p
+    L.rt_build_id.restype = ctypes.c_char_p
     L.rt_scene_create.argtypes = [vp, ci, vp, vp, vp, ci, vp, ci, ctypes.POINTER(vp)]
     L.rt_scene_destroy.argtypes = [vp]
     L.rt_scene_destroy.restype = None
@@ -119,6 +122,11 @@ def lib():
     L.rt_split_probe.argtypes = [vp, vp, ci, ci, ci, ci, ctypes.c_uint64, ctypes.c_int64, vp, ci]
     _lib = L
     return L
+
+
+def build_id() -> str:
+    """Hash of the sources + flags the LOADED library's device code was built from (rt_build_id)."""
+    return lib().rt_build_id().decode()
 
 
 def _check(rc: int, what: str) -> None:

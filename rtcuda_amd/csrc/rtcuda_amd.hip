@@ -2105,6 +2105,19 @@ struct rt_scene {
     int *d_order = nullptr;       // leaf order -> original
     std::vector<int> h_order;     // leaf order -> original
     std::vector<int> h_inverse;   // original -> leaf order
+    rt_scene() = default;
+    rt_scene(const rt_scene &) = delete;
+    rt_scene &operator=(const rt_scene &) = delete;
+    ~rt_scene() {  // (every early return of rt_scene_create goes through here: nothing leaks on an error path)
+        (void)hipFree(d_nodes);
+        (void)hipFree(d_tris);
+        (void)hipFree(d_tri_info);
+        (void)hipFree(d_tri_shade);
+        (void)hipFree(d_mats);
+        (void)hipFree(d_lights);
+        (void)hipFree(d_order);
+        (void)hipFree(d_tables);
+    }
     DScene dev() const {
         DScene s;
         s.nodes = d_nodes;
@@ -2261,6 +2274,24 @@ bool validate_quads(const std::vector<rtbvh::Pair> &quads, int n_tris) {
     return visited == nr / 2 && tris == n_tris;
 }
 
+// Device temporaries and events of one host call: released on EVERY return path (HIP_TRY returns early on errors)
+struct DevScope {
+    std::vector<void *> ptrs;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    ~DevScope() {
+        for (void *q : ptrs) (void)hipFree(q);
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+    }
+    template <typename T>
+    int alloc(T *&ptr, size_t count) {
+        void *raw = nullptr;
+        HIP_TRY(hipMalloc(&raw, std::max<size_t>(count, 1) * sizeof(T)));
+        ptrs.push_back(raw);
+        ptr = (T *)raw;
+        return 0;
+    }
+};
 // Device LBVH build: returns the pair records and the leaf order on the host (the caller uploads them
 // like the host builder's output).  n >= 2.
 int build_lbvh_device(const float *verts_host, int n, std::vector<rtbvh::Pair> &pairs, std::vector<int32_t> &order,
@@ -2278,23 +2309,17 @@ int build_lbvh_device(const float *verts_host, int n, std::vector<rtbvh::Pair> &
     float *d_verts = nullptr, *d_boxes = nullptr, *d_pairs = nullptr;
     unsigned long long *d_keys = nullptr;
     int *d_left = nullptr, *d_right = nullptr, *d_pi = nullptr, *d_pl = nullptr, *d_depth = nullptr, *d_arr = nullptr, *d_order = nullptr;
-    HIP_TRY(hipMalloc((void **)&d_verts, sizeof(float) * 9 * (size_t)n));
-    HIP_TRY(hipMalloc((void **)&d_keys, sizeof(unsigned long long) * (size_t)n_pad));
-    HIP_TRY(hipMalloc((void **)&d_left, sizeof(int) * (size_t)n));
-    HIP_TRY(hipMalloc((void **)&d_right, sizeof(int) * (size_t)n));
-    HIP_TRY(hipMalloc((void **)&d_pi, sizeof(int) * (size_t)n));
-    HIP_TRY(hipMalloc((void **)&d_pl, sizeof(int) * (size_t)n));
-    HIP_TRY(hipMalloc((void **)&d_depth, sizeof(int) * (size_t)n));
-    HIP_TRY(hipMalloc((void **)&d_arr, sizeof(int) * (size_t)n));
-    HIP_TRY(hipMalloc((void **)&d_order, sizeof(int) * (size_t)n));
-    HIP_TRY(hipMalloc((void **)&d_boxes, sizeof(float) * 6 * (size_t)n));
-    HIP_TRY(hipMalloc((void **)&d_pairs, sizeof(float) * 16 * (size_t)n));
+    DevScope tmp;  // the eleven temporaries and both events go away on every return path
+    if (tmp.alloc(d_verts, 9 * (size_t)n) || tmp.alloc(d_keys, (size_t)n_pad) || tmp.alloc(d_left, (size_t)n) ||
+        tmp.alloc(d_right, (size_t)n) || tmp.alloc(d_pi, (size_t)n) || tmp.alloc(d_pl, (size_t)n) || tmp.alloc(d_depth, (size_t)n) ||
+        tmp.alloc(d_arr, (size_t)n) || tmp.alloc(d_order, (size_t)n) || tmp.alloc(d_boxes, 6 * (size_t)n) || tmp.alloc(d_pairs, 16 * (size_t)n))
+        return 1;
     HIP_TRY(hipMemcpy(d_verts, verts_host, sizeof(float) * 9 * (size_t)n, hipMemcpyHostToDevice));
     HIP_TRY(hipMemset(d_arr, 0, sizeof(int) * (size_t)n));
     HIP_TRY(hipMemset(d_depth, 0, sizeof(int) * (size_t)n));
-    hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(hipEventCreate(&tmp.e0));
+    HIP_TRY(hipEventCreate(&tmp.e1));
+    const hipEvent_t e0 = tmp.e0, e1 = tmp.e1;
     HIP_TRY(hipEventRecord(e0, nullptr));
     const dim3 blk(256);
     hipLaunchKernelGGL(k_lbvh_keys, dim3((n_pad + 255) / 256), blk, 0, nullptr, d_verts, n, n_pad, lo[0], lo[1], lo[2], sc3[0],
@@ -2318,10 +2343,6 @@ int build_lbvh_device(const float *verts_host, int n, std::vector<rtbvh::Pair> &
     HIP_TRY(hipMemcpy(pairs.data(), d_pairs, sizeof(rtbvh::Pair) * (size_t)(n - 1), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(order.data(), d_order, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(&depth, d_depth, sizeof(int), hipMemcpyDeviceToHost));  // depth of the root
-    HIP_TRY(hipEventDestroy(e0));
-    HIP_TRY(hipEventDestroy(e1));
-    void *frees[] = {d_verts, d_keys, d_left, d_right, d_pi, d_pl, d_depth, d_arr, d_order, d_boxes, d_pairs};
-    for (void *f : frees) (void)hipFree(f);
     return 0;
 }
 
@@ -2586,6 +2607,7 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
     bool persistent = true;
     if (const char *e = getenv("RT_PERSISTENT")) persistent = atoi(e) != 0;
     float ms_paths = 0.f;
+    int top_records_in_lds = 0;
     if (persistent) {
         const int paths_cap = lds_stack_cap(scene, 8);
         int *const d_over2 = d_over;
@@ -2622,6 +2644,7 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
             if (const char *e = getenv("RT_TOP_NODES")) top_n = scene->top_prefix ? std::max(0, std::min(std::min(768, atoi(e)), prefix)) : 0;
             if (scene->wide) top_n &= ~1;  // whole nodes
             lds_paths += (size_t)top_n * 64;
+            top_records_in_lds = top_n;
         }
         // lanes waiting for the ADV block before it runs: full pool flat 22..26 on the 4-wide tree (24 + GEN 8: +1.5 % over
         // 30 + 6), the 2-waves-per-SIMD shards want 30..38 (24: -2.5 %)
@@ -2825,6 +2848,7 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
             stats->launches_trace = 1;
             stats->reserved[0] = 1;
             stats->reserved[1] = 1;
+            stats->reserved[2] = top_records_in_lds;
         }
     }
     return 0;
@@ -2880,6 +2904,7 @@ int render_overlapped(const rt_scene *scene, const rt_camera *camera, int width,
             tot.seconds_render = std::max(tot.seconds_render, sub[k].seconds_render);
             tot.seconds_rng_init = std::max(tot.seconds_rng_init, sub[k].seconds_rng_init);
             tot.reserved[0] += sub[k].reserved[0];
+            tot.reserved[2] = std::max(tot.reserved[2], sub[k].reserved[2]);
         }
         *stats = tot;
     }
@@ -2890,23 +2915,6 @@ int render_overlapped(const rt_scene *scene, const rt_camera *camera, int width,
 
 // ---- split probe: see the kernels (k_probe_*) for what is measured
 namespace {
-struct ProbeBufs {  // freed on every return path
-    std::vector<void *> ptrs;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    ~ProbeBufs() {
-        for (void *q : ptrs) (void)hipFree(q);
-        if (e0) (void)hipEventDestroy(e0);
-        if (e1) (void)hipEventDestroy(e1);
-    }
-    template <typename T>
-    int alloc(T *&ptr, size_t count) {
-        void *raw = nullptr;
-        HIP_TRY(hipMalloc(&raw, std::max<size_t>(count, 1) * sizeof(T)));
-        ptrs.push_back(raw);
-        ptr = (T *)raw;
-        return 0;
-    }
-};
 template <int MODE, bool WIDE, int MINW>
 int probe_trace_once(const rt_scene *scene, const TraceParams &tp, int stack_cap, int *d_over, int cus, hipEvent_t e0,
                      hipEvent_t e1, double *seconds, double *blocks_per_cu) {
@@ -2949,6 +2957,10 @@ extern "C" {
 
 const char *rt_last_error(void) { return g_last_error.c_str(); }
 const char *rt_version(void) { return "rtcuda_amd 0.1 (gfx950)"; }
+#ifndef RT_BUILD_ID
+#define RT_BUILD_ID "unknown"
+#endif
+const char *rt_build_id(void) { return RT_BUILD_ID; }
 
 int rt_scene_create(const float *tri_p0p1p2, int n_tris, const int32_t *tri_material, const int32_t *tri_light,
                     const rt_material *materials, int n_materials, const rt_light *lights, int n_lights,
@@ -3006,7 +3018,9 @@ int rt_scene_create(const float *tri_p0p1p2, int n_tris, const int32_t *tri_mate
     sc->n_tris = n_tris;
     sc->wide = true;  // 4-wide nodes (two pair-style records each): half the dependent fetches per ray; RT_BVH_WIDE=0: 2-wide
     if (const char *e = getenv("RT_BVH_WIDE")) sc->wide = atoi(e) != 0;
-    if (sc->wide && sc->builder == 1 && bvh.stack_bound > kMaxStackBound) sc->wide = false;  // (a very deep LBVH: 1 entry per level)
+    // a tree too deep for the 4-wide walk's stack (up to 3 entries per level) may still fit the 2-wide walk's (1 per level):
+    // a very deep LBVH, or a host tree the reinsertion pass deepened
+    if (sc->wide && bvh.stack_bound > kMaxStackBound) sc->wide = false;
     if ((sc->wide ? bvh.stack_bound : bvh.pair_depth + 1) > kMaxStackBound)
         return fail("rt_scene_create: BVH depth " + std::to_string(sc->wide ? bvh.max_depth : bvh.pair_depth) + " exceeds the traversal stack");
     sc->n_nodes = sc->wide ? (int)bvh.quads.size() : (int)bvh.pairs.size();  // 64-byte records
@@ -3101,18 +3115,7 @@ int rt_scene_create(const float *tri_p0p1p2, int n_tris, const int32_t *tri_mate
     return 0;
 }
 
-void rt_scene_destroy(rt_scene *scene) {
-    if (!scene) return;
-    (void)hipFree(scene->d_nodes);
-    (void)hipFree(scene->d_tris);
-    (void)hipFree(scene->d_tri_info);
-    (void)hipFree(scene->d_tri_shade);
-    (void)hipFree(scene->d_mats);
-    (void)hipFree(scene->d_lights);
-    (void)hipFree(scene->d_order);
-    (void)hipFree(scene->d_tables);
-    delete scene;
-}
+void rt_scene_destroy(rt_scene *scene) { delete scene; }  // (~rt_scene frees the device arrays)
 
 int rt_scene_info(const rt_scene *scene, int64_t out[4]) {
     if (!scene || !out) return fail("rt_scene_info: null argument");
@@ -3245,13 +3248,10 @@ int rt_trace_closest(const rt_scene *scene, int n, const float *origin_xyz, cons
     if (n == 0) return 0;
     float *d_o, *d_d, *d_tm, *d_t, *d_u, *d_v;
     int *d_h;
-    HIP_TRY(hipMalloc((void **)&d_o, sizeof(float) * 3 * (size_t)n));
-    HIP_TRY(hipMalloc((void **)&d_d, sizeof(float) * 3 * (size_t)n));
-    HIP_TRY(hipMalloc((void **)&d_tm, sizeof(float) * (size_t)n));
-    HIP_TRY(hipMalloc((void **)&d_t, sizeof(float) * (size_t)n));
-    HIP_TRY(hipMalloc((void **)&d_u, sizeof(float) * (size_t)n));
-    HIP_TRY(hipMalloc((void **)&d_v, sizeof(float) * (size_t)n));
-    HIP_TRY(hipMalloc((void **)&d_h, sizeof(int) * (size_t)n));
+    DevScope tmp;
+    if (tmp.alloc(d_o, 3 * (size_t)n) || tmp.alloc(d_d, 3 * (size_t)n) || tmp.alloc(d_tm, (size_t)n) || tmp.alloc(d_t, (size_t)n) ||
+        tmp.alloc(d_u, (size_t)n) || tmp.alloc(d_v, (size_t)n) || tmp.alloc(d_h, (size_t)n))
+        return 1;
     HIP_TRY(hipMemcpy(d_o, origin_xyz, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d_d, dir_xyz, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d_tm, tmax, sizeof(float) * (size_t)n, hipMemcpyHostToDevice));
@@ -3260,6 +3260,7 @@ int rt_trace_closest(const rt_scene *scene, int n, const float *origin_xyz, cons
     int *d_over = nullptr;
     int over_levels = 0;
     if (ensure_overflow(d_over, over_levels, scene->stack_bound - stack_cap)) return 1;
+    tmp.ptrs.push_back(d_over);
     {
         TraceParams tp{};
         tp.total = n;
@@ -3280,8 +3281,6 @@ int rt_trace_closest(const rt_scene *scene, int n, const float *origin_xyz, cons
     HIP_TRY(hipMemcpy(t, d_t, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(u, d_u, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(v, d_v, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost));
-    (void)hipFree(d_o); (void)hipFree(d_d); (void)hipFree(d_tm); (void)hipFree(d_t);
-    (void)hipFree(d_u); (void)hipFree(d_v); (void)hipFree(d_h); (void)hipFree(d_over);
     return 0;
 }
 
@@ -3297,11 +3296,10 @@ int rt_trace_any(const rt_scene *scene, int n, const float *origin_xyz, const fl
     }
     float *d_o, *d_d, *d_tm;
     int *d_e, *d_occ;
-    HIP_TRY(hipMalloc((void **)&d_o, sizeof(float) * 3 * (size_t)n));
-    HIP_TRY(hipMalloc((void **)&d_d, sizeof(float) * 3 * (size_t)n));
-    HIP_TRY(hipMalloc((void **)&d_tm, sizeof(float) * (size_t)n));
-    HIP_TRY(hipMalloc((void **)&d_e, sizeof(int) * (size_t)n));
-    HIP_TRY(hipMalloc((void **)&d_occ, sizeof(int) * (size_t)n));
+    DevScope tmp;
+    if (tmp.alloc(d_o, 3 * (size_t)n) || tmp.alloc(d_d, 3 * (size_t)n) || tmp.alloc(d_tm, (size_t)n) || tmp.alloc(d_e, (size_t)n) ||
+        tmp.alloc(d_occ, (size_t)n))
+        return 1;
     HIP_TRY(hipMemcpy(d_o, origin_xyz, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d_d, dir_xyz, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d_tm, tmax, sizeof(float) * (size_t)n, hipMemcpyHostToDevice));
@@ -3311,6 +3309,7 @@ int rt_trace_any(const rt_scene *scene, int n, const float *origin_xyz, const fl
     int *d_over = nullptr;
     int over_levels = 0;
     if (ensure_overflow(d_over, over_levels, scene->stack_bound - stack_cap)) return 1;
+    tmp.ptrs.push_back(d_over);
     {
         TraceParams tp{};
         tp.total = n;
@@ -3325,8 +3324,6 @@ int rt_trace_any(const rt_scene *scene, int n, const float *origin_xyz, const fl
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(occluded, d_occ, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost));
-    (void)hipFree(d_o); (void)hipFree(d_d); (void)hipFree(d_tm); (void)hipFree(d_e); (void)hipFree(d_occ);
-    (void)hipFree(d_over);
     return 0;
 }
 
@@ -3337,12 +3334,12 @@ int rt_xorwow_states(uint64_t seed, uint32_t first, uint32_t count, int draws, u
     DPools p{};
     uint32_t *buf = nullptr, *d_state = nullptr, *d_jump = nullptr;
     float *d_uni = nullptr;
-    HIP_TRY(hipMalloc((void **)&buf, sizeof(uint32_t) * 6 * (size_t)count));
+    DevScope tmp;
+    if (tmp.alloc(buf, 6 * (size_t)count) || tmp.alloc(d_state, 6 * (size_t)count) || tmp.alloc(d_uni, (size_t)count * draws) ||
+        tmp.alloc(d_jump, (size_t)20 * 800))
+        return 1;
     p.n = (int)count;  // only the six RNG arrays are touched: place array A_RD at buf
     p.base = (float *)buf - (size_t)A_RD * count;
-    HIP_TRY(hipMalloc((void **)&d_state, sizeof(uint32_t) * 6 * (size_t)count));
-    HIP_TRY(hipMalloc((void **)&d_uni, sizeof(float) * std::max<size_t>(1, (size_t)count * draws)));
-    HIP_TRY(hipMalloc((void **)&d_jump, sizeof(uint32_t) * 20 * 800));
     HIP_TRY(hipMemcpy(d_jump, jump_powers().data(), sizeof(uint32_t) * 20 * 800, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_rng_init, dim3(grid_for((int)count)), dim3(kBlock), 0, nullptr, p, (int)count, (int)first,
                        xorwow_seed(seed), d_jump);
@@ -3351,7 +3348,6 @@ int rt_xorwow_states(uint64_t seed, uint32_t first, uint32_t count, int draws, u
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(state6, d_state, sizeof(uint32_t) * 6 * (size_t)count, hipMemcpyDeviceToHost));
     if (draws > 0) HIP_TRY(hipMemcpy(uniforms, d_uni, sizeof(float) * (size_t)count * draws, hipMemcpyDeviceToHost));
-    (void)hipFree(buf); (void)hipFree(d_state); (void)hipFree(d_uni); (void)hipFree(d_jump);
     return 0;
 }
 
@@ -3359,12 +3355,12 @@ int rt_measure_copy_bandwidth(int64_t bytes, int reps, double *out_bytes_per_s) 
     if (bytes < 1024 || reps < 1 || !out_bytes_per_s) return fail("rt_measure_copy_bandwidth: bad argument");
     size_t n4 = (size_t)bytes / 16;
     float4 *a = nullptr, *b = nullptr;
-    HIP_TRY(hipMalloc((void **)&a, n4 * 16));
-    HIP_TRY(hipMalloc((void **)&b, n4 * 16));
+    DevScope tmp;
+    if (tmp.alloc(a, n4) || tmp.alloc(b, n4)) return 1;
     HIP_TRY(hipMemset(a, 1, n4 * 16));
-    hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(hipEventCreate(&tmp.e0));
+    HIP_TRY(hipEventCreate(&tmp.e1));
+    const hipEvent_t e0 = tmp.e0, e1 = tmp.e1;
     double best = 0.0;
     for (int r = 0; r < reps + 1; r++) {
         HIP_TRY(hipEventRecord(e0, nullptr));
@@ -3375,10 +3371,6 @@ int rt_measure_copy_bandwidth(int64_t bytes, int reps, double *out_bytes_per_s) 
         HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
         if (r > 0 && ms > 0.f) best = std::max(best, 2.0 * (double)n4 * 16.0 / (ms * 1e-3));
     }
-    HIP_TRY(hipEventDestroy(e0));
-    HIP_TRY(hipEventDestroy(e1));
-    (void)hipFree(a);
-    (void)hipFree(b);
     *out_bytes_per_s = best;
     return 0;
 }
@@ -3391,10 +3383,11 @@ int rt_calibrate_valu(int waves_per_simd, int iters, double *out_lane_ops_per_s,
     // one 256-thread workgroup = one wave on each of a CU's four SIMDs
     const int blocks = cus * waves_per_simd;
     float *d_out = nullptr;
-    HIP_TRY(hipMalloc((void **)&d_out, sizeof(float) * (size_t)blocks * 256));
-    hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
+    DevScope tmp;
+    if (tmp.alloc(d_out, (size_t)blocks * 256)) return 1;
+    HIP_TRY(hipEventCreate(&tmp.e0));
+    HIP_TRY(hipEventCreate(&tmp.e1));
+    const hipEvent_t e0 = tmp.e0, e1 = tmp.e1;
     double best = 0.0;
     for (int r = 0; r < 7; r++) {  // (first launch untimed; clocks ramp: the best of six)
         HIP_TRY(hipEventRecord(e0, nullptr));
@@ -3407,9 +3400,6 @@ int rt_calibrate_valu(int waves_per_simd, int iters, double *out_lane_ops_per_s,
         if (r > 0 && ms > 0.f) best = std::max(best, lane_ops / (ms * 1e-3));
     }
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventDestroy(e0));
-    HIP_TRY(hipEventDestroy(e1));
-    (void)hipFree(d_out);
     *out_lane_ops_per_s = best;
     if (out_wave_instr) *out_wave_instr = (double)blocks * 4.0 * 16.0 * (double)iters;  // v_fma_f32 wave-instructions per launch
     return 0;
@@ -3434,7 +3424,7 @@ int rt_split_probe(const rt_scene *scene, const rt_camera *camera, int width, in
     std::lock_guard<std::mutex> busy_lock(c.busy);
     double rng_seconds = 0.0;
     if (ensure_rng(c, seed, 0, nullptr, &rng_seconds)) return 1;
-    ProbeBufs pb;
+    DevScope pb;
     HIP_TRY(hipEventCreate(&pb.e0));
     HIP_TRY(hipEventCreate(&pb.e1));
     const unsigned cap = (unsigned)(target_rays + 2 * (long long)kW);

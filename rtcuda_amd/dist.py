@@ -49,6 +49,20 @@ def frame_step(zero, render_local, local_sum, post_process, rank: int, dst: int 
     return stats
 
 
+def agree_on_failure(failed: bool, group=None) -> bool:
+    """True on EVERY rank if any rank failed (one MAX all-reduce of a flag).  A rank that raised on its own in the
+    middle of a step would leave its peers blocked in the next collective for ever."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+        return bool(failed)
+    t = torch.tensor([1 if failed else 0], dtype=torch.int32)
+    if dist.get_backend(group) == "nccl":
+        t = t.cuda()
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return bool(int(t.item()))
+
+
 def timed_frames(step, steps: int, warmup: int, device_sync=None, group=None) -> float:
     """bench.py's timing contract: ``warmup`` untimed steps, then exactly ``steps`` steps bracketed by a barrier and a
     device synchronisation on both sides; returns the MAX over ranks of the elapsed seconds (every rank gets it)."""

@@ -119,6 +119,31 @@ static int unit() {
     Bvh bvh(tris, prims);
     Scene scene = {bvh, 1, lights.data()};
     printf("point_light=%d %d\n", (int)scene.d_lights[0].type, scene.bvh.num_primitives);
+    // the reference's host PODs around a Triangle: members {p0, e1, e2, n}, accessors, BoundingBox, Intersection, Ray
+    // (triangle.cuh:4-37, bounding_box.cuh:4-37, intersection.hpp:4-6, ray.cuh:4-25); the light triangle of SURVEY Appendix C
+    Triangle lt(Vec3(0.4f, 0.999f, -0.4f), Vec3(0.6f, 0.999f, -0.4f), Vec3(0.6f, 0.999f, -0.6f));
+    show("tri_e1", lt.e1); show("tri_e2", lt.e2); show("tri_n", lt.n);
+    show("tri_p1", lt.p1()); show("tri_p2", lt.p2()); show("tri_center", lt.center());
+    show("tri_puv", lt.p(0.25f, 0.5f));
+    printf("tri_area=%.9g\n", lt.area());
+    BoundingBox bb = lt.bounding_box();
+    printf("tri_bbox=%.9g %.9g %.9g %.9g %.9g %.9g\n", bb.bounds[0], bb.bounds[1], bb.bounds[2], bb.bounds[3], bb.bounds[4], bb.bounds[5]);
+    BoundingBox acc = BoundingBox::Empty();
+    printf("bbox_empty=%d\n", acc.bounds[0] == FLT_MAX && acc.bounds[1] == -FLT_MAX && acc.bounds[5] == -FLT_MAX ? 1 : 0);
+    acc.extend(bb);
+    acc.extend(BoundingBox(0.f, 1.f, 0.f, 0.5f, -1.f, 0.f));
+    printf("bbox_ext=%.9g %.9g %.9g %.9g %.9g %.9g\n", acc.bounds[0], acc.bounds[1], acc.bounds[2], acc.bounds[3], acc.bounds[4], acc.bounds[5]);
+    printf("bbox_half_area=%.9g\n", acc.half_area());
+    acc.reset();
+    printf("bbox_reset=%d\n", acc.bounds[2] == FLT_MAX && acc.bounds[3] == -FLT_MAX ? 1 : 0);
+    Intersection isect = {0.799000025f, 0.500000119f, 0.249999881f};
+    Ray ray(Vec3(0.55f, 0.2f, -0.45f), Vec3(0.f, 1.f, 0.f));
+    printf("ray_tmax_default=%d\n", ray.tmax == FLT_MAX ? 1 : 0);
+    show("ray_at", ray.at(isect.t));
+    show("offset_a", offset_ray_origin(Vec3(0.3f, 0.02f, -0.7f), Vec3(0.f, 1.f, 0.f)));
+    Ray sp = Ray::spawn_offset_ray(Vec3(0.3f, 0.5f, -0.7f), Vec3(0.6f, -0.8f, 0.f), Vec3(0.f, 0.f, 1.f), 2.5f);
+    show("offset_b", sp.origin);
+    printf("spawn_tmax=%.9g\n", sp.tmax);
     return 0;
 }
 

@@ -22,6 +22,9 @@ CASES = [("matte", 32, 32, 16), ("full_bsdf", 48, 27, 8), ("sixteen_lights", 40,
          ("full_bsdf", 128, 72, 256), ("matte", 100, 60, 400)]
 
 
+LITERAL_CASES = [("matte", 160, 100, 160), ("full_bsdf", 128, 72, 256)]  # 2.44 / 2.25 generations
+
+
 def main():
     build()
     orc = Oracle("pinned")
@@ -41,6 +44,18 @@ def main():
         key = f"{variant}_{w}x{h}x{spp}"
         out[key + "_img"] = img
         out[key + "_sum"] = raw
+        out[key + "_counts"] = np.array([st["sum_mat"], st["sum_ah"], st["emission_adds"], st["ah_adds"],
+                                         st["rr_draws"], w * h * spp], np.int64)
+        print(key, out[key + "_counts"].tolist(), img.reshape(-1, 3).mean(0))
+    # ONE fixture from the LITERAL oracle (the reference's own fp32 slab test and tree-order tie rule, aabb_intersector.cuh:
+    # 14-36, triangle.cuh:49): the product is held against it at the audited tolerance (tests/test_traversal_audit.py: the
+    # reference's walk loses about one accepted hit in 10^7 rays), so that an edit of the oracle's watertight mode cannot move
+    # both sides of every strict comparison at once.
+    for variant, w, h, spp in LITERAL_CASES:
+        cam = orc.camera((0.5, 0.5, 1.5), (0.5, 0.5, 0.0), (0.0, 1.0, 0.0), 37.8, w / h)
+        img, raw, st = orc.scene(scenes.cornell_bunny(variant)).render(cam, w, h, spp, threads=8)
+        key = f"literal_{variant}_{w}x{h}x{spp}"
+        out[key + "_img"] = img
         out[key + "_counts"] = np.array([st["sum_mat"], st["sum_ah"], st["emission_adds"], st["ah_adds"],
                                          st["rr_draws"], w * h * spp], np.int64)
         print(key, out[key + "_counts"].tolist(), img.reshape(-1, 3).mean(0))

@@ -127,3 +127,39 @@ def test_two_rank_shards_reduce_to_the_full_frame(tmp_path, oracle):
     assert int(got["mats"][0]) == st["sum_mat"]
     assert np.allclose(got["total"], full, rtol=1e-5, atol=1e-6)
     assert full.sum() > 0
+
+
+def _failure_worker(rank, world, port, out_dir):
+    """One rank sees a work-count mismatch in a timed step: as in bench.py it only RECORDS it, finishes the collective
+    sequence with its peers, and all ranks learn of it together (rtdist.agree_on_failure)."""
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from rtcuda_amd import dist as rtdist
+    local = torch.ones(8)
+    failed = {"flag": False}
+
+    def step():
+        rtdist.frame_step(local.zero_, lambda: {}, local, lambda: None, rank)
+        if rank == 1:
+            failed["flag"] = True  # (bench.py: the camera-ray count of the step is off)
+
+    rtdist.timed_frames(step, steps=2, warmup=0)
+    agreed = rtdist.agree_on_failure(failed["flag"])
+    none = rtdist.agree_on_failure(False)
+    with open(os.path.join(out_dir, f"fail{rank}.txt"), "w") as fh:
+        fh.write(f"{int(agreed)} {int(none)}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_a_failing_rank_does_not_strand_its_peers(tmp_path):
+    import torch.multiprocessing as mp
+    from rtcuda_amd import dist as rtdist
+    mp.spawn(_failure_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "fail0.txt").read_text() == "1 0"  # rank 0 did not fail itself, but knows
+    assert (tmp_path / "fail1.txt").read_text() == "1 0"
+    assert rtdist.agree_on_failure(True) is True and rtdist.agree_on_failure(False) is False  # single process

@@ -108,6 +108,53 @@ def test_trace_any_matches_oracle(api, oracle, gpu_matte, cpu_matte, bunny_matte
                                    np.zeros(0, np.float32), np.zeros(0, np.int32))) == 0
 
 
+# Path ray 1 836 499 of the matte 256 x 256 x 40 frame (bit patterns): the reference's walk returns wall triangle 69458
+# behind light triangle 69462 (tests/test_traversal_audit.py pins it on the CPU twin of the product's walk)
+KNOWN_MISS_O = np.array([1052665855, 1062038174, 3212836608], np.uint32).view(np.float32).reshape(1, 3)
+KNOWN_MISS_D = np.array([1048527110, 1054521025, 1063157561], np.uint32).view(np.float32).reshape(1, 3)
+_raylog = {}
+
+
+def _watertight_ray_log(oracle, bunny_matte):
+    """Every ray of a 160 x 160 x 8 watertight-oracle render of the matte scene (~0.8 M rays), with the oracle's results."""
+    if not _raylog:
+        sc = oracle.scene(bunny_matte).set_watertight(True)
+        oracle.raylog_enable(True)
+        sc.render(default_camera(oracle, 1.0), 160, 160, 8, threads=__import__("os").cpu_count() or 8)
+        _raylog.update(oracle.raylog_fetch())
+        oracle.raylog_enable(False)
+        brute = sc.trace_closest_brute(KNOWN_MISS_O, KNOWN_MISS_D, np.full(1, FLT_MAX, np.float32))
+        _raylog["miss_tri"], _raylog["miss_t"] = int(brute[0][0]), brute[1][0]
+    return _raylog
+
+
+@pytest.mark.parametrize("env", [{}, {"RT_BVH_WIDE": "0"}, {"RT_STACK_CAP": "2"}, {"RT_BVH_WIDE": "0", "RT_STACK_CAP": "2"}],
+                         ids=["wide", "pairs", "wide-overflow", "pairs-overflow"])
+def test_oracle_ray_log_replayed_ray_by_ray(api, oracle, bunny_matte, monkeypatch, env):
+    """The GPU arithmetic itself (v_rcp_f32 for 1/d, the one-comparison packed box test, the overflow stack), ray by
+    ray: every path and shadow ray of an oracle render goes through rt_trace_closest / rt_trace_any and must come back
+    with the watertight oracle's answer -- triangle index and t bit for bit, ties included, occlusion flag -- for both
+    node formats and with the traversal stack forced through its global overflow part.  The ray the reference's own
+    walk gets wrong (KNOWN_MISS) is one of them."""
+    log = _watertight_ray_log(oracle, bunny_matte)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    gpu = api.Scene(bunny_matte)  # (RT_BVH_WIDE is read at scene creation)
+    o = np.concatenate([log["closest_o"], KNOWN_MISS_O])
+    d = np.concatenate([log["closest_d"], KNOWN_MISS_D])
+    tri, t, _, _ = gpu.trace_closest(o, d, np.full(len(o), FLT_MAX, np.float32))
+    want_tri = np.concatenate([log["closest_tri"], [log["miss_tri"]]])
+    want_t = np.concatenate([log["closest_t"], [log["miss_t"]]])
+    assert log["miss_tri"] == 69462
+    assert np.array_equal(tri, want_tri)
+    hit = want_tri >= 0
+    assert np.array_equal(t[hit].view(np.uint32), want_t[hit].astype(np.float32).view(np.uint32))
+    occ = gpu.trace_any(log["any_o"], log["any_d"], log["any_tmax"], log["any_excluded"])
+    assert np.array_equal(occ, log["any_occluded"])
+    gpu.close()
+    assert len(o) > 500_000 and len(occ) > 200_000
+
+
 def _rms(a, b):
     return np.sqrt(np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2, axis=(0, 1)))
 

@@ -183,6 +183,30 @@ def test_cpp_vec3_matrix_transform_known_answers(exe):
     assert got["applied"][0] == float(f(ref[0])) and got["applied"][1] == float(f(ref[1]))  # x, y rounded to fp32
     assert got["applied"][2] == ref[2]                                                       # z kept in double
     assert got["point_light"] == [0.0, 1.0]
+    # ---- host PODs (row a30): Triangle members / accessors, BoundingBox, Intersection, Ray
+    p0, p1, p2 = np.array([0.4, 0.999, -0.4], f), np.array([0.6, 0.999, -0.4], f), np.array([0.6, 0.999, -0.6], f)
+    e1, e2 = p0 - p1, p2 - p0
+    n = np.array([e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]], f)
+    eq("tri_e1", e1); eq("tri_e2", e2); eq("tri_n", n)
+    assert f(got["tri_e1"][0]) == f(-0.200000018) and f(got["tri_n"][1]) == f(-0.0400000066)
+    eq("tri_p1", p0 - e1); eq("tri_p2", p0 + e2)  # the reference's rounded reconstructions (triangle.cuh:9-10)
+    eq("tri_center", ((p0 + (p0 - e1)) + (p0 + e2)) * (f(1) / f(3)))
+    eq("tri_puv", (p0 - f(0.25) * e1) + f(0.5) * e2)
+    nl2 = f(f(n[0] * n[0]) + f(n[1] * n[1])) + f(n[2] * n[2])
+    eq("tri_area", f(0.5) * np.sqrt(nl2))
+    assert f(got["tri_area"][0]) == f(0.0200000033)
+    q1, q2 = p0 - e1, p0 + e2
+    eq("tri_bbox", [min(p0[0], q1[0], q2[0]), max(p0[0], q1[0], q2[0]), min(p0[1], q1[1], q2[1]),
+                    max(p0[1], q1[1], q2[1]), min(p0[2], q1[2], q2[2]), max(p0[2], q1[2], q2[2])])
+    assert got["bbox_empty"] == [1.0] and got["bbox_reset"] == [1.0] and got["ray_tmax_default"] == [1.0]
+    ext = [0.0, 1.0, 0.0, float(max(p0[1], q1[1], q2[1])), -1.0, 0.0]
+    eq("bbox_ext", ext)
+    dx, dy, dz = f(ext[1]) - f(ext[0]), f(ext[3]) - f(ext[2]), f(ext[5]) - f(ext[4])
+    eq("bbox_half_area", f(f(dx + dy) * dz) + f(dx * dy))
+    eq("ray_at", np.array([0.55, 0.2, -0.45], f) + f(0.799000025) * np.array([0, 1, 0], f))
+    assert np.array(got["offset_a"], f).view(np.uint32).tolist() == [0x3E99999A, 0x3CA3F70A, 0xBF333333]  # Appendix C
+    assert np.array(got["offset_b"], f).view(np.uint32).tolist() == [0x3E999A33, 0x3EFFFF34, 0xBF333333]
+    assert got["spawn_tmax"] == [2.5]
 
 
 def test_stage_lines_have_the_reference_drivers_format(exe):

@@ -178,3 +178,27 @@ def test_oracle_shards_sum_to_full_image(oracle, bunny_matte):
         mats += st["sum_mat"]
     assert mats == st_full["sum_mat"]
     assert np.allclose(acc, full, rtol=1e-5, atol=1e-6)
+
+
+# ---- committed render fixtures (tests/golden/make_golden.py): the oracle still produces them, in BOTH of its modes
+GOLDEN = np.load(os.path.join(HERE, "golden", "render_goldens.npz"))
+AUDITED = ("sum_mat", "sum_ah", "emission_adds", "ah_adds", "rr_draws")
+
+
+def test_literal_and_watertight_fixtures_are_reproduced(oracle):
+    """`literal_*`: the reference's own slab test and tie rule (default mode) -- bit for bit.  The same frame in watertight
+    mode (what the strict GPU comparisons use) may differ from it only by the audited handful of rays (the reference's
+    walk loses about one accepted hit in 10^7: tests/test_traversal_audit.py), so neither mode can drift unnoticed."""
+    from rtcuda_amd import scenes
+    variant, w, h, spp = "matte", 160, 100, 160
+    key = f"literal_{variant}_{w}x{h}x{spp}"
+    sc = oracle.scene(scenes.cornell_bunny(variant))
+    cam = default_camera(oracle, w / h)
+    img, _, st = sc.render(cam, w, h, spp, threads=os.cpu_count() or 8)
+    assert [st[k] for k in AUDITED] + [w * h * spp] == GOLDEN[key + "_counts"].tolist()
+    assert np.array_equal(img.view(np.uint32), GOLDEN[key + "_img"].view(np.uint32))
+    img_w, _, st_w = sc.set_watertight(True).render(cam, w, h, spp, threads=os.cpu_count() or 8)
+    for k, want in zip(AUDITED, GOLDEN[key + "_counts"].tolist()):
+        assert abs(st_w[k] - want) <= 4, (k, st_w[k], want)
+    d = np.abs(img_w.astype(np.float64) - GOLDEN[key + "_img"])
+    assert (d.max(axis=2) > 1e-4).sum() <= 2 and np.sqrt(np.mean(d ** 2)) < 1e-4

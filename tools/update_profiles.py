@@ -12,6 +12,7 @@ import shutil
 import sys
 
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, root)
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 src = os.path.join(root, "gpurun_out", tag)
 dst = os.path.join(root, "profiles")
@@ -21,6 +22,12 @@ def counters(path, kernel="k_paths"):
     pmc = json.load(open(path))
     key = [k for k in pmc if kernel in k][0]
     return key, {n: v["mean_per_dispatch"] for n, v in pmc[key].items()}
+
+
+def build_id_of(d):
+    """The build the counters under `d` were collected on: tools/profile_scene.sh records rt_build_id() next to them."""
+    p = os.path.join(d, "build_id.txt")
+    return open(p).read().strip() if os.path.exists(p) else None
 
 
 table_path = os.path.join(dst, "pmc_k_paths.json")
@@ -33,7 +40,7 @@ for scene in ("full_bsdf", "four_bunnies", "sixteen_lights", "matte"):
     shutil.copy(os.path.join(d, "pmc_summary.json"), os.path.join(dst, f"{tag}_{scene}_pmc.json"))
     kname, c = counters(os.path.join(d, "pmc_summary.json"))
     gui = c["GRBM_GUI_ACTIVE"] / 8.0  # summed over the 8 XCDs
-    entry = {"kernel": "k_paths", "kernel_instance": kname,
+    entry = {"kernel": "k_paths", "kernel_instance": kname, "build_id": build_id_of(d),
              "SQ_INSTS_VALU": c["SQ_INSTS_VALU"], "SQ_ACTIVE_INST_VALU": c["SQ_ACTIVE_INST_VALU"],
              "SQ_THREAD_CYCLES_VALU": c["SQ_THREAD_CYCLES_VALU"], "SQ_INSTS_SALU": c["SQ_INSTS_SALU"],
              "SQ_INSTS_VMEM": c["SQ_INSTS_VMEM"], "SQ_INSTS_LDS": c["SQ_INSTS_LDS"],
