@@ -193,15 +193,16 @@ def main():
         np_src = "SURVEY.md Appendix C"
         out["parity"] = None
         if world == 1 and not args.no_cpu_baseline:
-            from oracle.oracle import Oracle
-            cores = max(1, os.cpu_count() or 1)  # all host cores of the node
+            from oracle.oracle import Oracle, usable_cpus
+            cores = usable_cpus()  # every CPU this process may use (all host cores; a box's cgroup quota caps it)
             orc = Oracle("pinned")
             osc = orc.scene(arrays)
             ocam = orc.camera((0.5, 0.5, 1.5), (0.5, 0.5, 0.0), (0.0, 1.0, 0.0), 37.8, w / h)
             oimg, _, ost = osc.render(ocam, w, h, args.cpu_spp, args.max_bounces, 1, threads=cores, collect_stats=True)
             cpu_v = w * h * args.cpu_spp / ost["seconds_loop"] / 1e6
             out["cpu_baseline"] = {
-                "value": round(cpu_v, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
+                "value": round(cpu_v, 4), "unit": "Msamples/s", "cores": cores, "host_logical_cpus": os.cpu_count(),
+                "kind": "port",
                 "sample": f"same scene and camera at {w}x{h}, {args.cpu_spp} spp ({w * h * args.cpu_spp} samples), "
                           f"render loop only ({ost['seconds_loop']:.1f} s; RNG init {ost['seconds_rng_init']:.2f} s "
                           f"reported apart), literal wavefront schedule, OpenMP over queue entries"}

@@ -29,6 +29,27 @@ def _ptr(a):
     return None if a is None else a.ctypes.data
 
 
+def usable_cpus() -> int:
+    """CPUs this process may actually use: the affinity mask capped by the cgroup's CPU quota.  (A GPU box shows 256
+    logical CPUs to a container that is allowed 16: 256 OpenMP threads on a 16-CPU quota run an oracle render ~10x slower.)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max",):
+        try:
+            quota, period = open(path).read().split()[:2]
+            if quota != "max":
+                n = min(n, max(1, int(int(quota) / int(period))))
+        except (OSError, ValueError):
+            pass
+    try:  # cgroup v1
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0:
+            n = min(n, max(1, q // per))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 class Oracle:
     """One loaded flavour of the oracle: ``"pinned"`` (default) or ``"libm"``."""
 

@@ -40,6 +40,11 @@ def bunny_full_bsdf():
     return scenes.cornell_bunny("full_bsdf")
 
 
+def usable_cpus():
+    from oracle.oracle import usable_cpus as _u
+    return _u()
+
+
 def default_camera(oracle, aspect):
     return oracle.camera((0.5, 0.5, 1.5), (0.5, 0.5, 0.0), (0.0, 1.0, 0.0), 37.8, aspect)
 
@@ -64,5 +69,5 @@ def oracle_render(oracle, variant, w, h, spp, max_bounces=10, seed=1, watertight
     if key not in _oracle_render_cache:
         sc = oracle_scene(oracle, variant, watertight)
         _oracle_render_cache[key] = sc.render(default_camera(oracle, w / h), w, h, spp, max_bounces=max_bounces, seed=seed,
-                                              slot_lo=slot_lo, slot_hi=slot_hi, threads=os.cpu_count() or 8)
+                                              slot_lo=slot_lo, slot_hi=slot_hi, threads=usable_cpus())
     return _oracle_render_cache[key]

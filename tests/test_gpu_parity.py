@@ -8,7 +8,7 @@ the oracle over several generations in tests/test_gpu_multigen.py."""
 import numpy as np
 import pytest
 
-from conftest import default_camera
+from conftest import default_camera, usable_cpus
 import raygen
 
 pytestmark = pytest.mark.gpu
@@ -120,7 +120,7 @@ def _watertight_ray_log(oracle, bunny_matte):
     if not _raylog:
         sc = oracle.scene(bunny_matte).set_watertight(True)
         oracle.raylog_enable(True)
-        sc.render(default_camera(oracle, 1.0), 160, 160, 8, threads=__import__("os").cpu_count() or 8)
+        sc.render(default_camera(oracle, 1.0), 160, 160, 8, threads=usable_cpus())
         _raylog.update(oracle.raylog_fetch())
         oracle.raylog_enable(False)
         brute = sc.trace_closest_brute(KNOWN_MISS_O, KNOWN_MISS_D, np.full(1, FLT_MAX, np.float32))

@@ -12,7 +12,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import default_camera
+from conftest import default_camera, usable_cpus
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 with open(os.path.join(HERE, "golden", "appendix_c.json")) as fh:
@@ -194,10 +194,10 @@ def test_literal_and_watertight_fixtures_are_reproduced(oracle):
     key = f"literal_{variant}_{w}x{h}x{spp}"
     sc = oracle.scene(scenes.cornell_bunny(variant))
     cam = default_camera(oracle, w / h)
-    img, _, st = sc.render(cam, w, h, spp, threads=os.cpu_count() or 8)
+    img, _, st = sc.render(cam, w, h, spp, threads=usable_cpus())
     assert [st[k] for k in AUDITED] + [w * h * spp] == GOLDEN[key + "_counts"].tolist()
     assert np.array_equal(img.view(np.uint32), GOLDEN[key + "_img"].view(np.uint32))
-    img_w, _, st_w = sc.set_watertight(True).render(cam, w, h, spp, threads=os.cpu_count() or 8)
+    img_w, _, st_w = sc.set_watertight(True).render(cam, w, h, spp, threads=usable_cpus())
     for k, want in zip(AUDITED, GOLDEN[key + "_counts"].tolist()):
         assert abs(st_w[k] - want) <= 4, (k, st_w[k], want)
     d = np.abs(img_w.astype(np.float64) - GOLDEN[key + "_img"])

@@ -18,7 +18,7 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np  # noqa: E402
 import torch  # noqa: E402,F401
-from oracle.oracle import Oracle  # noqa: E402
+from oracle.oracle import Oracle, usable_cpus  # noqa: E402
 from rtcuda_amd import api, scenes  # noqa: E402
 
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
@@ -36,7 +36,7 @@ out["k_paths"] = {g: int(st[g]) for g, _ in pairs}
 out["k_paths"]["seconds_render"] = st["seconds_render"]
 print("k_paths", out["k_paths"], flush=True, file=sys.stderr)
 orc = Oracle("pinned")
-cores = os.cpu_count() or 8
+cores = usable_cpus()
 cam = orc.camera((0.5, 0.5, 1.5), (0.5, 0.5, 0.0), (0.0, 1.0, 0.0), 37.8, w / h)
 
 
