@@ -1748,557 +1748,6 @@ k_paths(DScene sc, DPools p, Camera cam_arg, AdvanceParams ap_arg, float *__rest
     row_add(rows, v);
 }
 
-// ============================================================================ k_paths_pool
-// k_paths with the shading work POOLED over the four waves of a workgroup.
-//
-// In k_paths a wave runs its ADV block for whichever of its own lanes wait for it -- 32 of 64 on average, 12 of 64 in the
-// GEN block -- and those two blocks are a third of the wave's time.  But everything a shade or a gen() reads and writes
-// already lives in the slot's LDS COLUMN (slot state, sample sum; with the hit record and the spawned rays put there
-// too, nothing is left in the owner's registers), and LDS is shared by the workgroup.  So here a lane that needs shading
-// queues its COLUMN in a workgroup ring and goes on waiting; any wave of the workgroup that finds a full batch in a
-// ring takes 64 columns -- one per lane, whoever owns them -- and runs the block at 64 of 64 lanes; the owners find the
-// result in their column (a mail word) and carry on tracing.  Four waves fill a batch of 64 faster than one wave fills
-// its batch of 24, so the blocks are fuller AND the lanes wait less.
-//
-// The estimator, its arithmetic and the per-slot order of RNG draws are k_paths' (advance_core, gen_core, inner_step, the
-// triangle block): which lane executes a slot's shade has no influence on any value.
-//
-// Protocol (all in LDS, workgroup scope; LDS executes a wave's operations in order):
-//   owner:    hit record -> its idle stack rows; release; column -> ring[tail++] (one atomic per wave and push)
-//   worker:   ring counters read at every scheduling decision; the entries it would get (acquire), then ONE
-//             compare-and-swap on the ring's head claims them all (a failed claim costs nothing: the wave carries on
-//             with its own work); shade / gen on those columns; results -> the column's stack and parked-ray rows;
-//             release; mail word
-//   owner:    mail word read at every scheduling decision; acquire; rays -> registers
-// A wave only leaves the loop when none of its lanes traces or waits, and a wave with nothing else to do serves the
-// rings whatever their fill, so every queued column is served and every wave ends.
-enum { PW_NONE = 0, PW_SHADOW = 1, PW_PATH = 2, PW_BACK = 3 };  // mail: shadow + parked path ray / one ray / slot finished
-enum { PH_WAIT = 5 };
-constexpr int kRing = kBlock;     // a column is queued at most once, so 256 entries can never overflow (power of two)
-constexpr int kPoolRows = 27;     // rows of a column besides its stack rows: 9 parked ray + radiance, 15 slot state, 3 sample sum
-constexpr int kPoolMailRows = 8;  // stack rows a hit record (6) or a spawned shadow ray (8) occupies while the column is queued
-
-struct TravState {
-    V3 o, d, inv;
-    float tmax, hu, hv;
-    int cur, sp, tri, pend;
-};
-
-template <bool WIDE>
-__device__ __forceinline__ void pool_node_block(const DScene &sc, TravState &t, bool want, int *stack, int *over, int stack_cap) {
-    if (want) {
-        auto step = [&]() {
-            if (t.cur >= 0) {
-                inner_step<WIDE>(sc, t.o, t.inv, t.tmax, t.cur, t.sp, stack, over, stack_cap);
-            } else if (kSpeculate && t.cur != kEntryDone && t.pend == kEntryDone && t.sp > 0) {
-                t.pend = t.cur;  // a leaf: set it aside, go on with the next entry
-                t.cur = stack_pop(stack, over, t.sp, stack_cap);
-            }
-        };
-        if (kNodeCont == 0 || !WIDE) {
-#pragma unroll
-            for (int rep = 0; rep < (WIDE ? kNodePerStepWide : kNodePerStep); rep++) step();
-        } else {
-#pragma unroll
-            for (int rep = 0; rep < kNodePerStepWide; rep++) step();
-            if (wave_count(t.cur >= 0) >= kNodeCont) {
-#pragma unroll
-                for (int rep = 0; rep < kNodeExtra; rep++) step();
-            }
-        }
-    }
-}
-__device__ __forceinline__ void pool_tri_block(const DScene &sc, TravState &t, bool want, bool is_any, int *stack, int *over,
-                                               int stack_cap) {
-    if (want) {
-        bool stop = false;
-#pragma unroll
-        for (int reps = 0; reps < kTriPerStep; reps++) {
-            const bool leaf_cur = t.cur != kEntryDone && t.cur < 0;
-            const bool from_pend = kSpeculate && t.pend != kEntryDone;  // the postponed leaf first
-            const bool active = !stop && (leaf_cur || from_pend);
-            if (active) {
-                const int enc = from_pend ? t.pend : t.cur;  // ~((first << 3) | count)
-                const int ref = ~enc;
-                const int k = ref >> 3;
-                const bool more = (ref & 7) > 1;
-                Tri tr = load_tri(sc.tris, k);
-                float tt, u, v;
-                const bool hit = tri_intersect(tr, t.o, t.d, t.tmax, tt, u, v);
-                const bool occluded = hit && is_any && k != t.tri;  // bvh.cuh:243
-                bool better = hit && !is_any;                       // bvh.cuh:227-231, ties by closest_hit_wins
-                if (better && tt == t.tmax && t.tri >= 0) better = sc.order[(unsigned)k] > sc.order[(unsigned)t.tri];
-                t.tmax = better ? tt : t.tmax;
-                t.hu = occluded ? 1.f : (better ? u : t.hu);
-                t.hv = better ? v : t.hv;
-                t.tri = better ? k : t.tri;
-                stop = occluded;
-                const int rest = more ? enc - 7 : kEntryDone;
-                const bool pop = !occluded && !from_pend && !more;
-                int popped = kEntryDone;
-                if (pop && t.sp > 0) popped = stack_pop(stack, over, t.sp, stack_cap);
-                t.pend = occluded ? kEntryDone : (from_pend ? rest : t.pend);
-                t.cur = occluded ? kEntryDone : (from_pend ? t.cur : (more ? rest : popped));
-            }
-        }
-    }
-}
-
-// workgroup-scope LDS accesses that the compiler may neither cache nor reorder across
-__device__ __forceinline__ int lds_load_acquire(const int *q) {
-    return __hip_atomic_load(q, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-__device__ __forceinline__ void lds_store_release(int *q, int v) {
-    __hip_atomic_store(q, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-__device__ __forceinline__ int lds_load_relaxed(const int *q) {
-    return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-
-// LDS layout (dynamic): columns [stack: max(stack_cap + 1, 8)][parked ray + radiance: 9][slot state: 15][sample sum: 3] x kBlock,
-// then [ADV ring: kRing][GEN ring: kRing][ring counters: 4][tables][uniforms]
-template <bool LDS_TABLES, bool WIDE>
-__global__ void __launch_bounds__(kBlock, 4)
-k_paths_pool(DScene sc, DPools p, Camera cam_arg, AdvanceParams ap_arg, float *__restrict__ fb, DWaveRow *__restrict__ rows,
-             int stack_cap, int *overflow, int adv_take, int gen_take, int debug_no_deposit, int prio_period, int rot_wave,
-             int rot_set, int tri_follow, long long iter_cap, unsigned long long *prof) {
-    extern __shared__ int s_lds[];
-    const int col = (int)threadIdx.x;
-    const int srows = max(stack_cap + 1, kPoolMailRows);                // (the stack rows double as the column's mail slot)
-    int *const stack_rows = s_lds;                                      // row r of column c at [r * kBlock + c]
-    float *const park_rows = (float *)(s_lds + srows * kBlock);
-    int *const cold_rows = s_lds + (srows + 9) * kBlock;
-    float *const acc_rows = (float *)(s_lds + (srows + 24) * kBlock);
-    int *const ring_adv = s_lds + (srows + kPoolRows) * kBlock;
-    int *const ring_gen = ring_adv + kRing;
-    int *const ctr = ring_gen + kRing;  // {adv head, adv tail, gen head, gen tail}
-    float *s_tab = (float *)(ctr + 4);
-    int *stack = stack_rows + col;
-    float *park = park_rows + col;
-    int *cold = cold_rows + col;  // 0..11 slot state (cold_save), 12 previous pixel (x | y << 16), 13 slot index, 14 mail
-    float *acc = acc_rows + col;
-    int *over = overflow + (blockIdx.x * kBlock + threadIdx.x) % kOverStride;
-    const float *tab = sc.tables;
-    if (LDS_TABLES) {
-        for (int k = threadIdx.x; k < sc.tab_dwords; k += kBlock) s_tab[k] = sc.tables[k];
-        tab = s_tab;
-    }
-    struct Uniforms {
-        Camera cam;
-        AdvanceParams ap;
-    };
-    static_assert(sizeof(Uniforms) % 4 == 0, "dword copy");
-    Uniforms *s_uni = (Uniforms *)(s_tab + (LDS_TABLES ? ((sc.tab_dwords + 3) & ~3) : 0));
-    {
-        Uniforms u;
-        u.cam = cam_arg;
-        u.ap = ap_arg;
-        const int *srcw = (const int *)&u;
-        for (int k = threadIdx.x; k < (int)(sizeof(Uniforms) / 4); k += kBlock) ((int *)s_uni)[k] = srcw[k];
-    }
-    ring_adv[col] = -1;  // (no index has generation -1)
-    ring_gen[col] = -1;
-    if (col < 4) ctr[col] = 0;
-    cold[14 * kBlock] = PW_NONE;
-    acc[0 * kBlock] = acc[1 * kBlock] = acc[2 * kBlock] = 0.f;
-    __syncthreads();
-    const Camera &cam = s_uni->cam;
-    const AdvanceParams &ap = s_uni->ap;
-    const int ap_n = ap_arg.n, ap_max_bounces = ap_arg.max_bounces, ap_fb_fixed = ap_arg.fb_fixed;
-    const int lanes_in_grid = (int)(gridDim.x * blockDim.x);
-    auto slot_of = [&](int set) {  // as in k_paths
-        const unsigned lane_in_grid = blockIdx.x * blockDim.x + threadIdx.x;
-        const unsigned wave_in_grid = lane_in_grid >> 6, lane_in_wave = lane_in_grid & 63u;
-        const unsigned b = (wave_in_grid + (wave_in_grid & 3u) * (unsigned)rot_wave + (unsigned)set * (unsigned)rot_set) &
-                           (((unsigned)lanes_in_grid >> 6) - 1u);
-        return set * lanes_in_grid + (int)(b * 64u + lane_in_wave);
-    };
-    int slot_set = 0;
-    int i = slot_of(0);
-    const unsigned lane = lane_id();
-    // pools <-> the lane's own column
-    auto slot_to_column = [&](int k) {
-        cold[0 * kBlock] = p.bounces(k);
-        cold[1 * kBlock] = p.pixel(k);
-        cold[2 * kBlock] = p.gen(k);
-        cold[3 * kBlock] = (int)p.rd(k);
-        cold[4 * kBlock] = (int)p.r0(k);
-        cold[5 * kBlock] = (int)p.r1(k);
-        cold[6 * kBlock] = (int)p.r2(k);
-        cold[7 * kBlock] = (int)p.r3(k);
-        cold[8 * kBlock] = (int)p.r4(k);
-        cold[9 * kBlock] = __float_as_int(p.br(k));
-        cold[10 * kBlock] = __float_as_int(p.bg(k));
-        cold[11 * kBlock] = __float_as_int(p.bb(k));
-        cold[12 * kBlock] = -1;  // no previous pixel
-        cold[13 * kBlock] = k;
-    };
-    auto column_to_slot = [&](int k) {  // the lockstep rounds of the final generation continue from the pools
-        p.bounces(k) = cold[0 * kBlock];
-        p.pixel(k) = cold[1 * kBlock];
-        p.gen(k) = cold[2 * kBlock];
-        p.hit_info(k) = -1;
-        p.stmax(k) = -1.f;
-        p.rd(k) = (uint32_t)cold[3 * kBlock];
-        p.r0(k) = (uint32_t)cold[4 * kBlock];
-        p.r1(k) = (uint32_t)cold[5 * kBlock];
-        p.r2(k) = (uint32_t)cold[6 * kBlock];
-        p.r3(k) = (uint32_t)cold[7 * kBlock];
-        p.r4(k) = (uint32_t)cold[8 * kBlock];
-        p.br(k) = __int_as_float(cold[9 * kBlock]);
-        p.bg(k) = __int_as_float(cold[10 * kBlock]);
-        p.bb(k) = __int_as_float(cold[11 * kBlock]);
-    };
-    // queue columns: one atomic per wave and push; `c` = the column a lane queues (its own, or the one it just shaded)
-    // A ring entry carries its own index's generation -- (index & ~255) | column -- so a reader knows whether the entry
-    // it looks at is the one it came for, and nobody ever has to clear an entry.
-    auto push = [&](bool want, int c, int *ring, int *tail) {
-        const unsigned long long m = wave_ballot(want);
-        if (m) {
-            int base = 0;
-            if (lane == 0) base = atomicAdd(tail, (int)__popcll(m));
-            base = __builtin_amdgcn_readfirstlane(base);
-            const int idx = base + (int)prefix_popc(m);
-            if (want) lds_store_release(&ring[(unsigned)idx & (kRing - 1)], (idx & ~(kRing - 1)) | c);
-        }
-    };
-    int phase = PH_IDLE;
-    TravState t;
-    t.o = t.d = t.inv = mk(0, 0, 0);
-    t.tmax = t.hu = t.hv = 0.f;
-    t.cur = kEntryDone;
-    t.sp = 0;
-    t.tri = -1;
-    t.pend = kEntryDone;
-    {
-        bool alive = false;
-        if (i < ap_n) {
-            slot_to_column(i);
-            const int b = cold[0 * kBlock];
-            alive = b != kDone && b != kParked;  // (untouched slots: bounces = max_bounces, so their first step is a gen())
-        }
-        if (alive) phase = PH_WAIT;
-        push(alive, col, ring_gen, &ctr[3]);
-    }
-    unsigned long long n_gen = 0, n_shade = 0, n_traced = 0, n_shadow = 0, n_emit = 0, n_deposit = 0, n_rr = 0, n_capped = 0;
-    unsigned prio_tick = 0;
-    const unsigned prio_rank = (4u * blockIdx.x) / gridDim.x;
-    long long iters = 0;
-#ifdef RT_TRACE_PROFILE
-    // [0] iterations [1] ADV batches [2] their columns [3] GEN batches [4] their columns [5] idle polls [6] node blocks
-    // [7] their lanes [8] triangle blocks [9] their lanes [10] failed claims [11] waiting lanes, summed over iterations
-    // [12] cycles in ADV batches [13] in GEN batches [14] wave lifetime
-    unsigned long long pq[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    const unsigned long long pq_t0 = __builtin_readcyclecounter();
-#endif
-    while (true) {
-        if (++iters > iter_cap) {  // (a scheduling bug must end in an error code, not in a hung GPU)
-            n_capped = 1;
-            break;
-        }
-        if (prio_period && (prio_tick++ & ((1u << prio_period) - 1u)) == 0u) {
-            unsigned lvl = ((prio_tick >> prio_period) + prio_rank) & 3u;
-            lvl = max(lvl, prio_rank >> 1);
-            switch (lvl) {
-                case 0: __builtin_amdgcn_s_setprio(0); break;
-                case 1: __builtin_amdgcn_s_setprio(1); break;
-                case 2: __builtin_amdgcn_s_setprio(2); break;
-                default: __builtin_amdgcn_s_setprio(3); break;
-            }
-        }
-        // ---------------- mail: results for the lanes that wait
-        if (wave_ballot(phase == PH_WAIT)) {
-            const int code = phase == PH_WAIT ? lds_load_acquire(&cold[14 * kBlock]) : (int)PW_NONE;
-            if (wave_ballot(code != PW_NONE)) {
-                bool regen = false;
-                if (code != PW_NONE) {
-                    cold[14 * kBlock] = PW_NONE;
-                    if (code == PW_BACK) {
-                        // the slot has no camera ray left (or is parked for the lockstep final generation): back to the
-                        // pools, and on to the lane's next one
-                        column_to_slot(i);
-                        phase = PH_IDLE;
-                        slot_set++;
-                        i = slot_of(slot_set);
-                        if (i < ap_n) {
-                            slot_to_column(i);
-                            const int b = cold[0 * kBlock];
-                            if (b != kDone && b != kParked) {
-                                regen = true;
-                                phase = PH_WAIT;
-                            } else {
-                                i = ap_n;  // (cannot happen: untouched slots start alive)
-                            }
-                        }
-                    } else {
-                        t.o = mk(__int_as_float(stack[0 * kBlock]), __int_as_float(stack[1 * kBlock]), __int_as_float(stack[2 * kBlock]));
-                        t.d = mk(__int_as_float(stack[3 * kBlock]), __int_as_float(stack[4 * kBlock]), __int_as_float(stack[5 * kBlock]));
-                        const float s_tmax = __int_as_float(stack[6 * kBlock]);
-                        const int s_target = stack[7 * kBlock];
-                        const bool sh = code == PW_SHADOW;
-                        phase = sh ? (int)PH_ANY : (int)PH_CLOSEST;
-                        t.tmax = sh ? s_tmax : kFltMax;
-                        t.tri = sh ? s_target : -1;
-                        t.hu = 0.f;
-                        t.inv = inv_dir(t.d);
-                        t.cur = 0;
-                        t.sp = 0;
-                        t.pend = kEntryDone;
-                    }
-                }
-                push(regen, col, ring_gen, &ctr[3]);
-            }
-        }
-        // ---------------- what each lane wants next
-        const bool trav = phase == PH_ANY || phase == PH_CLOSEST;
-        const bool want_node = trav && t.cur >= 0;
-        const bool want_tri = trav && ((t.cur != kEntryDone && t.cur < 0) || (kSpeculate && t.pend != kEntryDone));
-        const int n_node = wave_count(want_node);
-        const int n_tri = wave_count(want_tri);
-        const int n_wait = wave_count(phase == PH_WAIT);
-        if (n_node + n_tri + n_wait == 0) break;
-#ifdef RT_TRACE_PROFILE
-        pq[0]++; pq[11] += n_wait;
-#endif
-        // ---------------- pooled work: a full batch in a ring (or any batch, when this wave has nothing else to do)
-        {
-            const int a_head = lds_load_relaxed(&ctr[0]), a_tail = lds_load_relaxed(&ctr[1]);
-            const int g_head = lds_load_relaxed(&ctr[2]), g_tail = lds_load_relaxed(&ctr[3]);
-            const bool nothing_else = n_node + n_tri == 0;
-            const int avail_a = a_tail - a_head, avail_g = g_tail - g_head;
-            const bool go_adv = avail_a >= adv_take || (nothing_else && avail_a > 0);
-            const bool go_gen = !go_adv && (avail_g >= gen_take || (nothing_else && avail_g > 0));
-            if (go_adv || go_gen) {
-                // Entries first, claim second: each lane reads the entry it would get; if every one of them has been
-                // stored by its pusher already, ONE compare-and-swap on the head takes them all.  The head only ever
-                // grows, and an entry is overwritten only after the head has passed it, so a successful swap proves that
-                // the entries read are still the queue's.  A failed attempt costs nothing: the wave goes on with its own work.
-                const int head = go_adv ? a_head : g_head;
-                const int take = min(go_adv ? avail_a : avail_g, 64);
-                int *const ring = go_adv ? ring_adv : ring_gen;
-                const bool mine = (int)lane < take;
-                const int idx = head + (int)lane;
-                const int entry = mine ? lds_load_acquire(&ring[(unsigned)idx & (kRing - 1)]) : 0;
-                const bool stored = !mine || (entry & ~(kRing - 1)) == (idx & ~(kRing - 1));
-                int got = head - 1;
-                if (wave_ballot(!stored) == 0) {
-                    if (lane == 0) got = atomicCAS(&ctr[go_adv ? 0 : 2], head, head + take);
-                    got = __builtin_amdgcn_readfirstlane(got);
-                }
-#ifdef RT_TRACE_PROFILE
-                if (got != head) pq[10]++;
-                const unsigned long long pq_tb = __builtin_readcyclecounter();
-#endif
-                if (got == head) {
-                    const int c = mine ? (entry & (kRing - 1)) : 0;
-                    int *const ccold = cold_rows + c;
-                    int *const cstack = stack_rows + c;
-                    float *const cpark = park_rows + c;
-                    float *const cacc = acc_rows + c;
-                    AdvanceOut out;
-                    out.did_gen = out.did_shade = out.has_shadow = out.did_emit = out.new_ray = out.wants_gen = false;
-                    out.rr_draws = 0;
-                    bool to_gen = false;
-                    if (go_adv) {
-                        // ---------------- ADV: init() + mat() (render.cuh:84-248) for 64 queued columns
-                        if (mine) {
-                            SlotState st;
-                            st.bounces = ccold[0 * kBlock];
-                            st.pixel = ccold[1 * kBlock];
-                            st.gen = ccold[2 * kBlock];
-                            st.rs = Rng{(uint32_t)ccold[3 * kBlock], (uint32_t)ccold[4 * kBlock], (uint32_t)ccold[5 * kBlock],
-                                        (uint32_t)ccold[6 * kBlock], (uint32_t)ccold[7 * kBlock], (uint32_t)ccold[8 * kBlock]};
-                            st.beta = mk(__int_as_float(ccold[9 * kBlock]), __int_as_float(ccold[10 * kBlock]),
-                                         __int_as_float(ccold[11 * kBlock]));
-                            const int h_tri = cstack[0 * kBlock];
-                            const float h_u = __int_as_float(cstack[1 * kBlock]), h_v = __int_as_float(cstack[2 * kBlock]);
-                            st.wo = mk(__int_as_float(cstack[3 * kBlock]), __int_as_float(cstack[4 * kBlock]), __int_as_float(cstack[5 * kBlock]));
-                            st.hit_info = -1;
-                            st.isect_p = st.isect_n = mk(0, 0, 0);
-                            if (h_tri >= 0) {  // hit record in the form mat() consumes (render.cuh:152-153, 311-316)
-                                Tri tr = load_tri(sc.tris, h_tri);
-                                float4 sh = sc.tri_shade[(unsigned)h_tri];
-                                st.isect_p = tri_point(tr, h_u, h_v);
-                                st.isect_n = mk(sh.x, sh.y, sh.z);
-                                st.hit_info = __float_as_int(sh.w);
-                            }
-                            advance_core<true, true, true>(sc, tab, cam, ap, 0, st, out, fb, cacc);
-                            ccold[0 * kBlock] = st.bounces;
-                            ccold[3 * kBlock] = (int)st.rs.d;
-                            ccold[4 * kBlock] = (int)st.rs.v0;
-                            ccold[5 * kBlock] = (int)st.rs.v1;
-                            ccold[6 * kBlock] = (int)st.rs.v2;
-                            ccold[7 * kBlock] = (int)st.rs.v3;
-                            ccold[8 * kBlock] = (int)st.rs.v4;
-                            ccold[9 * kBlock] = __float_as_int(st.beta.x);
-                            ccold[10 * kBlock] = __float_as_int(st.beta.y);
-                            ccold[11 * kBlock] = __float_as_int(st.beta.z);
-                            int code = PW_NONE;
-                            if (out.has_shadow) {
-                                cpark[0 * kBlock] = out.ray_o.x;
-                                cpark[1 * kBlock] = out.ray_o.y;
-                                cpark[2 * kBlock] = out.ray_o.z;
-                                cpark[3 * kBlock] = out.ray_d.x;
-                                cpark[4 * kBlock] = out.ray_d.y;
-                                cpark[5 * kBlock] = out.ray_d.z;
-                                cpark[6 * kBlock] = out.s_L.x;
-                                cpark[7 * kBlock] = out.s_L.y;
-                                cpark[8 * kBlock] = out.s_L.z;
-                                cstack[0 * kBlock] = __float_as_int(out.s_o.x);
-                                cstack[1 * kBlock] = __float_as_int(out.s_o.y);
-                                cstack[2 * kBlock] = __float_as_int(out.s_o.z);
-                                cstack[3 * kBlock] = __float_as_int(out.s_d.x);
-                                cstack[4 * kBlock] = __float_as_int(out.s_d.y);
-                                cstack[5 * kBlock] = __float_as_int(out.s_d.z);
-                                cstack[6 * kBlock] = __float_as_int(out.s_tmax);
-                                cstack[7 * kBlock] = out.s_target;
-                                code = PW_SHADOW;
-                            } else if (out.new_ray) {
-                                cstack[0 * kBlock] = __float_as_int(out.ray_o.x);
-                                cstack[1 * kBlock] = __float_as_int(out.ray_o.y);
-                                cstack[2 * kBlock] = __float_as_int(out.ray_o.z);
-                                cstack[3 * kBlock] = __float_as_int(out.ray_d.x);
-                                cstack[4 * kBlock] = __float_as_int(out.ray_d.y);
-                                cstack[5 * kBlock] = __float_as_int(out.ray_d.z);
-                                code = PW_PATH;
-                            } else {
-                                to_gen = true;  // Russian roulette ended the path (its draws are in the column's RNG state)
-                            }
-                            if (code != PW_NONE) lds_store_release(&ccold[14 * kBlock], code);
-                        }
-                        push(to_gen, c, ring_gen, &ctr[3]);  // (the column goes straight to the GEN ring; its owner keeps waiting)
-                        n_shade += wave_count(out.did_shade);
-                        n_traced += wave_count(out.new_ray);
-                        n_shadow += wave_count(out.has_shadow);
-                        n_emit += wave_count(out.did_emit);
-                        int rr = out.rr_draws;
-                        if (wave_ballot(rr != 0)) {
-                            for (int off = 32; off > 0; off >>= 1) rr += __shfl_xor(rr, off);
-                            n_rr += (unsigned long long)rr;
-                        }
-                    } else {
-                        // ---------------- GEN: gen() (render.cuh:250-275) for 64 queued columns
-                        if (mine) {
-                            SlotState st;
-                            st.gen = ccold[2 * kBlock];
-                            st.rs = Rng{(uint32_t)ccold[3 * kBlock], (uint32_t)ccold[4 * kBlock], (uint32_t)ccold[5 * kBlock],
-                                        (uint32_t)ccold[6 * kBlock], (uint32_t)ccold[7 * kBlock], (uint32_t)ccold[8 * kBlock]};
-                            st.bounces = 0;
-                            st.pixel = 0;
-                            st.beta = mk(0, 0, 0);
-                            int pxy = ccold[12 * kBlock];
-                            acc_flush(cacc, fb, ap_fb_fixed, ccold[1 * kBlock]);  // the camera ray that ended: its sum -> its pixel
-                            gen_core<true>(cam, ap, ap.slot_lo + ccold[13 * kBlock], st, out, &pxy);
-                            ccold[0 * kBlock] = st.bounces;
-                            ccold[2 * kBlock] = st.gen;
-                            ccold[3 * kBlock] = (int)st.rs.d;
-                            ccold[4 * kBlock] = (int)st.rs.v0;
-                            ccold[5 * kBlock] = (int)st.rs.v1;
-                            ccold[6 * kBlock] = (int)st.rs.v2;
-                            ccold[7 * kBlock] = (int)st.rs.v3;
-                            ccold[8 * kBlock] = (int)st.rs.v4;
-                            int code = PW_BACK;  // out of camera rays, or parked for the lockstep final generation
-                            if (out.new_ray) {
-                                ccold[1 * kBlock] = st.pixel;
-                                ccold[9 * kBlock] = __float_as_int(st.beta.x);
-                                ccold[10 * kBlock] = __float_as_int(st.beta.y);
-                                ccold[11 * kBlock] = __float_as_int(st.beta.z);
-                                ccold[12 * kBlock] = pxy;
-                                cstack[0 * kBlock] = __float_as_int(out.ray_o.x);
-                                cstack[1 * kBlock] = __float_as_int(out.ray_o.y);
-                                cstack[2 * kBlock] = __float_as_int(out.ray_o.z);
-                                cstack[3 * kBlock] = __float_as_int(out.ray_d.x);
-                                cstack[4 * kBlock] = __float_as_int(out.ray_d.y);
-                                cstack[5 * kBlock] = __float_as_int(out.ray_d.z);
-                                code = PW_PATH;
-                            }
-                            lds_store_release(&ccold[14 * kBlock], code);
-                        }
-                        n_gen += wave_count(out.did_gen);
-                        n_traced += wave_count(out.new_ray);
-                    }
-#ifdef RT_TRACE_PROFILE
-                    pq[go_adv ? 1 : 3]++; pq[go_adv ? 2 : 4] += take; pq[go_adv ? 12 : 13] += __builtin_readcyclecounter() - pq_tb;
-#endif
-                    continue;
-                }
-            }
-            if (nothing_else) {  // every lane of this wave waits for a column another wave holds: yield the SIMD
-#ifdef RT_TRACE_PROFILE
-                pq[5]++;
-#endif
-                __builtin_amdgcn_s_sleep(4);
-                continue;
-            }
-        }
-        // ---------------- traversal: the more popular block; the triangle block right behind the node block (tri_follow)
-        const bool is_any = phase == PH_ANY;
-        if (n_node > 0 && n_node >= n_tri) {
-#ifdef RT_TRACE_PROFILE
-            pq[6]++; pq[7] += n_node;
-#endif
-            pool_node_block<WIDE>(sc, t, want_node, stack, over, stack_cap);
-            if (tri_follow > 0) {
-                const bool w = trav && ((t.cur != kEntryDone && t.cur < 0) || (kSpeculate && t.pend != kEntryDone));
-                const int nw = wave_count(w);
-#ifdef RT_TRACE_PROFILE
-                if (nw >= tri_follow) { pq[8]++; pq[9] += nw; }
-#endif
-                if (nw >= tri_follow) pool_tri_block(sc, t, w, is_any, stack, over, stack_cap);
-            }
-        } else if (n_tri > 0) {
-#ifdef RT_TRACE_PROFILE
-            pq[8]++; pq[9] += n_tri;
-#endif
-            pool_tri_block(sc, t, want_tri, is_any, stack, over, stack_cap);
-        }
-        // ---------------- finished rays
-        const bool fin = trav && t.cur == kEntryDone && (!kSpeculate || t.pend == kEntryDone);
-        n_deposit += wave_count(fin && is_any && t.hu == 0.f);
-        bool q_adv = false, q_gen = false;
-        if (fin) {
-            if (is_any) {
-                if (t.hu == 0.f && !debug_no_deposit)  // unoccluded: render.cuh:291-293
-                    acc_add(acc, park[6 * kBlock], park[7 * kBlock], park[8 * kBlock]);
-                // now the slot's path ray
-                t.o = mk(park[0 * kBlock], park[1 * kBlock], park[2 * kBlock]);
-                t.d = mk(park[3 * kBlock], park[4 * kBlock], park[5 * kBlock]);
-                phase = PH_CLOSEST;
-                t.inv = inv_dir(t.d);
-                t.tmax = kFltMax;
-                t.tri = -1;
-                t.cur = 0;
-                t.sp = 0;
-            } else {
-                // the hit record goes into the column (its stack rows are idle now); a path that missed, or has no bounce
-                // left (and is not at bounce 0, where a hit light still emits: render.cuh:98-109), can only generate
-                const int b = cold[0 * kBlock];
-                q_gen = t.tri < 0 || (b >= ap_max_bounces && b > 0);
-                q_adv = !q_gen;
-                if (q_adv) {
-                    stack[0 * kBlock] = t.tri;
-                    stack[1 * kBlock] = __float_as_int(t.hu);
-                    stack[2 * kBlock] = __float_as_int(t.hv);
-                    stack[3 * kBlock] = __float_as_int(t.d.x);
-                    stack[4 * kBlock] = __float_as_int(t.d.y);
-                    stack[5 * kBlock] = __float_as_int(t.d.z);
-                }
-                phase = PH_WAIT;
-            }
-        }
-        push(q_adv, col, ring_adv, &ctr[1]);
-        push(q_gen, col, ring_gen, &ctr[3]);
-    }
-#ifdef RT_TRACE_PROFILE
-    if (prof && lane == 0) {
-        pq[14] = __builtin_readcyclecounter() - pq_t0;
-        for (int k = 0; k < 16; k++) atomicAdd(&prof[k], pq[k]);
-    }
-#endif
-    unsigned long long v[C_COUNT] = {n_gen, n_shade, n_traced, n_shadow, n_emit, n_deposit, n_rr, n_capped};
-    row_add(rows, v);
-}
-
 // post_process_framebuffer (render.cuh:330-338): c = sqrt(c * (1/spp))
 __global__ void k_post_process(float *fb, int n_values, float inv_spp) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -3248,29 +2697,7 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
             hipLaunchKernelGGL((k_paths<T, WD, MJ, 4>), grid_paths, block, lds_paths, st, sc, c.pools, cam, ap, d_sum,   \
                                c.d_rows, paths_cap, d_over2, adv_batch, dbg, paths_prof, 0, prio_rotate, rot_wave, rot_set, gen_batch, tri_follow);     \
     } while (0)
-        // RT_POOL=1 (full shards): the variant that pools the shading work over the four waves of a workgroup (k_paths_pool)
-        bool pool = false;
-        if (const char *e = getenv("RT_POOL")) pool = atoi(e) != 0;
-        if (few_blocks || !majority) pool = false;
-        if (pool) {
-            int adv_take = 64, gen_take = 64;  // columns in a ring before a wave takes a batch (unless it has nothing else to do)
-            if (const char *e = getenv("RT_POOL_ADV")) adv_take = std::max(1, std::min(64, atoi(e)));
-            if (const char *e = getenv("RT_POOL_GEN")) gen_take = std::max(1, std::min(64, atoi(e)));
-            const int srows = std::max(paths_cap + 1, kPoolMailRows);
-            const size_t lds_pool = sizeof(int) * ((size_t)kBlock * (size_t)(srows + kPoolRows) + 2 * kRing + 4) +
-                                    (lds_tables ? sizeof(float) * (size_t)((scene->tab_dwords + 3) & ~3) : 0) + sizeof(Camera) +
-                                    sizeof(AdvanceParams);
-            // scheduling decisions a wave can need: a few per ray of its lanes' slots, plus idle polls; far above that is a bug
-            const long long iter_cap = 4000000LL + 64LL * (long long)(cam_end / std::max(1, paths_blocks * 4)) * (long long)(max_bounces + 2);
-#define RT_LAUNCH_POOL(T, WD)                                                                                              \
-    hipLaunchKernelGGL((k_paths_pool<T, WD>), grid_paths, block, lds_pool, st, sc, c.pools, cam, ap, d_sum, c.d_rows, paths_cap, \
-                       d_over2, adv_take, gen_take, dbg, prio_rotate, rot_wave, rot_set, tri_follow, iter_cap, paths_prof)
-            if (lds_tables && scene->wide) RT_LAUNCH_POOL(true, true);
-            else if (lds_tables) RT_LAUNCH_POOL(true, false);
-            else if (scene->wide) RT_LAUNCH_POOL(false, true);
-            else RT_LAUNCH_POOL(false, false);
-#undef RT_LAUNCH_POOL
-        } else if (majority) {
+        if (majority) {
             if (lds_tables && scene->wide) RT_LAUNCH_PATHS(true, true, true);
             else if (lds_tables) RT_LAUNCH_PATHS(true, false, true);
             else if (scene->wide) RT_LAUNCH_PATHS(false, true, true);
@@ -3287,17 +2714,7 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
         HIP_TRY(hipEventSynchronize(c.ev_b));
         HIP_TRY(hipEventElapsedTime(&ms_paths, c.ev_a, c.ev_b));
 #ifdef RT_TRACE_PROFILE
-        if (pool) {
-            unsigned long long h[16];
-            HIP_TRY(hipMemcpy(h, paths_prof, sizeof(h), hipMemcpyDeviceToHost));
-            const double it = (double)std::max<unsigned long long>(h[0], 1);
-            fprintf(stderr, "k_paths_pool: iterations %llu | ADV batches %llu avg columns %.1f (%.1f %% of wave time) | GEN batches %llu avg columns %.1f (%.1f %%) | "
-                            "idle polls %llu | node blocks %llu avg lanes %.1f | tri blocks %llu avg lanes %.1f | failed claims %llu | waiting lanes per iteration %.1f\n",
-                    h[0], h[1], h[1] ? (double)h[2] / h[1] : 0.0, 100.0 * h[12] / std::max<unsigned long long>(h[14], 1), h[3],
-                    h[3] ? (double)h[4] / h[3] : 0.0, 100.0 * h[13] / std::max<unsigned long long>(h[14], 1), h[5], h[6],
-                    h[6] ? (double)h[7] / h[6] : 0.0, h[8], h[8] ? (double)h[9] / h[8] : 0.0, h[10], (double)h[11] / it);
-            (void)hipFree(paths_prof);
-        } else {
+        {
             unsigned long long h[24];
             HIP_TRY(hipMemcpy(h, paths_prof, 192, hipMemcpyDeviceToHost));
             fprintf(stderr, "k_paths cycles: ADV %.1f%% (%.0f / block) node %.1f%% (%.0f) tri %.1f%% (%.0f) rest %.1f%%\n",
@@ -3416,7 +2833,6 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
         t_ah += ms;
     }
     if (!finished) return fail("rt_render_shard: round limit reached before the path pool drained");
-    if (fin[C_UNUSED] != 0) return fail("rt_render_shard: the persistent kernel hit its scheduling-iteration cap (frame incomplete)");
     if (stats) {
         memset(stats, 0, sizeof(*stats));
         stats->camera_rays = (int64_t)fin[C_CAMERA];
