@@ -1223,6 +1223,7 @@ constexpr int kNodeCont = RT_NODE_CONT, kNodeExtra = RT_NODE_EXTRA;
 #ifndef RT_SPECULATE
 #define RT_SPECULATE 1
 #endif
+
 constexpr bool kSpeculate = RT_SPECULATE != 0;  // k_paths: postpone a leaf reached inside a node block (see `pend` there)
 
 // Register diet: across loop iterations a lane carries only ONE ray (o, d, 1/d, tmax) and the
@@ -1423,14 +1424,25 @@ k_paths(DScene sc, DPools p, Camera cam_arg, AdvanceParams ap_arg, float *__rest
             }
         }
         // ---- what each lane wants next: the ADV block, a node step, or triangle tests
-        const bool trav = phase == PH_ANY || phase == PH_CLOSEST;
-        const bool want_node = trav && cur >= 0;
-        const bool want_tri = trav && ((cur != kEntryDone && cur < 0) || (kSpeculate && pend != kEntryDone));
-        const int n_adv = wave_count((phase == PH_ADV));
+        bool trav = phase == PH_ANY || phase == PH_CLOSEST;
+        bool want_node = trav && cur >= 0;
+        bool want_tri = trav && ((cur != kEntryDone && cur < 0) || (kSpeculate && pend != kEntryDone));
+        int n_adv = wave_count((phase == PH_ADV));
         const int n_genw = wave_count((phase == PH_GEN));
-        const int n_node = wave_count((want_node));
-        const int n_tri = wave_count((want_tri));
+        int n_node = wave_count((want_node));
+        int n_tri = wave_count((want_tri));
         if (n_adv + n_genw + n_node + n_tri == 0) break;
+        // After a GEN or ADV block the wave goes straight on to the traversal blocks of this scheduling round (its lanes have
+        // just been given rays at the root): the lanes' wishes are taken again and the round trip through the loop head is
+        // saved (+3.8 % on C2).
+        auto retake = [&]() {
+            trav = phase == PH_ANY || phase == PH_CLOSEST;
+            want_node = trav && cur >= 0;
+            want_tri = trav && ((cur != kEntryDone && cur < 0) || (kSpeculate && pend != kEntryDone));
+            n_adv = wave_count((phase == PH_ADV));
+            n_node = wave_count((want_node));
+            n_tri = wave_count((want_tri));
+        };
         // Every block is issued for the whole wave whatever the number of lanes that need it.  The ADV
         // block is ~15x longer than a node step or a triangle test, so it waits for `adv_batch` lanes
         // unless nothing else can run.  MAJORITY additionally runs only the more popular of the two
@@ -1506,7 +1518,7 @@ k_paths(DScene sc, DPools p, Camera cam_arg, AdvanceParams ap_arg, float *__rest
 #ifdef RT_TRACE_PROFILE
             pf_gen_cycles += __builtin_readcyclecounter() - pf_tg;
 #endif
-            continue;
+            retake();
         }
         if (run_adv) {
 #ifdef RT_TRACE_PROFILE
@@ -1596,7 +1608,7 @@ k_paths(DScene sc, DPools p, Camera cam_arg, AdvanceParams ap_arg, float *__rest
 #ifdef RT_TRACE_PROFILE
             pf[8] += __builtin_readcyclecounter() - pf_ta;
 #endif
-            continue;
+            retake();
         }
         const bool is_any = phase == PH_ANY;
         // ---------------- node steps for the lanes in `want`
@@ -2657,11 +2669,12 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
             lds_paths += (size_t)top_n * 64;
             top_records_in_lds = top_n;
         }
-        // lanes waiting for the ADV block before it runs: full pool flat 22..26 on the 4-wide tree (24 + GEN 8: +1.5 % over
-        // 30 + 6), the 2-waves-per-SIMD shards want 30..38 (24: -2.5 %)
-        int adv_batch = few_blocks ? 34 : 24;
+        // lanes waiting for the ADV block before it runs: full pool flat 16..24 (round 3, with the triangle block behind the
+        // node block and no trip through the loop head after ADV / GEN: 20 and GEN 6 are 1 % ahead of 24 and 8); the
+        // 2-waves-per-SIMD shards want 30..38 (24: -2.5 %)
+        int adv_batch = few_blocks ? 34 : 20;
         if (const char *e = getenv("RT_ADV_BATCH")) adv_batch = std::max(1, std::min(64, atoi(e)));
-        int gen_batch = 8;  // lanes waiting for the GEN block before it runs (unless nothing else can); flat 6..10
+        int gen_batch = 6;  // lanes waiting for the GEN block before it runs (unless nothing else can); flat 4..8
         if (const char *e = getenv("RT_GEN_BATCH")) gen_batch = std::max(1, std::min(64, atoi(e)));
         int tri_follow = 1;  // a triangle block right behind a node block when this many lanes hold a leaf by then; 0 = never
         if (const char *e = getenv("RT_TRI_FOLLOW")) tri_follow = std::max(0, std::min(64, atoi(e)));
