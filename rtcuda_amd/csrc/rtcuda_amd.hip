@@ -1652,44 +1652,53 @@ k_paths(DScene sc, DPools p, Camera cam_arg, AdvanceParams ap_arg, float *__rest
             const unsigned long long pf_tt = __builtin_readcyclecounter();
 #endif
             if (want) {
-                // Straight-line bookkeeping: every outcome of a test is a select, not a branch (the merges of the branchy
-                // version cost the wave ~30 register moves per test: +1.1 % frame rate), the only branches left are the
-                // rare ones (a tie between two hits; a pop from the overflow column).  kTriPerStep tests per block also
-                // without MAJORITY.
-                bool stop = false;
+                // kTriPerStep tests per lane, and ALL their triangle records are fetched before the first test: which
+                // triangles come next does not depend on the outcome of a test (only whether they are still wanted does: an
+                // occluded shadow ray is finished), so the block waits for one memory round trip instead of one per test.
+                // The lane's walk through its leaves is made up front on copies of (pend, cur):
+                //   the postponed leaf first, then the leaf under the cursor; when the cursor's leaf is used up, the next
+                //   stack entry -- popped on the spot: a ray that turns out occluded has no use for its stack any more.
+                // Straight-line bookkeeping: every outcome is a select, not a branch (the merges of the branchy version cost
+                // the wave ~30 register moves per test); the only branches left are the rare ones (a tie between two hits;
+                // a pop from the overflow column).
+                int pd = pend, cu = cur;
+                int ks[kTriPerStep];
+                bool act[kTriPerStep];
+                Tri tr[kTriPerStep];
 #pragma unroll
-                for (int reps = 0; reps < kTriPerStep; reps++) {
-                    const bool leaf_cur = cur != kEntryDone && cur < 0;
-                    const bool from_pend = kSpeculate && pend != kEntryDone;  // the postponed leaf first
-                    const bool active = !stop && (leaf_cur || from_pend);
-                    if (active) {
-                        const int enc = from_pend ? pend : cur;  // ~((first << 3) | count)
-                        const int ref = ~enc;
-                        const int k = ref >> 3;
-                        const bool more = (ref & 7) > 1;
-                        Tri tr = load_tri(sc.tris, k);
+                for (int j = 0; j < kTriPerStep; j++) {
+                    const bool fp = kSpeculate && pd != kEntryDone;
+                    const bool leaf = cu != kEntryDone && cu < 0;
+                    act[j] = fp || leaf;
+                    const int enc = fp ? pd : cu;  // ~((first << 3) | count)
+                    ks[j] = act[j] ? (~enc) >> 3 : ks[0];  // (an address that is valid in any case)
+                    const bool more = ((~enc) & 7) > 1;
+                    const int rest = more ? enc - 7 : kEntryDone;  // one triangle further: first + 1, count - 1
+                    int popped = kEntryDone;
+                    if (act[j] && !fp && !more && sp > 0) popped = stack_pop(stack, over, sp, stack_cap);
+                    pd = (act[j] && fp) ? rest : pd;
+                    cu = (act[j] && !fp) ? (more ? rest : popped) : cu;
+                    tr[j] = load_tri(sc.tris, ks[j]);
+                }
+                // the tests, each with the tmax the earlier ones left.  any-hit: the first accepted hit that is not the
+                // excluded triangle (bvh.cuh:243); closest-hit: bvh.cuh:227-231 (t <= tmax), ties by closest_hit_wins
+                bool occluded = false;
+#pragma unroll
+                for (int j = 0; j < kTriPerStep; j++) {
+                    if (act[j] && !occluded) {
                         float t, u, v;
-                        const bool hit = tri_intersect(tr, o, d, tmax, t, u, v);
-                        // any-hit: the first accepted hit that is not the excluded triangle (bvh.cuh:243);
-                        // closest-hit: bvh.cuh:227-231 (t <= tmax), ties by closest_hit_wins
-                        const bool occluded = hit && is_any && k != tri;
+                        const bool hit = tri_intersect(tr[j], o, d, tmax, t, u, v);
+                        occluded = hit && is_any && ks[j] != tri;
                         bool better = hit && !is_any;
-                        if (better && t == tmax && tri >= 0) better = sc.order[(unsigned)k] > sc.order[(unsigned)tri];
+                        if (better && t == tmax && tri >= 0) better = sc.order[(unsigned)ks[j]] > sc.order[(unsigned)tri];
                         tmax = better ? t : tmax;
                         hu = occluded ? 1.f : (better ? u : hu);
                         hv = better ? v : hv;
-                        tri = better ? k : tri;
-                        stop = occluded;
-                        // what this lane looks at next: the rest of the leaf (one triangle further: first + 1, count - 1 is
-                        // enc - 7), or -- when the leaf under the cursor is used up -- the next stack entry
-                        const int rest = more ? enc - 7 : kEntryDone;
-                        const bool pop = !occluded && !from_pend && !more;
-                        int popped = kEntryDone;
-                        if (pop && sp > 0) popped = stack_pop(stack, over, sp, stack_cap);
-                        pend = occluded ? kEntryDone : (from_pend ? rest : pend);
-                        cur = occluded ? kEntryDone : (from_pend ? cur : (more ? rest : popped));
+                        tri = better ? ks[j] : tri;
                     }
                 }
+                pend = occluded ? kEntryDone : pd;
+                cur = occluded ? kEntryDone : cu;
             }
 #ifdef RT_TRACE_PROFILE
             pf[10] += __builtin_readcyclecounter() - pf_tt;
