@@ -78,6 +78,10 @@ def main():
     ap.add_argument("--debug-flags", type=int, default=0, help="perf experiments only (results invalid)")
     ap.add_argument("--allow-invalid", action="store_true", help="accept --debug-flags != 0 (the line is marked invalid)")
     ap.add_argument("--no-parity", action="store_true", help="skip the GPU-vs-oracle parity block")
+    ap.add_argument("--rng-mode", default="reference", choices=["reference", "per_sample"],
+                    help="reference: the reference's per-slot XORWOW streams (default; the parity mode; N ranks = N slot shards).  "
+                         "per_sample: NOT the reference's random numbers -- one stream per camera ray, so every rank runs the full "
+                         "slot pool on spp / N samples of every pixel (statistically equivalent image; see include/rtcuda_amd.h)")
     args = ap.parse_args()
     if args.debug_flags != 0 and not args.allow_invalid:
         raise SystemExit("--debug-flags changes what the kernels do (e.g. 0x100 drops every framebuffer deposit): the "
@@ -118,6 +122,8 @@ def main():
     fb_fixed = torch.zeros(h * w * 3, dtype=torch.int64, device="cuda") if args.deterministic else None
     stream = torch.cuda.current_stream().cuda_stream
     flags = (0 if args.no_kernel_timing else api.FLAG_TIME_KERNELS) | args.debug_flags
+    if args.rng_mode == "per_sample":
+        flags |= api.FLAG_RNG_PER_SAMPLE
     last_stats = {}
 
     def render_local():
@@ -182,12 +188,16 @@ def main():
                        "scene": args.scene, "width": w, "height": h, "spp": spp, "max_bounces": args.max_bounces,
                        "parallelism": f"slot-shard x{world} + 1 RCCL reduce" if world > 1 else "1 GPU",
                        "accumulation": "int64 fixed point (order-independent)" if args.deterministic else "fp32 atomics",
+                       "rng_mode": args.rng_mode,
                        "debug_flags": args.debug_flags},
             "ms_per_frame": round(1e3 * elapsed / max(args.steps, 1), 3),
         }
         if args.debug_flags != 0:
             out["invalid"] = "debug_flags != 0: work was skipped inside the timed region"
             out["value"] = None
+        if args.rng_mode == "per_sample":
+            out["scaling_mode"] = ("per_sample RNG streams: NOT the reference's image sample for sample (statistically equivalent; "
+                                   "the shards' sums are exactly partition-invariant); every rank runs all 2^20 slots")
         # ---- CPU baseline (rank 0, N = 1 only): the oracle on a bounded sample of the same workload
         np_c, tt_c, np_a, tt_a = APPX_C[args.scene]
         np_src = "SURVEY.md Appendix C"
@@ -215,7 +225,7 @@ def main():
             # ---- parity of THIS binary on THIS box: the sample frame on the GPU against the oracle -- its watertight
             # mode for the strict comparison (equal integer event totals), the literal reference walk (the run just
             # timed) beside it: that one loses about one accepted hit in 10^7 rays (tests/test_traversal_audit.py)
-            if not args.no_parity and args.debug_flags == 0:
+            if not args.no_parity and args.debug_flags == 0 and args.rng_mode == "reference":
                 gimg, gst = scene.render(cam, w, h, args.cpu_spp, max_bounces=args.max_bounces, seed=1)
                 wimg, _, wst = osc.set_watertight(True).render(ocam, w, h, args.cpu_spp, args.max_bounces, 1, threads=cores)
                 pairs = (("shade_events", "sum_mat"), ("any_rays", "sum_ah"), ("emission_adds", "emission_adds"),

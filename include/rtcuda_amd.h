@@ -86,6 +86,15 @@ typedef struct rt_stats {
 #define RT_FLAG_DETERMINISTIC 2u /* rt_render: accumulate in 64-bit fixed point (2^-30) instead of float atomics
                                     (vec3.cuh:149-153): bit-reproducible image, independent of summation order */
 
+#define RT_FLAG_RNG_PER_SAMPLE 4u /* NOT the reference's random numbers: every camera ray starts a stream of its own, keyed by
+                                    (seed, camera ray id), instead of continuing its path SLOT's stream (render.cuh:72,156,263).
+                                    The image is a statistically equivalent estimate, not the reference's image sample for
+                                    sample -- parity tests never use it.  What it buys: the frame no longer depends on which
+                                    slot or GPU serves a camera ray, so with rt_render_shard every rank runs ALL W slots on
+                                    num_samples / shard_count samples of every pixel (num_samples % shard_count == 0), the
+                                    shards' fixed-point sums add up to the 1-GPU sums exactly, and 8 GPUs are not held to
+                                    1/8 of the W chains each (SURVEY.md section 7 "per_sample", section 8b `rng_mode`) */
+
 /* ---- scene -------------------------------------------------------------------------------
  * Replaces: Triangle(p0,p1,p2) x n (triangle.cuh:6-7), cudaMalloc/Memcpy of triangles,
  * materials and lights (main.cu:50-51,119-122,136-137), Primitive(tri*,mat*,light*)

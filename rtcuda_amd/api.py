@@ -23,6 +23,7 @@ CSRC = os.path.join(_PKG, "csrc")
 W = 1 << 20  # RT_NUM_WORKING_PATHS
 FLAG_TIME_KERNELS = 1
 FLAG_DETERMINISTIC = 2
+FLAG_RNG_PER_SAMPLE = 4  # NOT the reference's random numbers (see include/rtcuda_amd.h): partition-invariant streams
 
 EXPORTS = [
     "rt_scene_create", "rt_scene_destroy", "rt_scene_info", "rt_scene_build_info", "rt_camera_make", "rt_render",

@@ -69,6 +69,26 @@ RT_DEV uint32_t rng_next(Rng &s) {
     s.d += 362437u;
     return s.v4 + s.d;
 }
+// RT_FLAG_RNG_PER_SAMPLE: the stream of ONE camera ray, keyed by (seed, global camera-ray id) -- not the reference's
+// stream (there a path continues the stream of its SLOT: render.cuh:72,156,263), so the image is a different, statistically
+// equivalent estimate; in exchange it does not depend on which slot, or which GPU, serves the camera ray.  splitmix64 of
+// the key, then curand_init's seed scramble of that word as the XORWOW state, subsequence 0.
+RT_DEV Rng rng_sample_stream(uint32_t seed_lo, uint32_t seed_hi, unsigned long long key) {
+    unsigned long long z = (((unsigned long long)seed_hi << 32) | seed_lo) + 0x9E3779B97F4A7C15ull * (key + 1ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    const uint32_t s0 = (uint32_t)z ^ 0xaad26b49u, s1 = (uint32_t)(z >> 32) ^ 0xf7dcefddu;
+    const uint32_t t0 = 1099087573u * s0, t1 = 2591861531u * s1;
+    Rng r;
+    r.d = 6615241u + t1 + t0;
+    r.v0 = 123456789u + t0;
+    r.v1 = 362436069u ^ t0;
+    r.v2 = 521288629u + t1;
+    r.v3 = 88675123u ^ t1;
+    r.v4 = 5783321u + t0;
+    return r;
+}
 // curand_uniform: (0, 1]
 RT_DEV float rng_uniform(Rng &s) { return (float)rng_next(s) * 2.3283064e-10f + (2.3283064e-10f / 2.0f); }
 

@@ -266,6 +266,10 @@ struct AdvanceParams {
     int fb_fixed;        // framebuffer holds 64-bit fixed-point sums (see deposit())
     int w_over_spp;      // W / spp when spp divides W (then pixel = gen * w_over_spp + slot / spp: no 64-bit divide), else 0
     int dpx, dpy;        // w_over_spp = dpy * width + dpx: how a slot's pixel moves per generation; dpy < 0: not usable
+    // RT_FLAG_RNG_PER_SAMPLE: every camera ray starts its own stream, keyed by its GLOBAL id = local id * key_mul + key_add
+    // (rank `key_add` of `key_mul` renders the frame at spp / key_mul with the full slot pool); no slot parks
+    int per_sample, key_mul, key_add;
+    uint32_t seed_lo, seed_hi;
 };
 
 constexpr int kLdsTable = 64;                   // materials / lights staged in LDS per workgroup
@@ -443,6 +447,7 @@ __device__ __forceinline__ void gen_core(const Camera &cam, const AdvanceParams 
         px = st.pixel - py * ap.width;
     }
     if (pxy) *pxy = px | (py << 16);
+    if (ap.per_sample) st.rs = rng_sample_stream(ap.seed_lo, ap.seed_hi, (unsigned long long)cid * (unsigned)ap.key_mul + (unsigned)ap.key_add);
     float jx = rng_uniform(st.rs);  // x first, then y (Appendix A.7)
     float jy = rng_uniform(st.rs);
     camera_get_ray(cam, (px + jx) / ap.width, (py + jy) / ap.height, out.ray_o, out.ray_d);
@@ -2518,14 +2523,22 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
         return fail("rt_render_shard: shard_count must divide 1048576 and 0 <= shard_index < shard_count");
     if ((long long)width * height > (long long)(0x7fffffff / 3))  // framebuffer values are indexed with 32 bits
         return fail("rt_render_shard: width*height exceeds 715827882 pixels");
+    // RT_FLAG_RNG_PER_SAMPLE: this rank renders the whole frame at num_samples / shard_count samples per pixel with ALL W
+    // slots; camera ray `cid` of the rank has the global key cid * shard_count + shard_index, so the keys of a pixel's
+    // samples are the same set whatever the shard count (see AdvanceParams)
+    const bool per_sample = (flags & RT_FLAG_RNG_PER_SAMPLE) != 0;
+    if (per_sample) {
+        if (spp % shard_count != 0) return fail("rt_render_shard: RT_FLAG_RNG_PER_SAMPLE needs num_samples divisible by shard_count");
+        spp /= shard_count;
+    }
     long long cam_end = (long long)width * height * spp;
     if (cam_end + 13LL * kW >= (1LL << 31))  // the reference's int32 camera_ray ids (render.cuh:370-371,440)
         return fail("rt_render_shard: width*height*spp exceeds the reference's int32 camera-ray range");
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
     if (dev != scene->device) return fail("rt_render_shard: scene was created on another device");
-    const int n = kW / shard_count;
-    const int slot_lo = shard_index * n;
+    const int n = per_sample ? kW : kW / shard_count;
+    const int slot_lo = per_sample ? 0 : shard_index * n;
     Context *cp = nullptr;
     if (get_context(n, ctx_lane, &cp)) return 1;
     Context &c = *cp;
@@ -2564,7 +2577,12 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
     ap.spp = spp;
     ap.max_bounces = max_bounces;
     ap.cam_end = cam_end;
-    ap.last_gen = (int)((cam_end + kW - 1) / kW) - 1;
+    ap.last_gen = per_sample ? 0x7fffffff : (int)((cam_end + kW - 1) / kW) - 1;  // (per-sample streams: no lockstep final generation)
+    ap.per_sample = per_sample ? 1 : 0;
+    ap.key_mul = per_sample ? shard_count : 1;
+    ap.key_add = per_sample ? shard_index : 0;
+    ap.seed_lo = (uint32_t)seed;
+    ap.seed_hi = (uint32_t)(seed >> 32);
     ap.round = 0;
     ap.batch_mask = 7;
     ap.lockstep = 0;
@@ -2638,6 +2656,7 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
     // round-per-launch pipeline (k_advance + k_trace) that the lockstep final generation also uses
     bool persistent = true;
     if (const char *e = getenv("RT_PERSISTENT")) persistent = atoi(e) != 0;
+    if (per_sample && !persistent) return fail("rt_render_shard: RT_FLAG_RNG_PER_SAMPLE runs on the persistent kernel only");
     float ms_paths = 0.f;
     int top_records_in_lds = 0;
     if (persistent) {
@@ -2803,7 +2822,7 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
     }
     // ---- final generation in lockstep (see k_advance): round 0 generates, every later round is one
     // reference iteration; the render ends at the first round in which nothing shades (render.cuh:436)
-    if (finished) {
+    if (finished && !per_sample) {
         ap.lockstep = 1;
         for (int j = 0; j <= max_bounces + 1; j++) {
             ap.round = (int)(rounds & 0x3fffffff);

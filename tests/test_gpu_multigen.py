@@ -361,3 +361,52 @@ def test_multi_generation_render_against_the_literal_reference_fixture(api, vari
     d = np.nan_to_num(np.abs(img.astype(np.float64) - ref))
     assert (d.max(axis=2) > 1e-4).sum() <= 2
     assert np.sqrt(np.mean(d ** 2)) < 1e-4
+
+
+def test_per_sample_rng_mode_is_partition_invariant_and_statistically_equivalent(api):
+    """RT_FLAG_RNG_PER_SAMPLE (NOT the reference's random numbers: SURVEY section 7 "per_sample"): every camera ray has a
+    stream of its own, keyed by (seed, camera ray id).
+      * partition invariance: rank r of R renders all pixels at spp / R with the full slot pool; the ranks' fixed-point
+        sums add up to EXACTLY the 1-rank sums for R = 2, 4, 8, and so do the event totals;
+      * it is the same estimator: against the default (reference) mode the image differs by Monte-Carlo noise only -- as
+        much as two default-mode renders with different seeds differ -- and the mean radiance agrees."""
+    import torch
+    from rtcuda_amd import scenes
+    w, h, spp = 240, 135, 256  # 7.9 generations
+    gpu = api.Scene(scenes.cornell_bunny("full_bsdf"))
+    cam = api.make_camera(aspect=w / h)
+    F = api.FLAG_RNG_PER_SAMPLE
+    keys = ("camera_rays", "shade_events", "any_rays", "emission_adds", "shadow_adds", "rr_draws")
+    full = torch.zeros(h * w * 3, dtype=torch.int64, device="cuda")
+    st_full = gpu.render_shard_fixed(cam, w, h, spp, 0, 1, full.data_ptr(), flags=F)
+    assert st_full["camera_rays"] == w * h * spp
+    for shards in (2, 4, 8):
+        acc = torch.zeros_like(full)
+        tot = {k: 0 for k in keys}
+        for r in range(shards):
+            st = gpu.render_shard_fixed(cam, w, h, spp, r, shards, acc.data_ptr(), flags=F)
+            assert st["camera_rays"] == w * h * spp // shards  # every rank: all pixels, spp / R samples each
+            for k in keys:
+                tot[k] += st[k]
+        torch.cuda.synchronize()
+        assert torch.equal(acc, full), shards
+        assert all(tot[k] == st_full[k] for k in keys), (shards, tot, st_full)
+    # spp must split evenly over the ranks
+    with pytest.raises(api.RtError):
+        gpu.render_shard_fixed(cam, w, h, 255, 0, 2, full.data_ptr(), flags=F)
+    gpu.close()
+    # the estimator: per-sample streams vs the reference's slot streams, on the matte scene (no specular fireflies) and with
+    # a robust measure -- the median absolute pixel difference -- next to the difference of two reference-mode renders
+    gpu = api.Scene(scenes.cornell_bunny("matte"))
+    img_ps, st_ps = gpu.render(cam, w, h, spp, flags=F)
+    img_a, st_a = gpu.render(cam, w, h, spp, seed=1)
+    img_b, _ = gpu.render(cam, w, h, spp, seed=2)
+    gpu.close()
+
+    def mad(x, y):
+        return float(np.nanmedian(np.abs(x.astype(np.float64) - y)))
+    noise = mad(img_a, img_b)  # two independent reference-mode renders
+    assert noise > 0
+    assert 0.8 * noise < mad(img_ps, img_a) < 1.25 * noise, (mad(img_ps, img_a), noise)
+    assert abs(np.nanmean(img_ps) - np.nanmean(img_a)) < 0.005 * np.nanmean(img_a)
+    assert abs(st_ps["shade_events"] - st_a["shade_events"]) < 0.005 * st_a["shade_events"]  # same path statistics

@@ -25,3 +25,19 @@ for R in (1, 2, 4, 8):
     base = base or rate
     print(f"shards {R}: {st['camera_rays']} samples in {dt*1e3:.1f} ms -> {rate:.1f} Msamples/s per GPU; "
           f"predicted {R}-GPU throughput {R*rate:.0f} Msamples/s = {R*rate/base:.2f}x")
+
+# the same curve in the per-sample RNG mode (NOT the reference's random numbers): a rank runs the full slot pool on spp / R
+base = None
+for R in (1, 2, 4, 8):
+    fb.zero_()
+    scene.render_shard(cam, w, h, spp, 0, R, fb.data_ptr(), flags=api.FLAG_RNG_PER_SAMPLE)
+    fb.zero_()
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    st = scene.render_shard(cam, w, h, spp, 0, R, fb.data_ptr(), flags=api.FLAG_RNG_PER_SAMPLE)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t
+    rate = st["camera_rays"] / dt / 1e6
+    base = base or rate
+    print(f"per_sample shards {R}: {st['camera_rays']} samples in {dt*1e3:.1f} ms -> {rate:.1f} Msamples/s per GPU; "
+          f"predicted {R}-GPU throughput {R*rate:.0f} Msamples/s = {R*rate/base:.2f}x")

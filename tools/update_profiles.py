@@ -65,17 +65,26 @@ for name in ("bench_n1.json", "shard_rate.txt", "valu_calibration.json", "valu_c
 if os.path.exists(os.path.join(src, "shard8", "pmc_summary.json")):
     shutil.copy(os.path.join(src, "shard8", "pmc_summary.json"), os.path.join(dst, f"{tag}_shard8_pmc.json"))
 # shard-rate curve -> what bench.py echoes when n_gpus > 1
-rates = {}
+rates, rates_ps = {}, {}
 p = os.path.join(src, "shard_rate.txt")
 if os.path.exists(p):
     for ln in open(p):
         if ln.startswith("shards "):
             tok = ln.replace(":", "").split()
             rates[int(tok[1])] = float(ln.split("->")[1].split()[0])
+        if ln.startswith("per_sample shards "):
+            tok = ln.replace(":", "").split()
+            rates_ps[int(tok[2])] = float(ln.split("->")[1].split()[0])
 if rates:
     base = rates.get(1)
     json.dump({"source": f"tools/shard_rate.py on one MI355X ({tag}): the rate of ONE rank's slot shard, before the 24.9 MB reduce",
                "per_gpu_Msamples_per_s": rates,
                "predicted_Msamples_per_s": {n: round(n * r, 1) for n, r in rates.items()},
-               "predicted_speedup": {n: round(n * r / base, 3) for n, r in rates.items()} if base else None},
+               "predicted_speedup": {n: round(n * r / base, 3) for n, r in rates.items()} if base else None,
+               "per_sample_rng_mode": {
+                   "note": "RT_FLAG_RNG_PER_SAMPLE (bench.py --rng-mode per_sample): NOT the reference's random numbers; every rank "
+                           "runs the full slot pool on spp / N samples of every pixel",
+                   "per_gpu_Msamples_per_s": rates_ps,
+                   "predicted_Msamples_per_s": {n: round(n * r, 1) for n, r in rates_ps.items()},
+                   "predicted_speedup": ({n: round(n * r / rates_ps[1], 3) for n, r in rates_ps.items()} if rates_ps.get(1) else None)}},
               open(os.path.join(dst, "shard_rate_prediction.json"), "w"), indent=1)
