@@ -415,11 +415,13 @@ struct AdvanceOut {
 // generation, so with it the pixel coordinates follow by an add and a carry instead of two integer divisions.
 // NEVER_LOCKSTEP: the caller (k_paths) only ever runs with ap.lockstep == 0 -- known at compile time there, a value read
 // from LDS (and so a divergent branch with its merges, as far as the compiler can tell) otherwise.
+// `cid_given` >= 0 (per-sample streams on the persistent kernel only): the camera ray is not the slot's next one but the one
+// the wave drew from the frame's counter -- with a stream of its own per camera ray, any lane can take any camera ray.
 template <bool NEVER_LOCKSTEP = false>
 __device__ __forceinline__ void gen_core(const Camera &cam, const AdvanceParams &ap, int slot_global, SlotState &st,
-                                         AdvanceOut &out, int *pxy = nullptr) {
+                                         AdvanceOut &out, int *pxy = nullptr, long long cid_given = -1) {
     const bool lockstep = NEVER_LOCKSTEP ? false : (ap.lockstep != 0);
-    long long cid = (long long)st.gen * kW + slot_global;
+    long long cid = cid_given >= 0 ? cid_given : (long long)st.gen * kW + slot_global;
     if (cid >= ap.cam_end) {
         st.bounces = kDone;
         return;
@@ -432,7 +434,11 @@ __device__ __forceinline__ void gen_core(const Camera &cam, const AdvanceParams 
     // pixel = camera_ray_id / spp (render.cuh:254-256).  cid = gen * W + slot, so when spp divides W the quotient
     // splits exactly into two 32-bit terms; the general case keeps the 64-bit division.
     int px, py;
-    if (pxy && ap.dpy >= 0 && *pxy >= 0) {
+    if (cid_given >= 0) {
+        st.pixel = (int)((unsigned)cid / (unsigned)ap.spp);  // (camera-ray ids stay below 2^31: rt_render_shard checks)
+        py = (int)((unsigned)st.pixel / (unsigned)ap.width);
+        px = st.pixel - py * ap.width;
+    } else if (pxy && ap.dpy >= 0 && *pxy >= 0) {
         px = (*pxy & 0xffff) + ap.dpx;
         py = (*pxy >> 16) + ap.dpy;
         if (px >= ap.width) {
@@ -1204,6 +1210,7 @@ enum { PH_ADV = 0, PH_ANY = 1, PH_CLOSEST = 2, PH_IDLE = 3, PH_GEN = 4 };
 #ifndef RT_TRI_PER_STEP
 #define RT_TRI_PER_STEP 2
 #endif
+constexpr int kCidChunk = 512;  // camera-ray ids a wave draws at a time in the per-sample RNG mode
 constexpr int kTriPerStep = RT_TRI_PER_STEP;  // triangle tests a lane makes per scheduled triangle block
 #ifndef RT_NODE_PER_STEP
 #define RT_NODE_PER_STEP 8
@@ -1237,11 +1244,11 @@ constexpr bool kSpeculate = RT_SPECULATE != 0;  // k_paths: postpone a leaf reac
 // while a shadow ray is traced, the slot's path ray and the radiance to deposit wait in 9 more
 // dwords of LDS; the hit record is rebuilt from (tri, hu, hv) inside the ADV block.
 // LDS layout (dynamic): [stack: (stack_cap + 1) x kBlock (push_if)][parked ray: 9 x kBlock][slot state: 12 + 1 x kBlock][sample sum: 3 x kBlock][tables]
-template <bool LDS_TABLES, bool WIDE, bool MAJORITY, int MIN_WAVES>
+template <bool LDS_TABLES, bool WIDE, bool MAJORITY, int MIN_WAVES, bool DRAW_CIDS = false>
 __global__ void __launch_bounds__(kBlock, MIN_WAVES)
 k_paths(DScene sc, DPools p, Camera cam_arg, AdvanceParams ap_arg, float *__restrict__ fb, DWaveRow *__restrict__ rows,
         int stack_cap, int *overflow, int adv_batch, int debug_no_deposit, unsigned long long *prof, int top_n,
-        int prio_period, int rot_wave, int rot_set, int gen_batch, int tri_follow) {
+        int prio_period, int rot_wave, int rot_set, int gen_batch, int tri_follow, unsigned int *__restrict__ next_cid) {
     // The GEN block exists where the chip is short of issue slots (4 waves per SIMD): there it takes a third of the
     // lanes out of the long ADV block (+3 %, and the ADV block no longer spills).  On small shards (2 waves per
     // SIMD) a slot-round is a latency chain and one more block in it costs 5 %: gen() stays inside ADV there.
@@ -1284,6 +1291,12 @@ k_paths(DScene sc, DPools p, Camera cam_arg, AdvanceParams ap_arg, float *__rest
     const AdvanceParams &ap = s_uni->ap;
     // what the scheduling loop itself needs stays scalar
     const int ap_n = ap_arg.n, ap_max_bounces = ap_arg.max_bounces, ap_fb_fixed = ap_arg.fb_fixed;
+    // RT_FLAG_RNG_PER_SAMPLE: camera rays are not tied to slots, so the wave DRAWS them -- kCidChunk ids at a time from the
+    // frame's counter (one global atomic per chunk), handed to its lanes as they ask for one -- and no lane is left with more
+    // work than the others at the end of the frame (the static deal of slots costs 6 % there, 23 % on a 1/8 frame)
+    // (a build of its own -- DRAW_CIDS -- so that the reference-mode kernel carries none of it)
+    constexpr bool draw_cids = DRAW_CIDS && SPLIT_GEN;
+    int cid_next = 0, cid_end = 0;
     // A lane works through the slots i, i + G, i + 2G, ... (G = lanes of the grid), each for the whole
     // frame, one after the other: with G dividing the slot count every lane gets the same number of
     // slots, so all lanes -- and all workgroups, which are all resident -- finish together.
@@ -1475,6 +1488,24 @@ k_paths(DScene sc, DPools p, Camera cam_arg, AdvanceParams ap_arg, float *__rest
             out.ray_o = o;
             out.ray_d = d;
             bool hand_back = false;
+            long long my_cid = -1;
+            if (draw_cids) {
+                const unsigned long long m = wave_ballot(phase == PH_GEN);
+                const int need = (int)__popcll(m), rank = (int)prefix_popc(m);
+                int served = 0;
+                while (served < need) {
+                    if (cid_next == cid_end) {
+                        unsigned base = 0;
+                        if (lane_id() == 0) base = atomicAdd(next_cid, (unsigned)kCidChunk);
+                        cid_next = (int)min(__builtin_amdgcn_readfirstlane(base), 0x7fffff00u);  // (past the frame's end: "none left")
+                        cid_end = cid_next + kCidChunk;
+                    }
+                    const int take = min(need - served, cid_end - cid_next);
+                    if (phase == PH_GEN && rank >= served && rank < served + take) my_cid = cid_next + (rank - served);
+                    cid_next += take;
+                    served += take;
+                }
+            }
             if (phase == PH_GEN) {
                 SlotState st;
                 st.gen = cold[2 * kBlock];
@@ -1485,7 +1516,7 @@ k_paths(DScene sc, DPools p, Camera cam_arg, AdvanceParams ap_arg, float *__rest
                 st.beta = mk(0, 0, 0);
                 int pxy = cold[12 * kBlock];
                 acc_flush(acc, fb, ap_fb_fixed, cold[1 * kBlock]);  // the camera ray that ended: its sum -> its pixel
-                gen_core<true>(cam, ap, ap.slot_lo + i, st, out, &pxy);
+                gen_core<true>(cam, ap, ap.slot_lo + i, st, out, &pxy, my_cid);
                 // the slot state gen() leaves: bounces (0, or the kDone / kParked sentinel), gen, the RNG; a new path also
                 // has its pixel and beta = 1
                 cold[0 * kBlock] = st.bounces;
@@ -1516,7 +1547,10 @@ k_paths(DScene sc, DPools p, Camera cam_arg, AdvanceParams ap_arg, float *__rest
             cur = nr ? 0 : cur;
             sp = nr ? 0 : sp;
             if (wave_ballot(hand_back)) {  // rare (once per slot and frame): kept out of the merges above
-                if (hand_back) next_slot(PH_GEN);
+                if (hand_back) {
+                    if (draw_cids) phase = PH_IDLE;  // (the frame's counter has run out: nothing is tied to this lane's slot)
+                    else next_slot(PH_GEN);
+                }
             }
             n_gen += wave_count((out.did_gen));
             n_traced += wave_count((out.new_ray));
@@ -2733,12 +2767,22 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
     do {                                                                                                               \
         if (few_blocks)                                                                                                \
             hipLaunchKernelGGL((k_paths<T, WD, MJ, 2>), grid_paths, block, lds_paths, st, sc, c.pools, cam, ap, d_sum,   \
-                               c.d_rows, paths_cap, d_over2, adv_batch, dbg, paths_prof, top_n, prio_rotate, rot_wave, rot_set, gen_batch, tri_follow); \
+                               c.d_rows, paths_cap, d_over2, adv_batch, dbg, paths_prof, top_n, prio_rotate, rot_wave, rot_set, gen_batch, tri_follow, &c.d_ctr->pad2[0]); \
         else                                                                                                           \
             hipLaunchKernelGGL((k_paths<T, WD, MJ, 4>), grid_paths, block, lds_paths, st, sc, c.pools, cam, ap, d_sum,   \
-                               c.d_rows, paths_cap, d_over2, adv_batch, dbg, paths_prof, 0, prio_rotate, rot_wave, rot_set, gen_batch, tri_follow);     \
+                               c.d_rows, paths_cap, d_over2, adv_batch, dbg, paths_prof, 0, prio_rotate, rot_wave, rot_set, gen_batch, tri_follow, &c.d_ctr->pad2[0]);     \
     } while (0)
-        if (majority) {
+        if (per_sample && !few_blocks) {
+            // per-sample streams: the build in which the waves draw their camera rays from the frame's counter
+#define RT_LAUNCH_DRAW(T, WD)                                                                                          \
+    hipLaunchKernelGGL((k_paths<T, WD, true, 4, true>), grid_paths, block, lds_paths, st, sc, c.pools, cam, ap, d_sum,  \
+                       c.d_rows, paths_cap, d_over2, adv_batch, dbg, paths_prof, 0, prio_rotate, rot_wave, rot_set, gen_batch, tri_follow, &c.d_ctr->pad2[0])
+            if (lds_tables && scene->wide) RT_LAUNCH_DRAW(true, true);
+            else if (lds_tables) RT_LAUNCH_DRAW(true, false);
+            else if (scene->wide) RT_LAUNCH_DRAW(false, true);
+            else RT_LAUNCH_DRAW(false, false);
+#undef RT_LAUNCH_DRAW
+        } else if (majority) {
             if (lds_tables && scene->wide) RT_LAUNCH_PATHS(true, true, true);
             else if (lds_tables) RT_LAUNCH_PATHS(true, false, true);
             else if (scene->wide) RT_LAUNCH_PATHS(false, true, true);

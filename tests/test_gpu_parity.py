@@ -483,3 +483,23 @@ def test_device_lbvh_builder_gives_the_same_image(api, oracle, cpu_matte, bunny_
         assert _rms(img_m, img_ref).max() < 2e-6
         print("LBVH build", info["build_seconds"], "s (wide=%s); host SAH build" % wide, ref_info["build_seconds"], "s")
         sc.close()
+
+
+def test_split_probe_counts_what_the_frame_traces(api, gpu_full):
+    """rt_split_probe (the stage split priced: tools/split_probe.py) on a small frame: the rays and shading records it dumps
+    are the frame's own -- as many closest-hit rays as the round pipeline traces in those rounds, every shading record in
+    one of the three material buckets -- and every timed stage reports a positive time."""
+    w, h, spp = 320, 180, 64  # 3.5 generations
+    r = api.split_probe(gpu_full, api.make_camera(aspect=w / h), w, h, spp, target_rays=3_000_000)
+    assert r["rounds"] >= 2 and r["closest_rays"] + r["any_rays"] >= 3_000_000
+    assert r["closest_rays"] <= r["rounds"] * api.W and 0 < r["any_rays"] < r["closest_rays"]
+    shades = r["shades_matte"] + r["shades_mirror"] + r["shades_glass"]
+    assert r["shades_matte"] > r["shades_mirror"] > 0 and r["shades_glass"] > 0
+    assert r["any_rays"] <= shades <= r["closest_rays"]  # a shadow ray needs a shade; a shade needs a path ray that hit
+    for k in ("s_advance_round0", "s_advance", "s_trace_pool", "s_shade_matte", "s_shade_mirror", "s_shade_glass"):
+        assert r[k] > 0, k
+    for wv in (8, 6, 5, 4):
+        assert r[f"s_trace_closest_w{wv}"] > 0 and r[f"s_trace_any_w{wv}"] > 0 and r[f"trace_blocks_per_cu_w{wv}"] >= 1
+    # the frame itself is untouched by the probe (its own context, its own buffers)
+    img, st = gpu_full.render(api.make_camera(aspect=w / h), w, h, spp)
+    assert st["camera_rays"] == w * h * spp
