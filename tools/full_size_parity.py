@@ -28,7 +28,7 @@ variant = args[1] if len(args) > 1 else "full_bsdf"
 do_literal = "--no-literal" not in sys.argv
 arrays = scenes.cornell_bunny(variant)
 gpu = api.Scene(arrays)
-out = {"frame": f"{variant} {w}x{h}x{spp}", "samples": w * h * spp}
+out = {"frame": f"{variant} {w}x{h}x{spp}", "samples": w * h * spp, "build_id": api.build_id()}
 pairs = (("shade_events", "sum_mat"), ("any_rays", "sum_ah"), ("emission_adds", "emission_adds"),
          ("shadow_adds", "ah_adds"), ("rr_draws", "rr_draws"))
 img, st = gpu.render(api.make_camera(aspect=w / h), w, h, spp)
