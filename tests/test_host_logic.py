@@ -220,16 +220,19 @@ def test_full_pool_k_paths_build_does_not_spill_vector_registers():
     lines = r.stdout.splitlines()
     found = 0
     for k, line in enumerate(lines):
-        # k_paths<LDS_TABLES = true, WIDE = true (bench) / false, MAJORITY = true, MIN_WAVES = 4>
-        if "Function Name: _Z7k_pathsILb1ELb1ELb1ELi4E" in line or "Function Name: _Z7k_pathsILb1ELb0ELb1ELi4E" in line:
-            block = "\n".join(lines[k:k + 12])
-            m_spill = re.search(r"VGPRs Spill: (\d+)", block)
-            m_occ = re.search(r"Occupancy \[waves/SIMD\]: (\d+)", block)
-            assert m_spill and m_occ, block
-            assert int(m_occ.group(1)) == 4, block
-            assert int(m_spill.group(1)) == 0, block
-            found += 1
-    assert found == 2, "k_paths<true, {true, false}, true, 4> not in the resource remarks"
+        # k_paths<LDS_TABLES = true, WIDE = true (bench) / false, MAJORITY = true, MIN_WAVES = 4, DRAW_CIDS = false>: the
+        # reference-mode builds; DRAW_CIDS = true: the per-sample-RNG builds (fewer registers: at least 4 waves)
+        for draw in (0, 1):
+            if (f"Function Name: _Z7k_pathsILb1ELb1ELb1ELi4ELb{draw}E" in line
+                    or f"Function Name: _Z7k_pathsILb1ELb0ELb1ELi4ELb{draw}E" in line):
+                block = "\n".join(lines[k:k + 12])
+                m_spill = re.search(r"VGPRs Spill: (\d+)", block)
+                m_occ = re.search(r"Occupancy \[waves/SIMD\]: (\d+)", block)
+                assert m_spill and m_occ, block
+                assert int(m_occ.group(1)) == 4 if draw == 0 else int(m_occ.group(1)) >= 4, block
+                assert int(m_spill.group(1)) == 0, block
+                found += 1
+    assert found == 4, "k_paths<true, {true, false}, true, 4, {false, true}> not in the resource remarks"
 
 
 def test_bench_refuses_debug_flags_without_allow_invalid():
