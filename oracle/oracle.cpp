@@ -4,6 +4,12 @@
 // cpu_baseline leg and __graft_entry__.smoke() may load it.  Nothing under rtcuda_amd/ links,
 // imports or calls it.
 //
+// PARITY UNPINNED.  The reference ships no test, fixture or golden image for this path and cannot be
+// built or run in this image (nvcc, cuRAND, CUB absent), so nothing the reference itself produced pins
+// this restatement: its pins are the known answers SURVEY.md Appendix C records
+// (tests/golden/appendix_c.json, tests/test_oracle_pins.py) and the committed outputs of its own two
+// modes (tests/golden/render_goldens.npz).
+//
 // What it restates (file:line into the reference tree; nothing is copied, every function is
 // re-written from the behaviour read there):
 //   vec3.cuh:32-147          V3 arithmetic forms (Vec3/float == multiply by reciprocal, ...)
