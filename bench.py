@@ -293,7 +293,7 @@ def main():
                     "reference_equivalent_bytes_per_sample": round(ref_bytes / (float(w) * h * spp / world), 1) if persistent else None,
                     "np_tt_source": np_src}
             pmc_file = os.path.join(ROOT, "profiles", "pmc_k_paths.json")
-            key = f"{args.scene}_{w}x{h}x{spp}_n{world}"
+            key = f"{args.scene}_{w}x{h}x{spp}_n{world}" + ("" if args.rng_mode == "reference" else "_" + args.rng_mode)  # (another build of the kernel)
             pmc = json.load(open(pmc_file)).get(key) if os.path.exists(pmc_file) else None
             roof["build_id"] = api.build_id()
             if pmc and pmc.get("kernel") == kernel and pmc.get("build_id") != roof["build_id"]:
