@@ -39,11 +39,12 @@ for setting in (args or [""]):
         torch.cuda.synchronize()
         if r > 0:
             times.append(time.perf_counter() - t)
+    digest = float(torch.nan_to_num(fb.double()).sum().item())  # (float atomics: equal sums to ~1e-9 relative between result-invariant knobs)
     sc.close()
     for k in env:
         del os.environ[k]
     best, mean = min(times) * 1e3, sum(times) / len(times) * 1e3
     base = base or best
     print(f"{setting or '(defaults)':40s} best {best:8.2f} ms  mean {mean:8.2f} ms  kernel {st['seconds_trace'] * 1e3:8.2f} ms  "
-          f"x{base / best:.3f}  events {st['camera_rays']} {st['shade_events']} {st['any_rays']} {st['shadow_adds']} {st['rr_draws']}",
+          f"x{base / best:.3f}  events {st['camera_rays']} {st['shade_events']} {st['any_rays']} {st['shadow_adds']} {st['rr_draws']}  image sum {digest:.6f}",
           flush=True)
