@@ -1808,534 +1808,6 @@ k_paths(DScene sc, DPools p, Camera cam_arg, AdvanceParams ap_arg, float *__rest
     row_add(rows, v);
 }
 
-// ============================================================================ k_paths_share
-// k_paths whose ADV and GEN blocks also serve the OTHER waves of the workgroup.
-//
-// An ADV block runs for the ~30 lanes of the wave that wait for it and a GEN block for ~15; the other lanes sit through
-// it.  Everything a shade or a gen() needs of a slot is in the slot's LDS column (state, sample sum; the hit record and
-// the spawned rays can be put there), and LDS is the workgroup's.  So: a lane that starts to wait PUBLISHES the fact (its
-// bit in its wave's 64-bit word); a wave that runs a block first takes its own word (those lanes it serves from
-// registers, as k_paths does), then takes the words of the other three waves as far as it has lanes left, and serves
-// those columns through LDS: results into the column, a mail word for the owner.  Nobody waits for a batch to fill -- a
-// block runs when k_paths would run it -- so no lane is served later than in k_paths, and the lanes another wave picks up are
-// served earlier.  (The pure queue version, k_paths_pool of commit fe0c3de, made lanes wait for full batches and lost.)
-//
-// Protocol (LDS, workgroup scope; LDS executes a wave's operations in order):
-//   owner   hit record -> its idle stack rows; then OR its bit into word[kind][wave]      (one atomic per wave and round)
-//   server  own word: exchange with 0.  Other words: compare-and-swap to 0 if all its bits fit the lanes left.  A taken
-//           bit is a claim: nobody else serves that column.  Columns are dealt to the free lanes through a scratch row.
-//   server  results of a foreign column -> its stack / parked-ray rows; release; mail word
-//   owner   lanes that wait read their mail word at every scheduling decision; acquire; rays -> registers
-enum { SW_NONE = 0, SW_SHADOW = 1, SW_PATH = 2, SW_BACK = 3, SW_GEN = 4 };  // mail: what the server left in the column
-constexpr int kShareMailRows = 8;  // stack rows a hit record (6) or a spawned shadow ray (8) occupies while a column waits
-constexpr int kShareRows = 27;     // rows of a column besides its stack rows: 9 parked ray + radiance, 15 slot state, 3 sample sum
-
-
-// LDS layout (dynamic): columns [parked ray + radiance: 9][slot state: 15][sample sum: 3][stack: max(stack_cap + 1, 8)] x kBlock,
-// then [words: 2 kinds x 4 waves x 64 bit][scratch: kBlock ints][tables][uniforms]
-template <bool LDS_TABLES, bool WIDE>
-__global__ void __launch_bounds__(kBlock, 4)
-k_paths_share(DScene sc, DPools p, Camera cam_arg, AdvanceParams ap_arg, float *__restrict__ fb, DWaveRow *__restrict__ rows,
-              int stack_cap, int *overflow, int adv_batch, int debug_no_deposit, int prio_period, int rot_wave, int rot_set,
-              int gen_batch, int tri_follow) {
-    extern __shared__ int s_lds[];
-    const int col = (int)threadIdx.x;
-    const int srows = max(stack_cap + 1, kShareMailRows);
-    // (the rows whose number is fixed come first: every row of a column is then the column's address plus a constant)
-    float *const park_rows = (float *)s_lds;  // row r of column c at [r * kBlock + c]
-    int *const cold_rows = s_lds + 9 * kBlock;
-    float *const acc_rows = (float *)(s_lds + 24 * kBlock);
-    int *const stack_rows = s_lds + kShareRows * kBlock;
-    unsigned long long *const words = (unsigned long long *)(s_lds + (srows + kShareRows) * kBlock);  // [kind 0 = ADV, 1 = GEN][wave]
-    int *const scratch = (int *)(words + 8);
-    float *s_tab = (float *)(scratch + kBlock);
-    int *stack = stack_rows + col;
-    float *park = park_rows + col;
-    int *cold = cold_rows + col;  // 0..11 slot state, 12 previous pixel (x | y << 16), 13 slot index, 14 mail
-    float *acc = acc_rows + col;
-    int *over = overflow + (blockIdx.x * kBlock + threadIdx.x) % kOverStride;
-    const float *tab = sc.tables;
-    if (LDS_TABLES) {
-        for (int k = threadIdx.x; k < sc.tab_dwords; k += kBlock) s_tab[k] = sc.tables[k];
-        tab = s_tab;
-    }
-    struct Uniforms {
-        Camera cam;
-        AdvanceParams ap;
-    };
-    static_assert(sizeof(Uniforms) % 4 == 0, "dword copy");
-    Uniforms *s_uni = (Uniforms *)(s_tab + (LDS_TABLES ? ((sc.tab_dwords + 3) & ~3) : 0));
-    {
-        Uniforms u;
-        u.cam = cam_arg;
-        u.ap = ap_arg;
-        const int *srcw = (const int *)&u;
-        for (int k = threadIdx.x; k < (int)(sizeof(Uniforms) / 4); k += kBlock) ((int *)s_uni)[k] = srcw[k];
-    }
-    if (col < 8) words[col] = 0ull;
-    cold[14 * kBlock] = SW_NONE;
-    acc[0 * kBlock] = acc[1 * kBlock] = acc[2 * kBlock] = 0.f;
-    __syncthreads();
-    const Camera &cam = s_uni->cam;
-    const AdvanceParams &ap = s_uni->ap;
-    const int ap_n = ap_arg.n, ap_max_bounces = ap_arg.max_bounces, ap_fb_fixed = ap_arg.fb_fixed;
-    const int lanes_in_grid = (int)(gridDim.x * blockDim.x);
-    auto slot_of = [&](int set) {  // as in k_paths
-        const unsigned lane_in_grid = blockIdx.x * blockDim.x + threadIdx.x;
-        const unsigned wave_in_grid = lane_in_grid >> 6, lane_in_wave = lane_in_grid & 63u;
-        const unsigned b = (wave_in_grid + (wave_in_grid & 3u) * (unsigned)rot_wave + (unsigned)set * (unsigned)rot_set) &
-                           (((unsigned)lanes_in_grid >> 6) - 1u);
-        return set * lanes_in_grid + (int)(b * 64u + lane_in_wave);
-    };
-    int slot_set = 0;
-    int i = slot_of(0);
-    const unsigned lane = lane_id();
-    const int wave = __builtin_amdgcn_readfirstlane(col >> 6);  // this wave's index in the workgroup (a scalar)
-    auto slot_to_column = [&](int k) {
-        cold[0 * kBlock] = p.bounces(k);
-        cold[1 * kBlock] = p.pixel(k);
-        cold[2 * kBlock] = p.gen(k);
-        cold[3 * kBlock] = (int)p.rd(k);
-        cold[4 * kBlock] = (int)p.r0(k);
-        cold[5 * kBlock] = (int)p.r1(k);
-        cold[6 * kBlock] = (int)p.r2(k);
-        cold[7 * kBlock] = (int)p.r3(k);
-        cold[8 * kBlock] = (int)p.r4(k);
-        cold[9 * kBlock] = __float_as_int(p.br(k));
-        cold[10 * kBlock] = __float_as_int(p.bg(k));
-        cold[11 * kBlock] = __float_as_int(p.bb(k));
-        cold[12 * kBlock] = -1;  // no previous pixel
-        cold[13 * kBlock] = k;
-    };
-    auto column_to_slot = [&](int k) {  // the lockstep rounds of the final generation continue from the pools
-        p.bounces(k) = cold[0 * kBlock];
-        p.pixel(k) = cold[1 * kBlock];
-        p.gen(k) = cold[2 * kBlock];
-        p.hit_info(k) = -1;
-        p.stmax(k) = -1.f;
-        p.rd(k) = (uint32_t)cold[3 * kBlock];
-        p.r0(k) = (uint32_t)cold[4 * kBlock];
-        p.r1(k) = (uint32_t)cold[5 * kBlock];
-        p.r2(k) = (uint32_t)cold[6 * kBlock];
-        p.r3(k) = (uint32_t)cold[7 * kBlock];
-        p.r4(k) = (uint32_t)cold[8 * kBlock];
-        p.br(k) = __int_as_float(cold[9 * kBlock]);
-        p.bg(k) = __int_as_float(cold[10 * kBlock]);
-        p.bb(k) = __int_as_float(cold[11 * kBlock]);
-    };
-    // LDS executes the operations of a wave in the order the wave issues them, and hands the results back in that order:
-    // "data, then flag" on the writer's side and "flag, then data" (behind the branch on the flag) on the reader's need no
-    // wait of their own -- only that the compiler keeps the order.  (A workgroup-scope fence would also wait for the wave's
-    // outstanding global loads and atomics.)
-    auto lds_order = [&]() { asm volatile("" ::: "memory"); };
-    // a lane says that it waits (kind 0: for ADV, 1: for GEN): one atomic OR per wave
-    auto publish = [&](bool want, int kind) {
-        const unsigned long long m = wave_ballot(want);
-        if (m) {
-            lds_order();  // (the column's rows before the bit)
-            if (lane == 0) atomicOr(&words[kind * 4 + wave], m);
-        }
-    };
-    auto uniform64 = [&](unsigned long long x) {
-        const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(x >> 32)), lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)x);  // (the builtin returns int: no sign extension into the upper word)
-        return ((unsigned long long)hi << 32) | (unsigned long long)lo;
-    };
-    // The columns a block of this wave works on: those of its own waiting lanes that nobody has taken yet (their bits come
-    // out of the wave's own word), and on the lanes that are left the waiting columns of the other waves (a whole word at a
-    // time, if it fits).  Returns the column the lane serves, or -1.
-    auto collect = [&](int kind, bool i_wait) {
-        unsigned long long *const w = words + kind * 4;
-        unsigned long long mine = 0ull, x1 = 0ull, x2 = 0ull, x3 = 0ull;
-        if (lane == 0) {  // (four LDS operations in flight at once)
-            mine = atomicExch(&w[wave], 0ull);
-            x1 = __hip_atomic_load(&w[(wave + 1) & 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            x2 = __hip_atomic_load(&w[(wave + 2) & 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            x3 = __hip_atomic_load(&w[(wave + 3) & 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-        mine = uniform64(mine);
-        const unsigned long long xs[3] = {uniform64(x1), uniform64(x2), uniform64(x3)};
-        const bool own = i_wait && ((mine >> lane) & 1ull);
-        int serve_col = own ? col : -1;
-        const unsigned long long free_mask = ~wave_ballot(own);
-        int left = (int)__popcll(free_mask), dealt = 0;
-#pragma unroll
-        for (int step = 0; step < 3; step++) {
-            const int v = (wave + 1 + step) & 3;
-            const unsigned long long x = xs[step];
-            const int nx = (int)__popcll(x);
-            if (nx == 0 || nx > left) continue;
-            unsigned long long got = ~x;
-            if (lane == 0) got = atomicCAS(&w[v], x, 0ull);
-            got = uniform64(got);
-            if (got != x) continue;  // (the word moved under us: left to a later block)
-            if ((x >> lane) & 1ull) scratch[wave * 64 + dealt + (int)prefix_popc(x)] = v * 64 + (int)lane;
-            dealt += nx;
-            left -= nx;
-        }
-        lds_order();  // (the taken columns' rows after their bits)
-        if (dealt > 0) {
-            const int q = (int)prefix_popc(free_mask);
-            if (!own && q < dealt) serve_col = scratch[wave * 64 + q];
-        }
-        return serve_col;
-    };
-#ifdef RT_SHARE_CHECK
-    unsigned long long ck_blocks[2] = {0, 0}, ck_served[2] = {0, 0}, ck_own[2] = {0, 0}, ck_iters = 0;
-#endif
-    int phase = PH_IDLE;
-    int tri = -1;
-    V3 o = mk(0, 0, 0), d = mk(0, 0, 0), inv = mk(0, 0, 0);
-    float tmax = 0.f, hu = 0.f, hv = 0.f;
-    int cur = kEntryDone, sp = 0;
-    int pend = kEntryDone;
-    if (i < ap_n) {
-        slot_to_column(i);
-        const int b = cold[0 * kBlock];
-        phase = (b != kDone && b != kParked) ? (int)PH_GEN : (int)PH_IDLE;  // (untouched slots: their first step is a gen())
-    }
-    publish(phase == PH_GEN, 1);
-    unsigned long long n_gen = 0, n_shade = 0, n_traced = 0, n_shadow = 0, n_emit = 0, n_deposit = 0, n_rr = 0;
-    unsigned prio_tick = 0;
-    const unsigned prio_rank = (4u * blockIdx.x) / gridDim.x;
-    while (true) {
-#ifdef RT_SHARE_CHECK
-        ck_iters++;
-#endif
-        if (prio_period && (prio_tick++ & ((1u << prio_period) - 1u)) == 0u) {
-            unsigned lvl = ((prio_tick >> prio_period) + prio_rank) & 3u;
-            lvl = max(lvl, prio_rank >> 1);
-            switch (lvl) {
-                case 0: __builtin_amdgcn_s_setprio(0); break;
-                case 1: __builtin_amdgcn_s_setprio(1); break;
-                case 2: __builtin_amdgcn_s_setprio(2); break;
-                default: __builtin_amdgcn_s_setprio(3); break;
-            }
-        }
-        // ---------------- what each lane wants next (a lane another wave has served counts as waiting until it has read its mail)
-        bool trav = phase == PH_ANY || phase == PH_CLOSEST;
-        bool want_node = trav && cur >= 0;
-        bool want_tri = trav && ((cur != kEntryDone && cur < 0) || (kSpeculate && pend != kEntryDone));
-        int n_adv = wave_count(phase == PH_ADV);
-        const int n_genw = wave_count(phase == PH_GEN);
-        int n_node = wave_count(want_node);
-        int n_tri = wave_count(want_tri);
-        if (n_adv + n_genw + n_node + n_tri == 0) break;
-        const bool run_adv = n_adv > 0 && ((n_adv >= adv_batch && 2 * n_adv >= n_node && 2 * n_adv >= n_tri) || n_node + n_tri == 0);
-        const bool run_gen = !run_adv && n_genw > 0 && (n_genw >= gen_batch || n_node + n_tri == 0);
-        if (run_gen) {
-            // ---------------- GEN block: gen() (render.cuh:250-275) on the columns this wave has taken
-            const int c = collect(1, phase == PH_GEN);
-#ifdef RT_SHARE_CHECK
-            ck_blocks[1]++;
-            ck_served[1] += wave_count(c >= 0);
-            ck_own[1] += wave_count(c == col);
-#endif
-            AdvanceOut out;
-            out.did_gen = out.new_ray = false;
-            if (c >= 0) {
-                int *const ccold = cold_rows + c;
-                int *const cstack = stack_rows + c;
-                float *const cacc = acc_rows + c;
-                SlotState st;
-                st.gen = ccold[2 * kBlock];
-                st.rs = Rng{(uint32_t)ccold[3 * kBlock], (uint32_t)ccold[4 * kBlock], (uint32_t)ccold[5 * kBlock],
-                            (uint32_t)ccold[6 * kBlock], (uint32_t)ccold[7 * kBlock], (uint32_t)ccold[8 * kBlock]};
-                st.bounces = 0;
-                st.pixel = 0;
-                st.beta = mk(0, 0, 0);
-                int pxy = ccold[12 * kBlock];
-                acc_flush(cacc, fb, ap_fb_fixed, ccold[1 * kBlock]);  // the camera ray that ended: its sum -> its pixel
-                gen_core<true>(cam, ap, ap.slot_lo + ccold[13 * kBlock], st, out, &pxy);
-                ccold[0 * kBlock] = st.bounces;
-                ccold[2 * kBlock] = st.gen;
-                ccold[3 * kBlock] = (int)st.rs.d;
-                ccold[4 * kBlock] = (int)st.rs.v0;
-                ccold[5 * kBlock] = (int)st.rs.v1;
-                ccold[6 * kBlock] = (int)st.rs.v2;
-                ccold[7 * kBlock] = (int)st.rs.v3;
-                ccold[8 * kBlock] = (int)st.rs.v4;
-                if (out.new_ray) {
-                    ccold[1 * kBlock] = st.pixel;
-                    ccold[9 * kBlock] = __float_as_int(st.beta.x);
-                    ccold[10 * kBlock] = __float_as_int(st.beta.y);
-                    ccold[11 * kBlock] = __float_as_int(st.beta.z);
-                    ccold[12 * kBlock] = pxy;
-                    cstack[0 * kBlock] = __float_as_int(out.ray_o.x);
-                    cstack[1 * kBlock] = __float_as_int(out.ray_o.y);
-                    cstack[2 * kBlock] = __float_as_int(out.ray_o.z);
-                    cstack[3 * kBlock] = __float_as_int(out.ray_d.x);
-                    cstack[4 * kBlock] = __float_as_int(out.ray_d.y);
-                    cstack[5 * kBlock] = __float_as_int(out.ray_d.z);
-                }
-                lds_order();
-                ccold[14 * kBlock] = out.new_ray ? (int)SW_PATH : (int)SW_BACK;
-            }
-            n_gen += wave_count(out.did_gen);
-            n_traced += wave_count(out.new_ray);
-        }
-        if (run_adv) {
-            // ---------------- ADV block: init() + mat() (render.cuh:84-248) on the columns this wave has taken
-            const int c = collect(0, phase == PH_ADV);
-#ifdef RT_SHARE_CHECK
-            ck_blocks[0]++;
-            ck_served[0] += wave_count(c >= 0);
-            ck_own[0] += wave_count(c == col);
-#endif
-            AdvanceOut out;
-            out.did_gen = out.did_shade = out.has_shadow = out.did_emit = out.new_ray = out.wants_gen = false;
-            out.rr_draws = 0;
-            if (c >= 0) {
-                int *const ccold = cold_rows + c;
-                int *const cstack = stack_rows + c;
-                float *const cpark = park_rows + c;
-                float *const cacc = acc_rows + c;
-                SlotState st;
-                st.bounces = ccold[0 * kBlock];
-                st.pixel = ccold[1 * kBlock];
-                st.gen = ccold[2 * kBlock];
-                st.rs = Rng{(uint32_t)ccold[3 * kBlock], (uint32_t)ccold[4 * kBlock], (uint32_t)ccold[5 * kBlock],
-                            (uint32_t)ccold[6 * kBlock], (uint32_t)ccold[7 * kBlock], (uint32_t)ccold[8 * kBlock]};
-                st.beta = mk(__int_as_float(ccold[9 * kBlock]), __int_as_float(ccold[10 * kBlock]), __int_as_float(ccold[11 * kBlock]));
-                // the hit record, from the rows its owner left it in
-                const int h_tri = cstack[0 * kBlock];
-                const float h_u = __int_as_float(cstack[1 * kBlock]), h_v = __int_as_float(cstack[2 * kBlock]);
-                st.wo = mk(__int_as_float(cstack[3 * kBlock]), __int_as_float(cstack[4 * kBlock]), __int_as_float(cstack[5 * kBlock]));
-                st.hit_info = -1;
-                st.isect_p = st.isect_n = mk(0, 0, 0);
-                if (h_tri >= 0) {  // hit record in the form mat() consumes (render.cuh:152-153, 311-316)
-                    Tri tr = load_tri(sc.tris, h_tri);
-                    float4 sh = sc.tri_shade[(unsigned)h_tri];
-                    st.isect_p = tri_point(tr, h_u, h_v);
-                    st.isect_n = mk(sh.x, sh.y, sh.z);
-                    st.hit_info = __float_as_int(sh.w);
-                }
-                advance_core<true, true, true>(sc, tab, cam, ap, 0, st, out, fb, cacc);
-                ccold[0 * kBlock] = st.bounces;
-                ccold[3 * kBlock] = (int)st.rs.d;
-                ccold[4 * kBlock] = (int)st.rs.v0;
-                ccold[5 * kBlock] = (int)st.rs.v1;
-                ccold[6 * kBlock] = (int)st.rs.v2;
-                ccold[7 * kBlock] = (int)st.rs.v3;
-                ccold[8 * kBlock] = (int)st.rs.v4;
-                ccold[9 * kBlock] = __float_as_int(st.beta.x);
-                ccold[10 * kBlock] = __float_as_int(st.beta.y);
-                ccold[11 * kBlock] = __float_as_int(st.beta.z);
-                int code = SW_GEN;  // out.wants_gen: Russian roulette ended the path (its draws are in the column's RNG state)
-                if (out.has_shadow) {  // the path ray and the radiance wait in the column's parked-ray rows, as in k_paths
-                    cpark[0 * kBlock] = out.ray_o.x;
-                    cpark[1 * kBlock] = out.ray_o.y;
-                    cpark[2 * kBlock] = out.ray_o.z;
-                    cpark[3 * kBlock] = out.ray_d.x;
-                    cpark[4 * kBlock] = out.ray_d.y;
-                    cpark[5 * kBlock] = out.ray_d.z;
-                    cpark[6 * kBlock] = out.s_L.x;
-                    cpark[7 * kBlock] = out.s_L.y;
-                    cpark[8 * kBlock] = out.s_L.z;
-                    cstack[0 * kBlock] = __float_as_int(out.s_o.x);
-                    cstack[1 * kBlock] = __float_as_int(out.s_o.y);
-                    cstack[2 * kBlock] = __float_as_int(out.s_o.z);
-                    cstack[3 * kBlock] = __float_as_int(out.s_d.x);
-                    cstack[4 * kBlock] = __float_as_int(out.s_d.y);
-                    cstack[5 * kBlock] = __float_as_int(out.s_d.z);
-                    cstack[6 * kBlock] = __float_as_int(out.s_tmax);
-                    cstack[7 * kBlock] = out.s_target;
-                    code = SW_SHADOW;
-                } else if (out.new_ray) {
-                    cstack[0 * kBlock] = __float_as_int(out.ray_o.x);
-                    cstack[1 * kBlock] = __float_as_int(out.ray_o.y);
-                    cstack[2 * kBlock] = __float_as_int(out.ray_o.z);
-                    cstack[3 * kBlock] = __float_as_int(out.ray_d.x);
-                    cstack[4 * kBlock] = __float_as_int(out.ray_d.y);
-                    cstack[5 * kBlock] = __float_as_int(out.ray_d.z);
-                    code = SW_PATH;
-                }
-                lds_order();
-                ccold[14 * kBlock] = code;
-            }
-            inv = inv_dir(d);  // (as in k_paths: 1 / d does not live across the block)
-            n_shade += wave_count(out.did_shade);
-            n_traced += wave_count(out.new_ray);
-            n_shadow += wave_count(out.has_shadow);
-            n_emit += wave_count(out.did_emit);
-            int rr = out.rr_draws;
-            if (wave_ballot(rr != 0)) {
-                for (int off = 32; off > 0; off >>= 1) rr += __shfl_xor(rr, off);
-                n_rr += (unsigned long long)rr;
-            }
-        }
-        // ---------------- mail: what a block -- this wave's a moment ago, or another wave's -- has left in the columns of the lanes that wait
-        {
-            int code = SW_NONE;
-            if (phase == PH_ADV || phase == PH_GEN) code = __hip_atomic_load(&cold[14 * kBlock], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (wave_ballot(code != SW_NONE)) {
-                lds_order();
-                bool regen = false, back = false;
-                if (code != SW_NONE) {
-                    cold[14 * kBlock] = SW_NONE;
-                    o = mk(__int_as_float(stack[0 * kBlock]), __int_as_float(stack[1 * kBlock]), __int_as_float(stack[2 * kBlock]));
-                    d = mk(__int_as_float(stack[3 * kBlock]), __int_as_float(stack[4 * kBlock]), __int_as_float(stack[5 * kBlock]));
-                    const float s_tmax = __int_as_float(stack[6 * kBlock]);
-                    const int s_target = stack[7 * kBlock];
-                    const bool sh = code == SW_SHADOW, ray = sh || code == SW_PATH;
-                    phase = sh ? (int)PH_ANY : (code == SW_PATH ? (int)PH_CLOSEST : (int)PH_GEN);
-                    tmax = sh ? s_tmax : kFltMax;
-                    tri = sh ? s_target : -1;
-                    hu = 0.f;
-                    cur = ray ? 0 : cur;
-                    sp = 0;
-                    regen = code == SW_GEN;
-                    back = code == SW_BACK;
-                }
-                inv = inv_dir(d);
-                if (wave_ballot(back)) {  // rare (once per slot and frame)
-                    if (back) {
-                        // no camera ray left (or parked for the lockstep final generation): back to the pools, next slot
-                        column_to_slot(i);
-                        phase = PH_IDLE;
-                        slot_set++;
-                        i = slot_of(slot_set);
-                        if (i < ap_n) {
-                            slot_to_column(i);
-                            const int b = cold[0 * kBlock];
-                            if (b != kDone && b != kParked) {
-                                phase = PH_GEN;
-                                regen = true;
-                            } else {
-                                i = ap_n;  // (cannot happen: untouched slots start alive)
-                            }
-                        }
-                    }
-                }
-                publish(regen, 1);
-                trav = phase == PH_ANY || phase == PH_CLOSEST;
-                want_node = trav && cur >= 0;
-                want_tri = trav && ((cur != kEntryDone && cur < 0) || (kSpeculate && pend != kEntryDone));
-                n_node = wave_count(want_node);
-                n_tri = wave_count(want_tri);
-            }
-        }
-        const bool is_any = phase == PH_ANY;
-        // ---------------- node steps / triangle tests: k_paths' blocks
-        auto node_block = [&](bool want) {
-            if (want) {
-                auto step = [&]() {
-                    if (cur >= 0) {
-                        inner_step<WIDE>(sc, o, inv, tmax, cur, sp, stack, over, stack_cap);
-                    } else if (kSpeculate && cur != kEntryDone && pend == kEntryDone && sp > 0) {
-                        pend = cur;  // a leaf: set it aside, go on with the next entry
-                        cur = stack_pop(stack, over, sp, stack_cap);
-                    }
-                };
-                if (kNodeCont == 0 || !WIDE) {
-#pragma unroll
-                    for (int rep = 0; rep < (WIDE ? kNodePerStepWide : kNodePerStep); rep++) step();
-                } else {
-#pragma unroll
-                    for (int rep = 0; rep < kNodePerStepWide; rep++) step();
-                    if (wave_count(cur >= 0) >= kNodeCont) {
-#pragma unroll
-                        for (int rep = 0; rep < kNodeExtra; rep++) step();
-                    }
-                }
-            }
-        };
-        auto tri_block = [&](bool want) {
-            if (want) {
-                int pd = pend, cu = cur;
-                int ks[kTriPerStep];
-                bool act[kTriPerStep];
-                Tri tr[kTriPerStep];
-#pragma unroll
-                for (int j = 0; j < kTriPerStep; j++) {
-                    const bool fp = kSpeculate && pd != kEntryDone;
-                    const bool leaf = cu != kEntryDone && cu < 0;
-                    act[j] = fp || leaf;
-                    const int enc = fp ? pd : cu;
-                    ks[j] = act[j] ? (~enc) >> 3 : ks[0];
-                    const bool more = ((~enc) & 7) > 1;
-                    const int rest = more ? enc - 7 : kEntryDone;
-                    int popped = kEntryDone;
-                    if (act[j] && !fp && !more && sp > 0) popped = stack_pop(stack, over, sp, stack_cap);
-                    pd = (act[j] && fp) ? rest : pd;
-                    cu = (act[j] && !fp) ? (more ? rest : popped) : cu;
-                    tr[j] = load_tri(sc.tris, ks[j]);
-                }
-                bool occluded = false;
-#pragma unroll
-                for (int j = 0; j < kTriPerStep; j++) {
-                    if (act[j] && !occluded) {
-                        float t, u, v;
-                        const bool hit = tri_intersect(tr[j], o, d, tmax, t, u, v);
-                        occluded = hit && is_any && ks[j] != tri;
-                        bool better = hit && !is_any;
-                        if (better && t == tmax && tri >= 0) better = sc.order[(unsigned)ks[j]] > sc.order[(unsigned)tri];
-                        tmax = better ? t : tmax;
-                        hu = occluded ? 1.f : (better ? u : hu);
-                        hv = better ? v : hv;
-                        tri = better ? ks[j] : tri;
-                    }
-                }
-                pend = occluded ? kEntryDone : pd;
-                cur = occluded ? kEntryDone : cu;
-            }
-        };
-        if (n_node > 0 && n_node >= n_tri) {
-            node_block(want_node);
-            if (tri_follow > 0) {
-                const bool w = trav && ((cur != kEntryDone && cur < 0) || (kSpeculate && pend != kEntryDone));
-                if (wave_count(w) >= tri_follow) tri_block(w);
-            }
-        } else if (n_tri > 0) {
-            tri_block(want_tri);
-        }
-        // ---------------- finished rays
-        const bool fin = trav && cur == kEntryDone && (!kSpeculate || pend == kEntryDone);
-        n_deposit += wave_count(fin && is_any && hu == 0.f);
-        bool q_adv = false, q_gen = false;
-        if (fin) {
-            if (is_any) {
-                if (hu == 0.f && !debug_no_deposit)  // unoccluded: render.cuh:291-293
-                    acc_add(acc, park[6 * kBlock], park[7 * kBlock], park[8 * kBlock]);
-                // now the slot's path ray
-                o = mk(park[0 * kBlock], park[1 * kBlock], park[2 * kBlock]);
-                d = mk(park[3 * kBlock], park[4 * kBlock], park[5 * kBlock]);
-                phase = PH_CLOSEST;
-                inv = inv_dir(d);
-                tmax = kFltMax;
-                tri = -1;
-                cur = 0;
-                sp = 0;
-            } else {
-                // (tri, hu, hv, d) is the hit record: it stays in the registers for this wave's own ADV block and goes into the
-                // column's idle stack rows for any other wave's; a path that missed, or has no bounce left (and is not at
-                // bounce 0, where a hit light still emits: render.cuh:98-109), can only generate
-                const int b = cold[0 * kBlock];
-                q_gen = tri < 0 || (b >= ap_max_bounces && b > 0);
-                q_adv = !q_gen;
-                phase = q_gen ? (int)PH_GEN : (int)PH_ADV;
-                if (q_adv) {
-                    stack[0 * kBlock] = tri;
-                    stack[1 * kBlock] = __float_as_int(hu);
-                    stack[2 * kBlock] = __float_as_int(hv);
-                    stack[3 * kBlock] = __float_as_int(d.x);
-                    stack[4 * kBlock] = __float_as_int(d.y);
-                    stack[5 * kBlock] = __float_as_int(d.z);
-                }
-            }
-        }
-        publish(q_adv, 0);
-        publish(q_gen, 1);
-    }
-#ifdef RT_SHARE_CHECK
-    if (blockIdx.x % 97 == 0 && lane == 0 && wave == 1)
-        printf("block %d: iterations %llu | ADV blocks %llu, columns %.1f (own %.1f) | GEN blocks %llu, columns %.1f (own %.1f)\n", (int)blockIdx.x, ck_iters,
-               ck_blocks[0], (double)ck_served[0] / (double)max(ck_blocks[0], 1ull), (double)ck_own[0] / (double)max(ck_blocks[0], 1ull), ck_blocks[1],
-               (double)ck_served[1] / (double)max(ck_blocks[1], 1ull), (double)ck_own[1] / (double)max(ck_blocks[1], 1ull));
-#endif
-    unsigned long long v[C_COUNT] = {n_gen, n_shade, n_traced, n_shadow, n_emit, n_deposit, n_rr, 0ull};
-    row_add(rows, v);
-}
-
 // post_process_framebuffer (render.cuh:330-338): c = sqrt(c * (1/spp))
 __global__ void k_post_process(float *fb, int n_values, float inv_spp) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -3300,21 +2772,7 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
             hipLaunchKernelGGL((k_paths<T, WD, MJ, 4>), grid_paths, block, lds_paths, st, sc, c.pools, cam, ap, d_sum,   \
                                c.d_rows, paths_cap, d_over2, adv_batch, dbg, paths_prof, 0, prio_rotate, rot_wave, rot_set, gen_batch, tri_follow, &c.d_ctr->pad2[0]);     \
     } while (0)
-        int share = 0;
-        if (const char *e = getenv("RT_SHARE")) share = atoi(e);
-        if (share && !per_sample && !few_blocks) {
-            const int srows = std::max(paths_cap + 1, kShareMailRows);
-            const size_t lds_share = sizeof(int) * (size_t)kBlock * (size_t)(srows + kShareRows + 1) + 64 +
-                                     (lds_tables ? sizeof(float) * (size_t)((scene->tab_dwords + 3) & ~3) : 0) + sizeof(Camera) + sizeof(AdvanceParams);
-#define RT_LAUNCH_SHARE(T, WD)                                                                                         \
-    hipLaunchKernelGGL((k_paths_share<T, WD>), grid_paths, block, lds_share, st, sc, c.pools, cam, ap, d_sum, c.d_rows,   \
-                       paths_cap, d_over2, adv_batch, dbg, prio_rotate, rot_wave, rot_set, gen_batch, tri_follow)
-            if (lds_tables && scene->wide) RT_LAUNCH_SHARE(true, true);
-            else if (lds_tables) RT_LAUNCH_SHARE(true, false);
-            else if (scene->wide) RT_LAUNCH_SHARE(false, true);
-            else RT_LAUNCH_SHARE(false, false);
-#undef RT_LAUNCH_SHARE
-        } else if (per_sample && !few_blocks) {
+        if (per_sample && !few_blocks) {
             // per-sample streams: the build in which the waves draw their camera rays from the frame's counter
 #define RT_LAUNCH_DRAW(T, WD)                                                                                          \
     hipLaunchKernelGGL((k_paths<T, WD, true, 4, true>), grid_paths, block, lds_paths, st, sc, c.pools, cam, ap, d_sum,  \
