@@ -1808,6 +1808,544 @@ k_paths(DScene sc, DPools p, Camera cam_arg, AdvanceParams ap_arg, float *__rest
     row_add(rows, v);
 }
 
+// ============================================================================ k_paths_pair
+// k_paths for SMALL SHARDS (an 8-GPU run: 2^17 slots per GPU, half the lanes the chip holds).  There a frame is a latency
+// chain -- every slot walks through its ~506 camera rays one after the other, and the chip waits with it -- and the only
+// way to shorten a chain is to take work out of it.  The shadow ray is such work: mat() spawns it together with the
+// path ray, its outcome feeds nothing but the framebuffer, yet in k_paths the lane traces it BEFORE its path ray.
+// Here a workgroup is 8 waves: waves 0..3 are k_paths (a lane owns a slot), waves 4..7 are HELPERS -- helper lane h
+// traces the shadow rays of slot lane h.  mat() posts the shadow ray (ray, excluded triangle, radiance, pixel) in the
+// lane's LDS mailbox and goes straight on with the path ray; the helper picks it up, traces it and deposits.  The
+// helpers run in the issue slots and the registers the half-empty chip has to spare (2 + 2 waves per SIMD).
+//   mailbox: one ray deep; the helper empties it when it STARTS on the ray, so a lane has two shadow rays in flight at
+//   most; when the mailbox is still full, the lane traces the shadow ray itself, as k_paths does (nobody ever waits).
+//   Results: the same RNG sequences, the same rays, the same deposits; only the order of the float atomics moves (it
+//   is not fixed in the reference either: vec3.cuh:149-153), and the deterministic int64 sums are equal bit for bit.
+// LDS layout (dynamic): slot lanes [stack: stack_cap + 1][parked ray: 9][slot state: 13][sample sum: 3][mailbox: 13] x kBlock,
+//                       helper lanes [stack: stack_cap + 1] x kBlock, [waves done][tables][uniforms]
+constexpr int kPairBlock = 2 * kBlock;
+constexpr int kMailRows = 13;  // o, d, tmax, excluded triangle, radiance, pixel; flag
+template <bool LDS_TABLES, bool WIDE>
+__global__ void __launch_bounds__(kPairBlock, 4)
+k_paths_pair(DScene sc, DPools p, Camera cam_arg, AdvanceParams ap_arg, float *__restrict__ fb, DWaveRow *__restrict__ rows,
+             int stack_cap, int *overflow, int adv_batch, int debug_no_deposit, int prio_period, int rot_wave, int rot_set,
+             int tri_follow) {
+    extern __shared__ int s_lds[];
+    const bool helper = threadIdx.x >= kBlock;
+    const int col = (int)threadIdx.x & (kBlock - 1);  // the slot lane's column; a helper lane has its partner's
+    const int slot_rows = stack_cap + 1 + 9 + 13 + 3 + kMailRows;
+    int *stack = s_lds + (helper ? slot_rows * kBlock : 0) + col;
+    float *park = (float *)(s_lds + (stack_cap + 1) * kBlock) + col;
+    int *cold = s_lds + (stack_cap + 10) * kBlock + col;
+    float *acc = (float *)(s_lds + (stack_cap + 23) * kBlock) + col;
+    int *mail = s_lds + (stack_cap + 26) * kBlock + col;  // element k at mail[k * kBlock]; [12] = 1: a shadow ray waits
+    int *s_done = s_lds + (slot_rows + stack_cap + 1) * kBlock;  // slot waves that have finished
+    float *s_tab = (float *)(s_done + 4);
+    int *over = overflow + (blockIdx.x * kPairBlock + threadIdx.x) % kOverStride;
+    const float *tab = sc.tables;
+    if (LDS_TABLES) {
+        for (int k = threadIdx.x; k < sc.tab_dwords; k += kPairBlock) s_tab[k] = sc.tables[k];
+        tab = s_tab;
+    }
+    struct Uniforms {
+        Camera cam;
+        AdvanceParams ap;
+    };
+    static_assert(sizeof(Uniforms) % 4 == 0, "dword copy");
+    Uniforms *s_uni = (Uniforms *)(s_tab + (LDS_TABLES ? ((sc.tab_dwords + 3) & ~3) : 0));
+    {
+        Uniforms u;
+        u.cam = cam_arg;
+        u.ap = ap_arg;
+        const int *srcw = (const int *)&u;
+        for (int k = threadIdx.x; k < (int)(sizeof(Uniforms) / 4); k += kPairBlock) ((int *)s_uni)[k] = srcw[k];
+    }
+    if (threadIdx.x == 0) s_done[0] = 0;
+    if (!helper) mail[12 * kBlock] = 0;
+    __syncthreads();  // (the only barrier: from here on the two halves of the workgroup go their own ways)
+    const int ap_fb_fixed = ap_arg.fb_fixed;
+    const unsigned row_index = blockIdx.x * (kBlock / 64) + ((unsigned)col >> 6);  // the slot wave's counter row (its helper wave adds to the same)
+
+    if (helper) {
+        // ------------------------------------------------------------------ helper waves: shadow rays (ah(): render.cuh:278-294)
+        V3 o = mk(0, 0, 0), d = mk(0, 0, 0), inv = mk(0, 0, 0), L = mk(0, 0, 0);
+        float tmax = 0.f;
+        bool occluded = false, busy = false;
+        int excluded = -1, pixel = 0;
+        int cur = kEntryDone, sp = 0, pend = kEntryDone;
+        // the contributions of one camera ray arrive one after the other: summed here, one atomic triple per camera ray
+        float sum_r = 0.f, sum_g = 0.f, sum_b = 0.f;
+        int sum_pixel = -1;
+        unsigned long long n_deposit = 0;
+#ifdef RT_PAIR_CHECK
+        unsigned long long hk_iters = 0, hk_sleeps = 0, hk_busy = 0, hk_rays = 0;
+#endif
+        while (true) {
+#ifdef RT_PAIR_CHECK
+            hk_iters++;
+            hk_busy += wave_count(busy);
+#endif
+            // ---- idle lanes look into their mailbox
+            int flag = 0;
+            if (!busy) flag = __hip_atomic_load(&mail[12 * kBlock], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#ifdef RT_PAIR_CHECK
+            hk_rays += wave_count(flag != 0);
+#endif
+            if (wave_ballot(flag != 0)) {
+                asm volatile("" ::: "memory");  // (LDS serves a wave in order: the ray's rows were written before the flag)
+                if (flag != 0) {
+                    o = mk(__int_as_float(mail[0 * kBlock]), __int_as_float(mail[1 * kBlock]), __int_as_float(mail[2 * kBlock]));
+                    d = mk(__int_as_float(mail[3 * kBlock]), __int_as_float(mail[4 * kBlock]), __int_as_float(mail[5 * kBlock]));
+                    tmax = __int_as_float(mail[6 * kBlock]);
+                    excluded = mail[7 * kBlock];
+                    L = mk(__int_as_float(mail[8 * kBlock]), __int_as_float(mail[9 * kBlock]), __int_as_float(mail[10 * kBlock]));
+                    pixel = mail[11 * kBlock];
+                    asm volatile("" ::: "memory");
+                    mail[12 * kBlock] = 0;  // the mailbox is free again while this ray is traced
+                    inv = inv_dir(d);
+                    busy = true;
+                    occluded = false;
+                    cur = 0;
+                    sp = 0;
+                    pend = kEntryDone;
+                }
+            }
+            const bool want_node = busy && cur >= 0;
+            const bool want_tri = busy && ((cur != kEntryDone && cur < 0) || (kSpeculate && pend != kEntryDone));
+            const int n_node = wave_count(want_node), n_tri = wave_count(want_tri);
+            if (n_node + n_tri == 0) {
+                if (wave_ballot(busy) == 0ull) {
+                    // nothing to trace: finished when the four slot waves are (their last rays were posted before they said so)
+                    const int done = __hip_atomic_load(s_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (done == kBlock / 64) {
+                        asm volatile("" ::: "memory");
+                        const int last = __hip_atomic_load(&mail[12 * kBlock], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (wave_ballot(last != 0) == 0ull) break;
+                    } else {
+#ifdef RT_PAIR_CHECK
+                        hk_sleeps++;
+#endif
+                        __builtin_amdgcn_s_sleep(4);
+                    }
+                    continue;
+                }
+            }
+            auto node_block = [&](bool want) {
+                if (want) {
+                    auto step = [&]() {
+                        if (cur >= 0) {
+                            inner_step<WIDE>(sc, o, inv, tmax, cur, sp, stack, over, stack_cap);
+                        } else if (kSpeculate && cur != kEntryDone && pend == kEntryDone && sp > 0) {
+                            pend = cur;
+                            cur = stack_pop(stack, over, sp, stack_cap);
+                        }
+                    };
+#pragma unroll
+                    for (int rep = 0; rep < (WIDE ? kNodePerStepWide + kNodeExtra : kNodePerStep); rep++) step();
+                }
+            };
+            auto tri_block = [&](bool want) {  // k_paths' triangle block, any-hit only (bvh.cuh:243)
+                if (want) {
+                    int pd = pend, cu = cur;
+                    int ks[kTriPerStep];
+                    bool act[kTriPerStep];
+                    Tri tr[kTriPerStep];
+#pragma unroll
+                    for (int j = 0; j < kTriPerStep; j++) {
+                        const bool fp = kSpeculate && pd != kEntryDone;
+                        const bool leaf = cu != kEntryDone && cu < 0;
+                        act[j] = fp || leaf;
+                        const int enc = fp ? pd : cu;
+                        ks[j] = act[j] ? (~enc) >> 3 : ks[0];
+                        const bool more = ((~enc) & 7) > 1;
+                        const int rest = more ? enc - 7 : kEntryDone;
+                        int popped = kEntryDone;
+                        if (act[j] && !fp && !more && sp > 0) popped = stack_pop(stack, over, sp, stack_cap);
+                        pd = (act[j] && fp) ? rest : pd;
+                        cu = (act[j] && !fp) ? (more ? rest : popped) : cu;
+                        tr[j] = load_tri(sc.tris, ks[j]);
+                    }
+#pragma unroll
+                    for (int j = 0; j < kTriPerStep; j++) {
+                        if (act[j] && !occluded) {
+                            float t, u, v;
+                            occluded = tri_intersect(tr[j], o, d, tmax, t, u, v) && ks[j] != excluded;
+                        }
+                    }
+                    pend = occluded ? kEntryDone : pd;
+                    cur = occluded ? kEntryDone : cu;
+                }
+            };
+            if (n_node > 0 && n_node >= n_tri) {
+                node_block(want_node);
+                if (tri_follow > 0) {
+                    const bool w = busy && ((cur != kEntryDone && cur < 0) || (kSpeculate && pend != kEntryDone));
+                    if (wave_count(w) >= tri_follow) tri_block(w);
+                }
+            } else if (n_tri > 0) {
+                tri_block(want_tri);
+            }
+            const bool fin = busy && cur == kEntryDone && (!kSpeculate || pend == kEntryDone);
+            n_deposit += (unsigned long long)wave_count(fin && !occluded);
+            if (fin) {
+                busy = false;
+                if (!occluded && !debug_no_deposit) {  // unoccluded: render.cuh:291-293
+                    if (pixel != sum_pixel) {
+                        if (sum_pixel >= 0) deposit(fb, ap_fb_fixed, sum_pixel, sum_r, sum_g, sum_b);
+                        sum_pixel = pixel;
+                        sum_r = sum_g = sum_b = 0.f;
+                    }
+                    sum_r += L.x;
+                    sum_g += L.y;
+                    sum_b += L.z;
+                }
+            }
+        }
+#ifdef RT_PAIR_CHECK
+        if (blockIdx.x % 61 == 0 && lane_id() == 0 && (col >> 6) == 1)
+            printf("block %d helper wave: iterations %llu (asleep %llu), busy lanes %.1f, rays %llu\n", (int)blockIdx.x, hk_iters, hk_sleeps, (double)hk_busy / (double)max(hk_iters - hk_sleeps, 1ull), hk_rays);
+#endif
+        if (sum_pixel >= 0) deposit(fb, ap_fb_fixed, sum_pixel, sum_r, sum_g, sum_b);
+        if (n_deposit != 0 && lane_id() == 0) atomicAdd(&rows[row_index].c[C_SHADOW_ADD], n_deposit);
+        return;
+    }
+
+    // ---------------------------------------------------------------------- slot waves: k_paths (its small-shard form: gen() inside the ADV block)
+    const Camera &cam = s_uni->cam;
+    const AdvanceParams &ap = s_uni->ap;
+    const int ap_n = ap_arg.n;
+    const int lanes_in_grid = (int)(gridDim.x * kBlock);
+    auto slot_of = [&](int set) {  // as in k_paths
+        const unsigned lane_in_grid = blockIdx.x * kBlock + threadIdx.x;
+        const unsigned wave_in_grid = lane_in_grid >> 6, lane_in_wave = lane_in_grid & 63u;
+        const unsigned b = (wave_in_grid + (wave_in_grid & 3u) * (unsigned)rot_wave + (unsigned)set * (unsigned)rot_set) &
+                           (((unsigned)lanes_in_grid >> 6) - 1u);
+        return set * lanes_in_grid + (int)(b * 64u + lane_in_wave);
+    };
+    int slot_set = 0;
+    int i = slot_of(0);
+    int bounces = kDone, pixel = 0, gen = 0;
+    Rng rs{0, 0, 0, 0, 0, 0};
+    V3 beta = mk(0, 0, 0);
+    auto load_slot = [&](int k) {
+        bounces = p.bounces(k);
+        pixel = p.pixel(k);
+        gen = p.gen(k);
+        rs = Rng{p.rd(k), p.r0(k), p.r1(k), p.r2(k), p.r3(k), p.r4(k)};
+        beta = mk(p.br(k), p.bg(k), p.bb(k));
+    };
+    auto store_slot = [&](int k) {
+        p.bounces(k) = bounces;
+        p.pixel(k) = pixel;
+        p.gen(k) = gen;
+        p.hit_info(k) = -1;
+        p.stmax(k) = -1.f;
+        p.br(k) = beta.x;
+        p.bg(k) = beta.y;
+        p.bb(k) = beta.z;
+        p.rd(k) = rs.d;
+        p.r0(k) = rs.v0;
+        p.r1(k) = rs.v1;
+        p.r2(k) = rs.v2;
+        p.r3(k) = rs.v3;
+        p.r4(k) = rs.v4;
+    };
+    auto cold_save = [&]() {
+        cold[0 * kBlock] = bounces;
+        cold[1 * kBlock] = pixel;
+        cold[2 * kBlock] = gen;
+        cold[3 * kBlock] = (int)rs.d;
+        cold[4 * kBlock] = (int)rs.v0;
+        cold[5 * kBlock] = (int)rs.v1;
+        cold[6 * kBlock] = (int)rs.v2;
+        cold[7 * kBlock] = (int)rs.v3;
+        cold[8 * kBlock] = (int)rs.v4;
+        cold[9 * kBlock] = __float_as_int(beta.x);
+        cold[10 * kBlock] = __float_as_int(beta.y);
+        cold[11 * kBlock] = __float_as_int(beta.z);
+    };
+    auto cold_load = [&]() {
+        bounces = cold[0 * kBlock];
+        pixel = cold[1 * kBlock];
+        gen = cold[2 * kBlock];
+        rs = Rng{(uint32_t)cold[3 * kBlock], (uint32_t)cold[4 * kBlock], (uint32_t)cold[5 * kBlock],
+                 (uint32_t)cold[6 * kBlock], (uint32_t)cold[7 * kBlock], (uint32_t)cold[8 * kBlock]};
+        beta = mk(__int_as_float(cold[9 * kBlock]), __int_as_float(cold[10 * kBlock]), __int_as_float(cold[11 * kBlock]));
+    };
+    int phase = PH_IDLE;
+    int tri = -1;
+    V3 o = mk(0, 0, 0), d = mk(0, 0, 0), inv = mk(0, 0, 0);
+    float tmax = 0.f, hu = 0.f, hv = 0.f;
+    int cur = kEntryDone, sp = 0;
+    auto next_slot = [&]() {
+        cold_load();
+        store_slot(i);
+        phase = PH_IDLE;
+        tri = -1;
+        slot_set++;
+        i = slot_of(slot_set);
+        if (i < ap_n) {
+            load_slot(i);
+            if (bounces != kDone && bounces != kParked) {
+                phase = PH_ADV;
+                cold_save();
+            } else {
+                i = ap_n;  // (cannot happen: untouched slots start alive)
+            }
+        }
+    };
+    int pend = kEntryDone;
+    acc[0 * kBlock] = acc[1 * kBlock] = acc[2 * kBlock] = 0.f;
+    if (i < ap_n) {
+        load_slot(i);
+        phase = (bounces != kDone && bounces != kParked) ? PH_ADV : PH_IDLE;  // (untouched slots: bounces = INT_MAX, their first step is a gen())
+        cold_save();
+    }
+    unsigned long long n_gen = 0, n_shade = 0, n_traced = 0, n_shadow = 0, n_emit = 0, n_deposit = 0, n_rr = 0;
+#ifdef RT_PAIR_CHECK
+    unsigned long long ck_posted = 0, ck_self = 0, ck_iters = 0, ck_adv = 0, ck_adv_lanes = 0;
+#endif
+    unsigned prio_tick = 0;
+    const unsigned prio_rank = (4u * blockIdx.x) / gridDim.x;
+    while (true) {
+        if (prio_period && (prio_tick++ & ((1u << prio_period) - 1u)) == 0u) {
+            unsigned lvl = ((prio_tick >> prio_period) + prio_rank) & 3u;
+            lvl = max(lvl, prio_rank >> 1);
+            switch (lvl) {
+                case 0: __builtin_amdgcn_s_setprio(0); break;
+                case 1: __builtin_amdgcn_s_setprio(1); break;
+                case 2: __builtin_amdgcn_s_setprio(2); break;
+                default: __builtin_amdgcn_s_setprio(3); break;
+            }
+        }
+#ifdef RT_PAIR_CHECK
+        ck_iters++;
+#endif
+        bool trav = phase == PH_ANY || phase == PH_CLOSEST;
+        bool want_node = trav && cur >= 0;
+        bool want_tri = trav && ((cur != kEntryDone && cur < 0) || (kSpeculate && pend != kEntryDone));
+        int n_adv = wave_count(phase == PH_ADV);
+        int n_node = wave_count(want_node);
+        int n_tri = wave_count(want_tri);
+        if (n_adv + n_node + n_tri == 0) break;
+        const bool run_adv = n_adv > 0 && ((n_adv >= adv_batch && 2 * n_adv >= n_node && 2 * n_adv >= n_tri) || n_node + n_tri == 0);
+        if (run_adv) {
+            // ---------------- ADV block: init() + mat() + gen()
+            AdvanceOut out;
+            out.did_gen = out.did_shade = out.has_shadow = out.did_emit = out.new_ray = false;
+            out.rr_draws = 0;
+            if (phase == PH_ADV) {
+                cold_load();
+                SlotState st;
+                st.bounces = bounces;
+                st.pixel = pixel;
+                st.gen = gen;
+                st.rs = rs;
+                st.beta = beta;
+                st.wo = d;
+                st.hit_info = -1;
+                st.isect_p = st.isect_n = mk(0, 0, 0);
+                if (tri >= 0) {  // hit record in the form mat() consumes (render.cuh:152-153, 311-316)
+                    Tri tr = load_tri(sc.tris, tri);
+                    float4 sh = sc.tri_shade[(unsigned)tri];
+                    st.isect_p = tri_point(tr, hu, hv);
+                    st.isect_n = mk(sh.x, sh.y, sh.z);
+                    st.hit_info = __float_as_int(sh.w);
+                }
+                const int posted = __hip_atomic_load(&mail[12 * kBlock], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // (read before the block's work: by the time it is needed it is there)
+                advance_core<false, true, true>(sc, tab, cam, ap, ap.slot_lo + i, st, out, fb, acc);
+                bounces = st.bounces;
+                pixel = st.pixel;
+                gen = st.gen;
+                rs = st.rs;
+                beta = st.beta;
+                if (out.has_shadow && posted == 0) {
+                    // the helper lane's: the shadow ray into the mailbox, and on with the path ray
+                    mail[0 * kBlock] = __float_as_int(out.s_o.x);
+                    mail[1 * kBlock] = __float_as_int(out.s_o.y);
+                    mail[2 * kBlock] = __float_as_int(out.s_o.z);
+                    mail[3 * kBlock] = __float_as_int(out.s_d.x);
+                    mail[4 * kBlock] = __float_as_int(out.s_d.y);
+                    mail[5 * kBlock] = __float_as_int(out.s_d.z);
+                    mail[6 * kBlock] = __float_as_int(out.s_tmax);
+                    mail[7 * kBlock] = out.s_target;
+                    mail[8 * kBlock] = __float_as_int(out.s_L.x);
+                    mail[9 * kBlock] = __float_as_int(out.s_L.y);
+                    mail[10 * kBlock] = __float_as_int(out.s_L.z);
+                    mail[11 * kBlock] = pixel;
+                    asm volatile("" ::: "memory");
+                    mail[12 * kBlock] = 1;
+                    o = out.ray_o;
+                    d = out.ray_d;
+                    phase = PH_CLOSEST;
+                    tmax = kFltMax;
+                    tri = -1;
+                } else if (out.has_shadow) {
+                    // the mailbox is still full: this lane traces the shadow ray itself, as in k_paths
+                    park[0 * kBlock] = out.ray_o.x;
+                    park[1 * kBlock] = out.ray_o.y;
+                    park[2 * kBlock] = out.ray_o.z;
+                    park[3 * kBlock] = out.ray_d.x;
+                    park[4 * kBlock] = out.ray_d.y;
+                    park[5 * kBlock] = out.ray_d.z;
+                    park[6 * kBlock] = out.s_L.x;
+                    park[7 * kBlock] = out.s_L.y;
+                    park[8 * kBlock] = out.s_L.z;
+                    o = out.s_o;
+                    d = out.s_d;
+                    phase = PH_ANY;
+                    tmax = out.s_tmax;
+                    tri = out.s_target;
+                    hu = 0.f;
+                } else if (out.new_ray) {
+                    o = out.ray_o;
+                    d = out.ray_d;
+                    phase = PH_CLOSEST;
+                    tmax = kFltMax;
+                    tri = -1;
+                } else {
+                    // this slot is out of camera rays (or parked for the lockstep final generation)
+                    cold_save();
+                    next_slot();
+                }
+                if (phase == PH_ANY || phase == PH_CLOSEST) {
+                    cur = 0;
+                    sp = 0;
+                }
+                if (phase != PH_IDLE) cold_save();
+            }
+            inv = inv_dir(d);
+            n_gen += wave_count(out.did_gen);
+            n_shade += wave_count(out.did_shade);
+            n_traced += wave_count(out.new_ray);
+            n_shadow += wave_count(out.has_shadow);
+#ifdef RT_PAIR_CHECK
+            ck_posted += wave_count(out.has_shadow && phase == PH_CLOSEST);
+            ck_self += wave_count(out.has_shadow && phase == PH_ANY);
+            ck_adv++;
+            ck_adv_lanes += wave_count(out.did_shade || out.did_gen);
+#endif
+            n_emit += wave_count(out.did_emit);
+            int rr = out.rr_draws;
+            if (wave_ballot(rr != 0)) {
+                for (int off = 32; off > 0; off >>= 1) rr += __shfl_xor(rr, off);
+                n_rr += (unsigned long long)rr;
+            }
+            trav = phase == PH_ANY || phase == PH_CLOSEST;
+            want_node = trav && cur >= 0;
+            want_tri = trav && ((cur != kEntryDone && cur < 0) || (kSpeculate && pend != kEntryDone));
+            n_node = wave_count(want_node);
+            n_tri = wave_count(want_tri);
+        }
+        const bool is_any = phase == PH_ANY;
+        auto node_block = [&](bool want) {
+            if (want) {
+                auto step = [&]() {
+                    if (cur >= 0) {
+                        inner_step<WIDE>(sc, o, inv, tmax, cur, sp, stack, over, stack_cap);
+                    } else if (kSpeculate && cur != kEntryDone && pend == kEntryDone && sp > 0) {
+                        pend = cur;  // a leaf: set it aside, go on with the next entry
+                        cur = stack_pop(stack, over, sp, stack_cap);
+                    }
+                };
+                if (kNodeCont == 0 || !WIDE) {
+#pragma unroll
+                    for (int rep = 0; rep < (WIDE ? kNodePerStepWide : kNodePerStep); rep++) step();
+                } else {
+#pragma unroll
+                    for (int rep = 0; rep < kNodePerStepWide; rep++) step();
+                    if (wave_count(cur >= 0) >= kNodeCont) {
+#pragma unroll
+                        for (int rep = 0; rep < kNodeExtra; rep++) step();
+                    }
+                }
+            }
+        };
+        auto tri_block = [&](bool want) {
+            if (want) {
+                int pd = pend, cu = cur;
+                int ks[kTriPerStep];
+                bool act[kTriPerStep];
+                Tri tr[kTriPerStep];
+#pragma unroll
+                for (int j = 0; j < kTriPerStep; j++) {
+                    const bool fp = kSpeculate && pd != kEntryDone;
+                    const bool leaf = cu != kEntryDone && cu < 0;
+                    act[j] = fp || leaf;
+                    const int enc = fp ? pd : cu;
+                    ks[j] = act[j] ? (~enc) >> 3 : ks[0];
+                    const bool more = ((~enc) & 7) > 1;
+                    const int rest = more ? enc - 7 : kEntryDone;
+                    int popped = kEntryDone;
+                    if (act[j] && !fp && !more && sp > 0) popped = stack_pop(stack, over, sp, stack_cap);
+                    pd = (act[j] && fp) ? rest : pd;
+                    cu = (act[j] && !fp) ? (more ? rest : popped) : cu;
+                    tr[j] = load_tri(sc.tris, ks[j]);
+                }
+                bool occluded = false;
+#pragma unroll
+                for (int j = 0; j < kTriPerStep; j++) {
+                    if (act[j] && !occluded) {
+                        float t, u, v;
+                        const bool hit = tri_intersect(tr[j], o, d, tmax, t, u, v);
+                        occluded = hit && is_any && ks[j] != tri;
+                        bool better = hit && !is_any;
+                        if (better && t == tmax && tri >= 0) better = sc.order[(unsigned)ks[j]] > sc.order[(unsigned)tri];
+                        tmax = better ? t : tmax;
+                        hu = occluded ? 1.f : (better ? u : hu);
+                        hv = better ? v : hv;
+                        tri = better ? ks[j] : tri;
+                    }
+                }
+                pend = occluded ? kEntryDone : pd;
+                cur = occluded ? kEntryDone : cu;
+            }
+        };
+        if (n_node > 0 && n_node >= n_tri) {
+            node_block(want_node);
+            if (tri_follow > 0) {
+                const bool w = trav && ((cur != kEntryDone && cur < 0) || (kSpeculate && pend != kEntryDone));
+                if (wave_count(w) >= tri_follow) tri_block(w);
+            }
+        } else if (n_tri > 0) {
+            tri_block(want_tri);
+        }
+        const bool fin = trav && cur == kEntryDone && (!kSpeculate || pend == kEntryDone);
+        n_deposit += wave_count(fin && is_any && hu == 0.f);
+        if (fin) {
+            if (is_any) {
+                if (hu == 0.f && !debug_no_deposit)  // unoccluded: render.cuh:291-293
+                    acc_add(acc, park[6 * kBlock], park[7 * kBlock], park[8 * kBlock]);
+                o = mk(park[0 * kBlock], park[1 * kBlock], park[2 * kBlock]);
+                d = mk(park[3 * kBlock], park[4 * kBlock], park[5 * kBlock]);
+                phase = PH_CLOSEST;
+                inv = inv_dir(d);
+                tmax = kFltMax;
+                tri = -1;
+                cur = 0;
+                sp = 0;
+            } else {
+                phase = PH_ADV;  // (tri, hu, hv, d) carry the hit to the ADV block
+            }
+        }
+    }
+#ifdef RT_PAIR_CHECK
+    if (blockIdx.x % 61 == 0 && lane_id() == 0 && (col >> 6) == 1)
+        printf("block %d slot wave: iterations %llu, ADV blocks %llu of %.1f lanes, shadow rays posted %llu, traced here %llu\n", (int)blockIdx.x, ck_iters, ck_adv,
+               (double)ck_adv_lanes / (double)max(ck_adv, 1ull), ck_posted, ck_self);
+#endif
+    asm volatile("" ::: "memory");
+    if (lane_id() == 0) atomicAdd(s_done, 1);  // (after this wave's last posted ray: LDS serves a wave in order)
+    unsigned long long v[C_COUNT] = {n_gen, n_shade, n_traced, n_shadow, n_emit, n_deposit, n_rr, 0ull};
+    {
+        const unsigned l = lane_id();
+        unsigned long long mine = 0;
+#pragma unroll
+        for (int k = 0; k < C_COUNT; k++) mine = (l == (unsigned)k) ? v[k] : mine;
+        if (l < C_COUNT && mine != 0) atomicAdd(&rows[row_index].c[l], mine);
+    }
+}
+
 // post_process_framebuffer (render.cuh:330-338): c = sqrt(c * (1/spp))
 __global__ void k_post_process(float *fb, int n_values, float inv_spp) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2772,7 +3310,22 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
             hipLaunchKernelGGL((k_paths<T, WD, MJ, 4>), grid_paths, block, lds_paths, st, sc, c.pools, cam, ap, d_sum,   \
                                c.d_rows, paths_cap, d_over2, adv_batch, dbg, paths_prof, 0, prio_rotate, rot_wave, rot_set, gen_batch, tri_follow, &c.d_ctr->pad2[0]);     \
     } while (0)
-        if (per_sample && !few_blocks) {
+        int pair = 0;
+        if (const char *e = getenv("RT_PAIR")) pair = atoi(e);
+        if (pair && few_blocks) {
+            // small shards: slot waves + helper waves that trace the shadow rays (k_paths_pair)
+            const size_t lds_pair = sizeof(int) * (size_t)kBlock * (size_t)(2 * (paths_cap + 1) + 9 + 13 + 3 + kMailRows) + 16 +
+                                    (lds_tables ? sizeof(float) * (size_t)((scene->tab_dwords + 3) & ~3) : 0) + sizeof(Camera) + sizeof(AdvanceParams);
+            top_records_in_lds = 0;
+#define RT_LAUNCH_PAIR(T, WD)                                                                                          \
+    hipLaunchKernelGGL((k_paths_pair<T, WD>), grid_paths, dim3(kPairBlock), lds_pair, st, sc, c.pools, cam, ap, d_sum,  \
+                       c.d_rows, paths_cap, d_over2, adv_batch, dbg, prio_rotate, rot_wave, rot_set, tri_follow)
+            if (lds_tables && scene->wide) RT_LAUNCH_PAIR(true, true);
+            else if (lds_tables) RT_LAUNCH_PAIR(true, false);
+            else if (scene->wide) RT_LAUNCH_PAIR(false, true);
+            else RT_LAUNCH_PAIR(false, false);
+#undef RT_LAUNCH_PAIR
+        } else if (per_sample && !few_blocks) {
             // per-sample streams: the build in which the waves draw their camera rays from the frame's counter
 #define RT_LAUNCH_DRAW(T, WD)                                                                                          \
     hipLaunchKernelGGL((k_paths<T, WD, true, 4, true>), grid_paths, block, lds_paths, st, sc, c.pools, cam, ap, d_sum,  \
