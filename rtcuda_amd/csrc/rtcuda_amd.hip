@@ -1808,514 +1808,6 @@ k_paths(DScene sc, DPools p, Camera cam_arg, AdvanceParams ap_arg, float *__rest
     row_add(rows, v);
 }
 
-// ============================================================================ k_paths_pair
-// k_paths for SMALL SHARDS (an 8-GPU run: 2^17 slots per GPU, half the lanes the chip holds).  There a frame is a latency
-// chain: a wave's blocks take the same time whether the SIMD holds one, two or four waves (measured: ADV 9 588 / 10 100 /
-// 9 808 cycles, node 3 352 / 3 745 / 4 719), so the frame time is the length of ONE wave's instruction stream -- of which
-// the ADV blocks (init() + mat() + gen()) are 38 % and stand between its lanes and their next node step.
-// Here a workgroup is 8 waves.  Waves 0..3 are SLOT waves: a lane owns a slot and traces its rays (k_paths' node and
-// triangle blocks, nothing else).  Waves 4..7 are SHADE waves: lane l of wave w + 4 runs init() + mat() + gen() for lane l of
-// wave w, on the slot's LDS column.  The two streams run side by side in the issue slots the half-empty chip has to
-// spare (2 + 2 waves per SIMD): the slot wave never stops for a shading block, and the shade wave starts on a hit the
-// moment it is free (no waiting for a batch: whatever has gathered while the previous block ran is the next block).
-//   slot lane, ray finished:  hit record (tri, u, v, d) -> its idle stack rows; mail word = kMailRequest
-//   shade lane:               sees the request; state from the column, mat() / gen(); results -> the column (state, parked
-//                             path ray + radiance, the ray to trace next in the stack rows); mail word = SW_SHADOW / SW_PATH / SW_BACK
-//   slot lane:                sees the answer; ray -> registers; mail word = 0
-// One word, one writer at a time; LDS serves a wave's operations in order ("data, then flag").  The same RNG sequences, the
-// same rays, the same sums in the same order as k_paths (a slot's steps stay strictly serial; only WHO executes them changed).
-// LDS layout (dynamic): [parked ray + radiance: 9][slot state: 15 (12 state, previous pixel, slot index, mail)][sample sum: 3][stack: max(stack_cap + 1, 8)] x kBlock,
-//                       [slot waves done: 4][tables][uniforms]     (the rows whose number is fixed first: a row = column address + constant)
-enum { SW_NONE = 0, SW_SHADOW = 1, SW_PATH = 2, SW_GEN = 3 };
-constexpr int kMailRequest = 8;
-constexpr int kPairBlock = 2 * kBlock;
-constexpr int kPairFixedRows = 27;  // 9 + 15 + 3
-constexpr int kPairMinStackRows = 8;  // a spawned shadow ray occupies 8 stack rows while the lane waits
-template <bool LDS_TABLES, bool WIDE>
-__global__ void __launch_bounds__(kPairBlock, 4)
-k_paths_pair(DScene sc, DPools p, Camera cam_arg, AdvanceParams ap_arg, float *__restrict__ fb, DWaveRow *__restrict__ rows,
-             int stack_cap, int *overflow, int shade_batch, int debug_no_deposit, int prio_period, int rot_wave, int rot_set,
-             int tri_follow, int gen_batch, int shade_patience) {
-    extern __shared__ int s_lds[];
-    const bool shader = threadIdx.x >= kBlock;
-    const int col = (int)threadIdx.x & (kBlock - 1);  // the slot lane's column; its shade lane works on the same
-    const int srows = max(stack_cap + 1, kPairMinStackRows);
-    float *park = (float *)s_lds + col;  // element k at park[k * kBlock]
-    int *cold = s_lds + 9 * kBlock + col;  // 0..11 slot state, 12 previous pixel (x | y << 16), 13 slot index, 14 mail
-    float *acc = (float *)(s_lds + 24 * kBlock) + col;
-    int *stack = s_lds + kPairFixedRows * kBlock + col;
-    int *mail = cold + 14 * kBlock;
-    int *s_done = s_lds + (kPairFixedRows + srows) * kBlock;
-    float *s_tab = (float *)(s_done + 4);
-    const float *tab = sc.tables;
-    if (LDS_TABLES) {
-        for (int k = threadIdx.x; k < sc.tab_dwords; k += kPairBlock) s_tab[k] = sc.tables[k];
-        tab = s_tab;
-    }
-    struct Uniforms {
-        Camera cam;
-        AdvanceParams ap;
-    };
-    static_assert(sizeof(Uniforms) % 4 == 0, "dword copy");
-    Uniforms *s_uni = (Uniforms *)(s_tab + (LDS_TABLES ? ((sc.tab_dwords + 3) & ~3) : 0));
-    {
-        Uniforms u;
-        u.cam = cam_arg;
-        u.ap = ap_arg;
-        const int *srcw = (const int *)&u;
-        for (int k = threadIdx.x; k < (int)(sizeof(Uniforms) / 4); k += kPairBlock) ((int *)s_uni)[k] = srcw[k];
-    }
-    const int ap_n = ap_arg.n;
-    const int lanes_in_grid = (int)(gridDim.x * kBlock);
-    auto slot_of = [&](int set) {  // as in k_paths
-        const unsigned lane_in_grid = blockIdx.x * kBlock + (unsigned)col;
-        const unsigned wave_in_grid = lane_in_grid >> 6, lane_in_wave = lane_in_grid & 63u;
-        const unsigned b = (wave_in_grid + (wave_in_grid & 3u) * (unsigned)rot_wave + (unsigned)set * (unsigned)rot_set) &
-                           (((unsigned)lanes_in_grid >> 6) - 1u);
-        return set * lanes_in_grid + (int)(b * 64u + lane_in_wave);
-    };
-    auto slot_to_column = [&](int k) {
-        cold[0 * kBlock] = p.bounces(k);
-        cold[1 * kBlock] = p.pixel(k);
-        cold[2 * kBlock] = p.gen(k);
-        cold[3 * kBlock] = (int)p.rd(k);
-        cold[4 * kBlock] = (int)p.r0(k);
-        cold[5 * kBlock] = (int)p.r1(k);
-        cold[6 * kBlock] = (int)p.r2(k);
-        cold[7 * kBlock] = (int)p.r3(k);
-        cold[8 * kBlock] = (int)p.r4(k);
-        cold[9 * kBlock] = __float_as_int(p.br(k));
-        cold[10 * kBlock] = __float_as_int(p.bg(k));
-        cold[11 * kBlock] = __float_as_int(p.bb(k));
-        cold[12 * kBlock] = -1;  // no previous pixel
-        cold[13 * kBlock] = k;
-    };
-    auto column_to_slot = [&](int k) {  // the lockstep rounds of the final generation continue from the pools
-        p.bounces(k) = cold[0 * kBlock];
-        p.pixel(k) = cold[1 * kBlock];
-        p.gen(k) = cold[2 * kBlock];
-        p.hit_info(k) = -1;
-        p.stmax(k) = -1.f;
-        p.rd(k) = (uint32_t)cold[3 * kBlock];
-        p.r0(k) = (uint32_t)cold[4 * kBlock];
-        p.r1(k) = (uint32_t)cold[5 * kBlock];
-        p.r2(k) = (uint32_t)cold[6 * kBlock];
-        p.r3(k) = (uint32_t)cold[7 * kBlock];
-        p.r4(k) = (uint32_t)cold[8 * kBlock];
-        p.br(k) = __int_as_float(cold[9 * kBlock]);
-        p.bg(k) = __int_as_float(cold[10 * kBlock]);
-        p.bb(k) = __int_as_float(cold[11 * kBlock]);
-    };
-    auto lds_order = [&]() { asm volatile("" ::: "memory"); };
-    const unsigned lane = lane_id();
-    const int pair_index = __builtin_amdgcn_readfirstlane(col >> 6);  // which of the four (slot wave, shade wave) pairs
-    const unsigned row_index = blockIdx.x * (kBlock / 64) + (unsigned)pair_index;  // the pair's counter row
-    // the slot lanes set their columns up; the shade lanes start when that is done
-    int slot_set = 0;
-    int i = ap_n;
-    int phase = PH_IDLE;
-    if (!shader) {
-        if (threadIdx.x < 4) s_done[threadIdx.x] = 0;
-        acc[0 * kBlock] = acc[1 * kBlock] = acc[2 * kBlock] = 0.f;
-        i = slot_of(0);
-        if (i < ap_n) {
-            slot_to_column(i);
-            const int b = cold[0 * kBlock];
-            if (b != kDone && b != kParked) phase = PH_GEN;  // (untouched slots: their first step is a gen())
-        }
-        mail[0] = SW_NONE;
-    }
-    __syncthreads();  // (the only barrier: from here on the two halves of the workgroup go their own ways)
-
-    if (shader) {
-        // ------------------------------------------------------------------ shade waves: init() + mat() + gen() (render.cuh:84-275)
-        const Camera &cam = s_uni->cam;
-        const AdvanceParams &ap = s_uni->ap;
-        unsigned long long n_shade = 0, n_traced = 0, n_shadow = 0, n_emit = 0, n_rr = 0;
-        int spins = 0;
-#ifdef RT_PAIR_CHECK
-        unsigned long long hk_blocks = 0, hk_lanes = 0, hk_cycles = 0, hk_sleeps = 0;
-        const unsigned long long hk_t0 = __builtin_readcyclecounter();
-#endif
-        while (true) {
-            const bool req = __hip_atomic_load(mail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == kMailRequest;
-            const int n_req = wave_count(req);
-            if (n_req == 0) {
-                if (__hip_atomic_load(&s_done[pair_index], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) break;
-#ifdef RT_PAIR_CHECK
-                hk_sleeps++;
-#endif
-                __builtin_amdgcn_s_sleep(2);
-                continue;
-            }
-            if (n_req < shade_batch && spins < shade_patience) {  // a bounded wait for company (the block costs the same for 1 lane as for 64)
-                spins++;
-                __builtin_amdgcn_s_sleep(4);
-                continue;
-            }
-            spins = 0;
-#ifdef RT_PAIR_CHECK
-            hk_blocks++;
-            hk_lanes += n_req;
-            const unsigned long long hk_tb = __builtin_readcyclecounter();
-#endif
-            lds_order();  // (the columns' rows after their mail words)
-            AdvanceOut out;
-            out.did_gen = out.did_shade = out.has_shadow = out.did_emit = out.new_ray = out.wants_gen = false;
-            out.rr_draws = 0;
-            if (req) {
-                SlotState st;
-                st.bounces = cold[0 * kBlock];
-                st.pixel = cold[1 * kBlock];
-                st.gen = cold[2 * kBlock];
-                st.rs = Rng{(uint32_t)cold[3 * kBlock], (uint32_t)cold[4 * kBlock], (uint32_t)cold[5 * kBlock],
-                            (uint32_t)cold[6 * kBlock], (uint32_t)cold[7 * kBlock], (uint32_t)cold[8 * kBlock]};
-                st.beta = mk(__int_as_float(cold[9 * kBlock]), __int_as_float(cold[10 * kBlock]), __int_as_float(cold[11 * kBlock]));
-                // the hit record, from the rows the slot lane left it in
-                const int h_tri = stack[0 * kBlock];
-                const float h_u = __int_as_float(stack[1 * kBlock]), h_v = __int_as_float(stack[2 * kBlock]);
-                st.wo = mk(__int_as_float(stack[3 * kBlock]), __int_as_float(stack[4 * kBlock]), __int_as_float(stack[5 * kBlock]));
-                st.hit_info = -1;
-                st.isect_p = st.isect_n = mk(0, 0, 0);
-                if (h_tri >= 0) {  // hit record in the form mat() consumes (render.cuh:152-153, 311-316)
-                    Tri tr = load_tri(sc.tris, h_tri);
-                    float4 sh = sc.tri_shade[(unsigned)h_tri];
-                    st.isect_p = tri_point(tr, h_u, h_v);
-                    st.isect_n = mk(sh.x, sh.y, sh.z);
-                    st.hit_info = __float_as_int(sh.w);
-                }
-                advance_core<true, true, true>(sc, tab, cam, ap, 0, st, out, fb, acc);
-                cold[0 * kBlock] = st.bounces;
-                cold[3 * kBlock] = (int)st.rs.d;
-                cold[4 * kBlock] = (int)st.rs.v0;
-                cold[5 * kBlock] = (int)st.rs.v1;
-                cold[6 * kBlock] = (int)st.rs.v2;
-                cold[7 * kBlock] = (int)st.rs.v3;
-                cold[8 * kBlock] = (int)st.rs.v4;
-                cold[9 * kBlock] = __float_as_int(st.beta.x);
-                cold[10 * kBlock] = __float_as_int(st.beta.y);
-                cold[11 * kBlock] = __float_as_int(st.beta.z);
-                int code = SW_GEN;  // out.wants_gen: Russian roulette ended the path (its draws are in the column's RNG state)
-                if (out.has_shadow) {  // the path ray and the radiance wait in the parked-ray rows, as in k_paths
-                    park[0 * kBlock] = out.ray_o.x;
-                    park[1 * kBlock] = out.ray_o.y;
-                    park[2 * kBlock] = out.ray_o.z;
-                    park[3 * kBlock] = out.ray_d.x;
-                    park[4 * kBlock] = out.ray_d.y;
-                    park[5 * kBlock] = out.ray_d.z;
-                    park[6 * kBlock] = out.s_L.x;
-                    park[7 * kBlock] = out.s_L.y;
-                    park[8 * kBlock] = out.s_L.z;
-                    stack[0 * kBlock] = __float_as_int(out.s_o.x);
-                    stack[1 * kBlock] = __float_as_int(out.s_o.y);
-                    stack[2 * kBlock] = __float_as_int(out.s_o.z);
-                    stack[3 * kBlock] = __float_as_int(out.s_d.x);
-                    stack[4 * kBlock] = __float_as_int(out.s_d.y);
-                    stack[5 * kBlock] = __float_as_int(out.s_d.z);
-                    stack[6 * kBlock] = __float_as_int(out.s_tmax);
-                    stack[7 * kBlock] = out.s_target;
-                    code = SW_SHADOW;
-                } else if (out.new_ray) {
-                    stack[0 * kBlock] = __float_as_int(out.ray_o.x);
-                    stack[1 * kBlock] = __float_as_int(out.ray_o.y);
-                    stack[2 * kBlock] = __float_as_int(out.ray_o.z);
-                    stack[3 * kBlock] = __float_as_int(out.ray_d.x);
-                    stack[4 * kBlock] = __float_as_int(out.ray_d.y);
-                    stack[5 * kBlock] = __float_as_int(out.ray_d.z);
-                    code = SW_PATH;
-                }
-                lds_order();
-                mail[0] = code;
-            }
-#ifdef RT_PAIR_CHECK
-            hk_cycles += __builtin_readcyclecounter() - hk_tb;
-#endif
-            n_shade += wave_count(out.did_shade);
-            n_traced += wave_count(out.new_ray);
-            n_shadow += wave_count(out.has_shadow);
-            n_emit += wave_count(out.did_emit);
-            int rr = out.rr_draws;
-            if (wave_ballot(rr != 0)) {
-                for (int off = 32; off > 0; off >>= 1) rr += __shfl_xor(rr, off);
-                n_rr += (unsigned long long)rr;
-            }
-        }
-#ifdef RT_PAIR_CHECK
-        if (blockIdx.x % 61 == 0 && lane == 0 && pair_index == 1)
-            printf("block %d shade wave: lifetime %llu cycles, %llu blocks of %.1f lanes, %.0f cycles each (%.1f %% of the time), %llu naps\n", (int)blockIdx.x,
-                   __builtin_readcyclecounter() - hk_t0, hk_blocks, (double)hk_lanes / (double)max(hk_blocks, 1ull), (double)hk_cycles / (double)max(hk_blocks, 1ull),
-                   100.0 * (double)hk_cycles / (double)(__builtin_readcyclecounter() - hk_t0), hk_sleeps);
-#endif
-        unsigned long long v[C_COUNT] = {0ull, n_shade, n_traced, n_shadow, n_emit, 0ull, n_rr, 0ull};
-        unsigned long long mine = 0;
-#pragma unroll
-        for (int k = 0; k < C_COUNT; k++) mine = (lane == (unsigned)k) ? v[k] : mine;
-        if (lane < C_COUNT && mine != 0) atomicAdd(&rows[row_index].c[lane], mine);
-        return;
-    }
-
-    // ---------------------------------------------------------------------- slot waves: the rays (ch() / ah(): render.cuh:278-328)
-    int *over = overflow + (blockIdx.x * kBlock + threadIdx.x) % kOverStride;
-    int tri = -1;
-    V3 o = mk(0, 0, 0), d = mk(0, 0, 0), inv = mk(0, 0, 0);
-    float tmax = 0.f, hu = 0.f, hv = 0.f;
-    int cur = kEntryDone, sp = 0, pend = kEntryDone;
-    const Camera &cam = s_uni->cam;
-    const AdvanceParams &ap = s_uni->ap;
-    const int ap_max_bounces = ap_arg.max_bounces, ap_fb_fixed = ap_arg.fb_fixed;
-    unsigned long long n_deposit = 0, n_gen = 0, n_traced = 0;
-#ifdef RT_PAIR_CHECK
-    unsigned long long ck_iters = 0, ck_naps = 0, ck_trav = 0, ck_wait = 0, ck_node = 0, ck_tri = 0;
-    const unsigned long long ck_t0 = __builtin_readcyclecounter();
-#endif
-    unsigned prio_tick = 0;
-    const unsigned prio_rank = (4u * blockIdx.x) / gridDim.x;
-    while (true) {
-        if (prio_period && (prio_tick++ & ((1u << prio_period) - 1u)) == 0u) {
-            unsigned lvl = ((prio_tick >> prio_period) + prio_rank) & 3u;
-            lvl = max(lvl, prio_rank >> 1);
-            switch (lvl) {
-                case 0: __builtin_amdgcn_s_setprio(0); break;
-                case 1: __builtin_amdgcn_s_setprio(1); break;
-                case 2: __builtin_amdgcn_s_setprio(2); break;
-                default: __builtin_amdgcn_s_setprio(3); break;
-            }
-        }
-        // ---------------- mail: what the shade lane has left for the lanes that wait
-        {
-            int code = SW_NONE;
-            if (phase == PH_ADV) code = __hip_atomic_load(mail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            const bool answered = code == SW_SHADOW || code == SW_PATH || code == SW_GEN;
-            if (wave_ballot(answered)) {
-                lds_order();
-                if (answered) {
-                    o = mk(__int_as_float(stack[0 * kBlock]), __int_as_float(stack[1 * kBlock]), __int_as_float(stack[2 * kBlock]));
-                    d = mk(__int_as_float(stack[3 * kBlock]), __int_as_float(stack[4 * kBlock]), __int_as_float(stack[5 * kBlock]));
-                    const float s_tmax = __int_as_float(stack[6 * kBlock]);
-                    const int s_target = stack[7 * kBlock];
-                    const bool sh = code == SW_SHADOW, regen = code == SW_GEN;
-                    phase = sh ? (int)PH_ANY : (regen ? (int)PH_GEN : (int)PH_CLOSEST);
-                    tmax = sh ? s_tmax : kFltMax;
-                    tri = sh ? s_target : -1;
-                    hu = 0.f;
-                    cur = regen ? kEntryDone : 0;
-                    sp = 0;
-                    inv = inv_dir(d);
-                    lds_order();
-                    mail[0] = SW_NONE;
-                }
-            }
-        }
-        // ---------------- GEN block: gen() (render.cuh:250-275) for the lanes whose path has ended -- as in k_paths, in THIS wave:
-        // it is a quarter of the shading block's length, and the shade wave is the busier of the two
-        {
-            const int n_genw = wave_count(phase == PH_GEN);
-            const bool t0 = phase == PH_ANY || phase == PH_CLOSEST;
-            if (n_genw > 0 && (n_genw >= gen_batch || wave_ballot(t0) == 0ull)) {
-                AdvanceOut out;
-                out.did_gen = out.new_ray = false;
-                out.ray_o = o;
-                out.ray_d = d;
-                bool hand_back = false;
-                if (phase == PH_GEN) {
-                    SlotState st;
-                    st.gen = cold[2 * kBlock];
-                    st.rs = Rng{(uint32_t)cold[3 * kBlock], (uint32_t)cold[4 * kBlock], (uint32_t)cold[5 * kBlock],
-                                (uint32_t)cold[6 * kBlock], (uint32_t)cold[7 * kBlock], (uint32_t)cold[8 * kBlock]};
-                    st.bounces = 0;
-                    st.pixel = 0;
-                    st.beta = mk(0, 0, 0);
-                    int pxy = cold[12 * kBlock];
-                    acc_flush(acc, fb, ap_fb_fixed, cold[1 * kBlock]);  // the camera ray that ended: its sum -> its pixel
-                    gen_core<true>(cam, ap, ap.slot_lo + i, st, out, &pxy);
-                    cold[0 * kBlock] = st.bounces;
-                    cold[2 * kBlock] = st.gen;
-                    cold[3 * kBlock] = (int)st.rs.d;
-                    cold[4 * kBlock] = (int)st.rs.v0;
-                    cold[5 * kBlock] = (int)st.rs.v1;
-                    cold[6 * kBlock] = (int)st.rs.v2;
-                    cold[7 * kBlock] = (int)st.rs.v3;
-                    cold[8 * kBlock] = (int)st.rs.v4;
-                    if (out.new_ray) {
-                        cold[1 * kBlock] = st.pixel;
-                        cold[9 * kBlock] = __float_as_int(st.beta.x);
-                        cold[10 * kBlock] = __float_as_int(st.beta.y);
-                        cold[11 * kBlock] = __float_as_int(st.beta.z);
-                        cold[12 * kBlock] = pxy;
-                    } else {
-                        hand_back = true;  // out of camera rays, or parked for the lockstep final generation
-                    }
-                }
-                const bool nr = out.new_ray;
-                o = out.ray_o;
-                d = out.ray_d;
-                inv = inv_dir(d);
-                phase = nr ? (int)PH_CLOSEST : phase;
-                tmax = nr ? kFltMax : tmax;
-                tri = nr ? -1 : tri;
-                cur = nr ? 0 : cur;
-                sp = nr ? 0 : sp;
-                if (wave_ballot(hand_back)) {  // rare (once per slot and frame)
-                    if (hand_back) {
-                        column_to_slot(i);
-                        phase = PH_IDLE;
-                        slot_set++;
-                        i = slot_of(slot_set);
-                        if (i < ap_n) {
-                            slot_to_column(i);
-                            const int b = cold[0 * kBlock];
-                            if (b != kDone && b != kParked) phase = PH_GEN;
-                            else i = ap_n;  // (cannot happen: untouched slots start alive)
-                        }
-                    }
-                }
-                n_gen += wave_count(out.did_gen);
-                n_traced += wave_count(out.new_ray);
-            }
-        }
-        const bool trav = phase == PH_ANY || phase == PH_CLOSEST;
-        const bool want_node = trav && cur >= 0;
-        const bool want_tri = trav && ((cur != kEntryDone && cur < 0) || (kSpeculate && pend != kEntryDone));
-        const int n_node = wave_count(want_node);
-        const int n_tri = wave_count(want_tri);
-#ifdef RT_PAIR_CHECK
-        ck_iters++;
-        ck_trav += wave_count(trav);
-        ck_wait += wave_count(phase == PH_ADV);
-        ck_node += n_node > 0 && n_node >= n_tri;
-        ck_tri += !(n_node > 0 && n_node >= n_tri) && n_tri > 0;
-#endif
-        if (n_node + n_tri == 0 && wave_ballot(trav) == 0ull) {
-            if (wave_ballot(phase == PH_ADV || phase == PH_GEN) == 0ull) break;  // every lane has handed its last slot back
-            if (wave_ballot(phase == PH_GEN) != 0ull) continue;  // (the GEN block is due: nothing else can run)
-#ifdef RT_PAIR_CHECK
-            ck_naps++;
-#endif
-            __builtin_amdgcn_s_sleep(1);
-            continue;
-        }
-        const bool is_any = phase == PH_ANY;
-        auto node_block = [&](bool want) {
-            if (want) {
-                auto step = [&]() {
-                    if (cur >= 0) {
-                        inner_step<WIDE>(sc, o, inv, tmax, cur, sp, stack, over, stack_cap);
-                    } else if (kSpeculate && cur != kEntryDone && pend == kEntryDone && sp > 0) {
-                        pend = cur;  // a leaf: set it aside, go on with the next entry
-                        cur = stack_pop(stack, over, sp, stack_cap);
-                    }
-                };
-                if (kNodeCont == 0 || !WIDE) {
-#pragma unroll
-                    for (int rep = 0; rep < (WIDE ? kNodePerStepWide : kNodePerStep); rep++) step();
-                } else {
-#pragma unroll
-                    for (int rep = 0; rep < kNodePerStepWide; rep++) step();
-                    if (wave_count(cur >= 0) >= kNodeCont) {
-#pragma unroll
-                        for (int rep = 0; rep < kNodeExtra; rep++) step();
-                    }
-                }
-            }
-        };
-        auto tri_block = [&](bool want) {
-            if (want) {
-                int pd = pend, cu = cur;
-                int ks[kTriPerStep];
-                bool act[kTriPerStep];
-                Tri tr[kTriPerStep];
-#pragma unroll
-                for (int j = 0; j < kTriPerStep; j++) {
-                    const bool fp = kSpeculate && pd != kEntryDone;
-                    const bool leaf = cu != kEntryDone && cu < 0;
-                    act[j] = fp || leaf;
-                    const int enc = fp ? pd : cu;
-                    ks[j] = act[j] ? (~enc) >> 3 : ks[0];
-                    const bool more = ((~enc) & 7) > 1;
-                    const int rest = more ? enc - 7 : kEntryDone;
-                    int popped = kEntryDone;
-                    if (act[j] && !fp && !more && sp > 0) popped = stack_pop(stack, over, sp, stack_cap);
-                    pd = (act[j] && fp) ? rest : pd;
-                    cu = (act[j] && !fp) ? (more ? rest : popped) : cu;
-                    tr[j] = load_tri(sc.tris, ks[j]);
-                }
-                bool occluded = false;
-#pragma unroll
-                for (int j = 0; j < kTriPerStep; j++) {
-                    if (act[j] && !occluded) {
-                        float t, u, v;
-                        const bool hit = tri_intersect(tr[j], o, d, tmax, t, u, v);
-                        occluded = hit && is_any && ks[j] != tri;
-                        bool better = hit && !is_any;
-                        if (better && t == tmax && tri >= 0) better = sc.order[(unsigned)ks[j]] > sc.order[(unsigned)tri];
-                        tmax = better ? t : tmax;
-                        hu = occluded ? 1.f : (better ? u : hu);
-                        hv = better ? v : hv;
-                        tri = better ? ks[j] : tri;
-                    }
-                }
-                pend = occluded ? kEntryDone : pd;
-                cur = occluded ? kEntryDone : cu;
-            }
-        };
-        if (n_node > 0 && n_node >= n_tri) {
-            node_block(want_node);
-            if (tri_follow > 0) {
-                const bool w = trav && ((cur != kEntryDone && cur < 0) || (kSpeculate && pend != kEntryDone));
-                if (wave_count(w) >= tri_follow) tri_block(w);
-            }
-        } else if (n_tri > 0) {
-            tri_block(want_tri);
-        }
-        // ---------------- finished rays
-        const bool fin = trav && cur == kEntryDone && (!kSpeculate || pend == kEntryDone);
-        n_deposit += wave_count(fin && is_any && hu == 0.f);
-        if (fin) {
-            if (is_any) {
-                if (hu == 0.f && !debug_no_deposit)  // unoccluded: render.cuh:291-293
-                    acc_add(acc, park[6 * kBlock], park[7 * kBlock], park[8 * kBlock]);
-                o = mk(park[0 * kBlock], park[1 * kBlock], park[2 * kBlock]);
-                d = mk(park[3 * kBlock], park[4 * kBlock], park[5 * kBlock]);
-                phase = PH_CLOSEST;
-                inv = inv_dir(d);
-                tmax = kFltMax;
-                tri = -1;
-                cur = 0;
-                sp = 0;
-            } else if (tri < 0 || (cold[0 * kBlock] >= ap_max_bounces && cold[0 * kBlock] > 0)) {
-                // a path that missed, or has no bounce left (and is not at bounce 0, where a hit light still emits:
-                // render.cuh:98-109), can only generate
-                phase = PH_GEN;
-            } else {
-                // the hit record goes to the shade lane through the column's idle stack rows
-                stack[0 * kBlock] = tri;
-                stack[1 * kBlock] = __float_as_int(hu);
-                stack[2 * kBlock] = __float_as_int(hv);
-                stack[3 * kBlock] = __float_as_int(d.x);
-                stack[4 * kBlock] = __float_as_int(d.y);
-                stack[5 * kBlock] = __float_as_int(d.z);
-                lds_order();
-                mail[0] = kMailRequest;
-                phase = PH_ADV;
-            }
-        }
-    }
-#ifdef RT_PAIR_CHECK
-    if (blockIdx.x % 61 == 0 && lane == 0 && pair_index == 1)
-        printf("block %d slot wave: lifetime %llu cycles, %llu rounds (%llu naps; node-first %llu, triangle-only %llu), lanes tracing %.1f, waiting %.1f\n", (int)blockIdx.x,
-               __builtin_readcyclecounter() - ck_t0, ck_iters, ck_naps, ck_node, ck_tri, (double)ck_trav / (double)max(ck_iters, 1ull), (double)ck_wait / (double)max(ck_iters, 1ull));
-#endif
-    lds_order();
-    if (lane == 0) __hip_atomic_store(&s_done[pair_index], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    {
-        unsigned long long v[C_COUNT] = {n_gen, 0ull, n_traced, 0ull, 0ull, n_deposit, 0ull, 0ull};
-        unsigned long long mine = 0;
-#pragma unroll
-        for (int k = 0; k < C_COUNT; k++) mine = (lane == (unsigned)k) ? v[k] : mine;
-        if (lane < C_COUNT && mine != 0) atomicAdd(&rows[row_index].c[lane], mine);
-    }
-}
-
 // post_process_framebuffer (render.cuh:330-338): c = sqrt(c * (1/spp))
 __global__ void k_post_process(float *fb, int n_values, float inv_spp) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -3280,27 +2772,7 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
             hipLaunchKernelGGL((k_paths<T, WD, MJ, 4>), grid_paths, block, lds_paths, st, sc, c.pools, cam, ap, d_sum,   \
                                c.d_rows, paths_cap, d_over2, adv_batch, dbg, paths_prof, 0, prio_rotate, rot_wave, rot_set, gen_batch, tri_follow, &c.d_ctr->pad2[0]);     \
     } while (0)
-        int pair = 0;
-        if (const char *e = getenv("RT_PAIR")) pair = atoi(e);
-        if (pair && few_blocks) {
-            // small shards: slot waves that trace + shade waves that run init() / mat() / gen() beside them (k_paths_pair)
-            const int srows = std::max(paths_cap + 1, kPairMinStackRows);
-            const size_t lds_pair = sizeof(int) * (size_t)kBlock * (size_t)(kPairFixedRows + srows) + 16 +
-                                    (lds_tables ? sizeof(float) * (size_t)((scene->tab_dwords + 3) & ~3) : 0) + sizeof(Camera) + sizeof(AdvanceParams);
-            top_records_in_lds = 0;
-            int shade_batch = 1;  // requests a shade wave waits for (briefly) before it runs a block
-            if (const char *e = getenv("RT_SHADE_BATCH")) shade_batch = std::max(1, std::min(64, atoi(e)));
-            int shade_patience = 4;  // ... in naps of 256 cycles
-            if (const char *e = getenv("RT_SHADE_PATIENCE")) shade_patience = std::max(0, atoi(e));
-#define RT_LAUNCH_PAIR(T, WD)                                                                                          \
-    hipLaunchKernelGGL((k_paths_pair<T, WD>), grid_paths, dim3(kPairBlock), lds_pair, st, sc, c.pools, cam, ap, d_sum,  \
-                       c.d_rows, paths_cap, d_over2, shade_batch, dbg, prio_rotate, rot_wave, rot_set, tri_follow, gen_batch, shade_patience)
-            if (lds_tables && scene->wide) RT_LAUNCH_PAIR(true, true);
-            else if (lds_tables) RT_LAUNCH_PAIR(true, false);
-            else if (scene->wide) RT_LAUNCH_PAIR(false, true);
-            else RT_LAUNCH_PAIR(false, false);
-#undef RT_LAUNCH_PAIR
-        } else if (per_sample && !few_blocks) {
+        if (per_sample && !few_blocks) {
             // per-sample streams: the build in which the waves draw their camera rays from the frame's counter
 #define RT_LAUNCH_DRAW(T, WD)                                                                                          \
     hipLaunchKernelGGL((k_paths<T, WD, true, 4, true>), grid_paths, block, lds_paths, st, sc, c.pools, cam, ap, d_sum,  \
