@@ -202,3 +202,19 @@ def test_literal_and_watertight_fixtures_are_reproduced(oracle):
         assert abs(st_w[k] - want) <= 4, (k, st_w[k], want)
     d = np.abs(img_w.astype(np.float64) - GOLDEN[key + "_img"])
     assert (d.max(axis=2) > 1e-4).sum() <= 2 and np.sqrt(np.mean(d ** 2)) < 1e-4
+
+
+def test_full_size_totals_fixture_is_well_formed():
+    """tests/golden/full_size_event_totals.json (the oracle's totals of the six full BASELINE frames, which the GPU suite
+    holds k_paths against): one entry per BASELINE frame, sample counts consistent, literal and watertight totals within
+    the audited distance of each other (about one ray in 10^7)."""
+    import json
+    import os
+    here = os.path.dirname(os.path.abspath(__file__))
+    frames = json.load(open(os.path.join(here, "golden", "full_size_event_totals.json")))["frames"]
+    assert sorted((f["scene"], f["spp"]) for f in frames) == [("four_bunnies", 256), ("full_bsdf", 256), ("matte", 256), ("matte", 1024),
+                                                              ("sixteen_lights", 256), ("sixteen_lights", 512)]
+    for f in frames:
+        assert f["samples"] == f["width"] * f["height"] * f["spp"] and (f["width"], f["height"]) == (1920, 1080)
+        for k, v in f["oracle_watertight"].items():
+            assert v > 0 and abs(v - f["oracle_literal"][k]) <= 2e-6 * f["oracle_watertight"]["shade_events"], (f["scene"], k)
