@@ -448,3 +448,31 @@ def test_every_full_baseline_frame_has_the_oracles_event_totals(api, frame):
     nan_pixels = int(torch.isnan(fb).view(-1, 3).any(dim=1).sum().item())
     assert nan_pixels == frame["oracle_nan_pixels"], (nan_pixels, frame["oracle_nan_pixels"])
     assert bool((torch.nan_to_num(fb) >= 0).all().item())
+
+
+@pytest.mark.parametrize("shards", [2, 8])
+def test_full_baseline_frame_is_exactly_the_sum_of_its_slot_shards(api, shards):
+    """BASELINE configs[1] at full size (1920x1080x256, full BSDF) in RT_FLAG_DETERMINISTIC arithmetic: the int64 raw sums of
+    the R slot-range shards -- what the R ranks of a multi-GPU run render and sum-reduce -- add up to EXACTLY the unsharded
+    frame's, and so do the event totals (which the test above holds equal to the oracle's).  R = 8 launches the small-shard
+    build of k_paths (2 waves per SIMD, gen() inside the ADV block), R = 2 the full-occupancy build on half the slots."""
+    import torch
+    from rtcuda_amd import scenes
+    w, h, spp = 1920, 1080, 256
+    if "full_bsdf" not in _scene_cache:
+        _scene_cache["full_bsdf"] = api.Scene(scenes.cornell_bunny("full_bsdf"))
+    gpu = _scene_cache["full_bsdf"]
+    cam = api.make_camera(aspect=w / h)
+    full = torch.zeros(h * w * 3, dtype=torch.int64, device="cuda")
+    st_full = gpu.render_shard_fixed(cam, w, h, spp, 0, 1, full.data_ptr())
+    acc = torch.zeros_like(full)
+    keys = ("camera_rays", "shade_events", "any_rays", "emission_adds", "shadow_adds", "rr_draws")
+    tot = {k: 0 for k in keys}
+    for r in range(shards):
+        st = gpu.render_shard_fixed(cam, w, h, spp, r, shards, acc.data_ptr())
+        for k in keys:
+            tot[k] += st[k]
+    torch.cuda.synchronize()
+    assert tot == {k: st_full[k] for k in keys}
+    assert tot["camera_rays"] == w * h * spp
+    assert torch.equal(acc, full)
