@@ -95,6 +95,20 @@ typedef struct rt_stats {
                                     shards' fixed-point sums add up to the 1-GPU sums exactly, and 8 GPUs are not held to
                                     1/8 of the W chains each (SURVEY.md section 7 "per_sample", section 8b `rng_mode`) */
 
+#define RT_FLAG_REFERENCE_WALK 8u /* opt-in parity mode, never benchmarked: traverse the REFERENCE's own tree with the reference's
+                                    own decisions instead of the product's.  Two results of lashhw/rtcuda are properties of its
+                                    BVH, not of the scene: its fp32 slab test on exact boxes (aabb_intersector.cuh:14-36,
+                                    hit iff entry <= exit) drops about one accepted hit in 10^7 rays, and among hits at exactly
+                                    equal t the triangle its walk tests last wins (triangle.cuh:49).  By default the library
+                                    defines both by the triangle list alone (an accepted hit is never culled; ties go to the
+                                    larger caller index).  With this flag the library builds the reference's binary SAH tree
+                                    (bvh.cuh:30-219: std::sort per axis, full sweep, stable partition) from the scene's
+                                    triangles on first use and every ray walks it as Bvh::traverse does (bvh.cuh:221-357):
+                                    same boxes, same arithmetic, near child first by fp32 entry distance, left leaf before
+                                    right leaf, later-tested triangle wins a tie.  The image then equals the reference
+                                    algorithm's image ray for ray, including the hits its box test loses.  Several times
+                                    slower than the default kernels.  Not combinable with RT_FLAG_RNG_PER_SAMPLE. */
+
 /* ---- scene -------------------------------------------------------------------------------
  * Replaces: Triangle(p0,p1,p2) x n (triangle.cuh:6-7), cudaMalloc/Memcpy of triangles,
  * materials and lights (main.cu:50-51,119-122,136-137), Primitive(tri*,mat*,light*)
@@ -159,6 +173,13 @@ int rt_trace_closest(const rt_scene *scene, int n, const float *origin_xyz, cons
 /* Any hit excluding one triangle (bvh.cuh:306-357; ah(), render.cuh:278-294): occluded[i] in {0,1}. */
 int rt_trace_any(const rt_scene *scene, int n, const float *origin_xyz, const float *dir_xyz,
                  const float *tmax, const int32_t *excluded_tri, int32_t *occluded);
+/* The same two entry points with a flags word: RT_FLAG_REFERENCE_WALK sends the rays through the reference's own
+ * tree and walk (see the flag) -- hit_tri, t, u, v and occluded are then the reference's answers, ties and lost
+ * hits included.  flags = 0 is rt_trace_closest / rt_trace_any. */
+int rt_trace_closest_flags(const rt_scene *scene, uint32_t flags, int n, const float *origin_xyz, const float *dir_xyz,
+                           const float *tmax, int32_t *hit_tri, float *t, float *u, float *v);
+int rt_trace_any_flags(const rt_scene *scene, uint32_t flags, int n, const float *origin_xyz, const float *dir_xyz,
+                       const float *tmax, const int32_t *excluded_tri, int32_t *occluded);
 /* curand_init(seed, subsequence, 0) for subsequences [first, first+count) (render.cuh:68-73):
  * state6 receives count x {d, v0..v4}.  Then `draws` uniforms per state into uniforms
  * (count x draws, may be 0 / NULL), advancing the returned states. */
@@ -175,6 +196,10 @@ int rt_measure_copy_bandwidth(int64_t bytes, int reps, double *out_bytes_per_s);
  * out_wave_instr (may be NULL): v_fma_f32 wave-instructions of one launch, for calibrating PMC counters.
  * No reference counterpart (the reference measures nothing). */
 int rt_calibrate_valu(int waves_per_simd, int iters, double *out_lane_ops_per_s, double *out_wave_instr);
+
+/* The same measurement with PACKED fp32 instructions (kind 1: v_pk_fma_f32, 2: v_pk_mul_f32, 3: v_pk_add_f32) on aligned
+ * register pairs; lane-operations are counted as two per lane and instruction.  No reference counterpart. */
+int rt_calibrate_valu_packed(int waves_per_simd, int iters, int kind, double *out_lane_ops_per_s);
 
 /* Measurement tool for the design question "one persistent kernel, or the reference's stage split (render.cuh:428-449:
  * init/mat/gen kernels and ah/ch kernels with dense queues between them)?".  Runs the round-per-launch pipeline of the

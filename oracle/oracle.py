@@ -241,6 +241,15 @@ class OracleScene:
         return {"num_nodes": int(out[0]), "num_prims": int(out[1]), "max_depth": int(out[2]),
                 "num_leaves": int(out[3]), "leaf_hist": [int(x) for x in out[4:12]], "root_bounds": root}
 
+    def nodes(self):
+        """The restated reference BVH (bvh.cuh:30-219): (bounds (n, 6), num_primitives (n,), index (n,), primitive order)."""
+        st = self.bvh_stats()
+        n, m = st["num_nodes"], st["num_prims"]
+        bounds = np.zeros((n, 6), np.float32)
+        count, index, prim_tri = np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(max(m, 1), np.int32)
+        self.o.lib.orc_scene_nodes(self.h, _ptr(bounds), _ptr(count), _ptr(index), _ptr(prim_tri))
+        return bounds, count, index, prim_tri[:m]
+
     def trace_closest(self, o3, d3, tmax, threads: int = 8):
         o3 = np.ascontiguousarray(o3, np.float32)
         d3 = np.ascontiguousarray(d3, np.float32)

@@ -24,11 +24,13 @@ W = 1 << 20  # RT_NUM_WORKING_PATHS
 FLAG_TIME_KERNELS = 1
 FLAG_DETERMINISTIC = 2
 FLAG_RNG_PER_SAMPLE = 4  # NOT the reference's random numbers (see include/rtcuda_amd.h): partition-invariant streams
+FLAG_REFERENCE_WALK = 8  # opt-in parity mode: the reference's own tree, box test, order and tie rule (never benchmarked)
 
 EXPORTS = [
     "rt_scene_create", "rt_scene_destroy", "rt_scene_info", "rt_scene_build_info", "rt_camera_make", "rt_render",
-    "rt_render_shard", "rt_render_shard_fixed", "rt_post_process", "rt_post_process_fixed", "rt_trace_closest", "rt_trace_any", "rt_xorwow_states",
-    "rt_measure_copy_bandwidth", "rt_calibrate_valu", "rt_split_probe", "rt_last_error", "rt_version", "rt_build_id",
+    "rt_render_shard", "rt_render_shard_fixed", "rt_post_process", "rt_post_process_fixed", "rt_trace_closest", "rt_trace_any",
+    "rt_trace_closest_flags", "rt_trace_any_flags", "rt_xorwow_states",
+    "rt_measure_copy_bandwidth", "rt_calibrate_valu", "rt_calibrate_valu_packed", "rt_split_probe", "rt_last_error", "rt_version", "rt_build_id",
 ]
 
 
@@ -117,9 +119,12 @@ def lib():
     L.rt_post_process_fixed.argtypes = [vp, vp, ci, ci, vp]
     L.rt_trace_closest.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp, vp]
     L.rt_trace_any.argtypes = [vp, ci, vp, vp, vp, vp, vp]
+    L.rt_trace_closest_flags.argtypes = [vp, ctypes.c_uint32, ci, vp, vp, vp, vp, vp, vp, vp]
+    L.rt_trace_any_flags.argtypes = [vp, ctypes.c_uint32, ci, vp, vp, vp, vp, vp]
     L.rt_xorwow_states.argtypes = [ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, ci, vp, vp]
     L.rt_measure_copy_bandwidth.argtypes = [ctypes.c_int64, ci, ctypes.POINTER(ctypes.c_double)]
     L.rt_calibrate_valu.argtypes = [ci, ci, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
+    L.rt_calibrate_valu_packed.argtypes = [ci, ci, ci, ctypes.POINTER(ctypes.c_double)]
     L.rt_split_probe.argtypes = [vp, vp, ci, ci, ci, ci, ctypes.c_uint64, ctypes.c_int64, vp, ci]
     _lib = L
     return L
@@ -218,25 +223,34 @@ class Scene:
         return st.as_dict()
 
     # ---- stage-level entry points (parity tests)
-    def trace_closest(self, o3, d3, tmax):
+    def trace_closest(self, o3, d3, tmax, flags: int = 0):
+        """``flags=FLAG_REFERENCE_WALK``: through the reference's own tree and walk (rt_trace_closest_flags)."""
         o3 = np.ascontiguousarray(o3, np.float32)
         d3 = np.ascontiguousarray(d3, np.float32)
         tmax = np.ascontiguousarray(tmax, np.float32)
         n = o3.shape[0]
         tri = np.zeros(n, np.int32)
         t, u, v = (np.zeros(n, np.float32) for _ in range(3))
-        _check(lib().rt_trace_closest(self.h, n, _p(o3), _p(d3), _p(tmax), _p(tri), _p(t), _p(u), _p(v)),
-               "rt_trace_closest")
+        if flags:
+            _check(lib().rt_trace_closest_flags(self.h, flags, n, _p(o3), _p(d3), _p(tmax), _p(tri), _p(t), _p(u), _p(v)),
+                   "rt_trace_closest_flags")
+        else:
+            _check(lib().rt_trace_closest(self.h, n, _p(o3), _p(d3), _p(tmax), _p(tri), _p(t), _p(u), _p(v)),
+                   "rt_trace_closest")
         return tri, t, u, v
 
-    def trace_any(self, o3, d3, tmax, excluded):
+    def trace_any(self, o3, d3, tmax, excluded, flags: int = 0):
         o3 = np.ascontiguousarray(o3, np.float32)
         d3 = np.ascontiguousarray(d3, np.float32)
         tmax = np.ascontiguousarray(tmax, np.float32)
         excluded = np.ascontiguousarray(excluded, np.int32)
         n = o3.shape[0]
         occ = np.zeros(n, np.int32)
-        _check(lib().rt_trace_any(self.h, n, _p(o3), _p(d3), _p(tmax), _p(excluded), _p(occ)), "rt_trace_any")
+        if flags:
+            _check(lib().rt_trace_any_flags(self.h, flags, n, _p(o3), _p(d3), _p(tmax), _p(excluded), _p(occ)),
+                   "rt_trace_any_flags")
+        else:
+            _check(lib().rt_trace_any(self.h, n, _p(o3), _p(d3), _p(tmax), _p(excluded), _p(occ)), "rt_trace_any")
         return occ
 
 
@@ -268,6 +282,13 @@ def calibrate_valu(waves_per_simd: int = 4, iters: int = 20000):
     rate, winstr = ctypes.c_double(0.0), ctypes.c_double(0.0)
     _check(lib().rt_calibrate_valu(waves_per_simd, iters, ctypes.byref(rate), ctypes.byref(winstr)), "rt_calibrate_valu")
     return rate.value, winstr.value
+
+
+def calibrate_valu_packed(waves_per_simd: int = 4, iters: int = 20000, kind: int = 1) -> float:
+    """Lane-operations/s of a packed-fp32 stream (kind 1 v_pk_fma_f32, 2 v_pk_mul_f32, 3 v_pk_add_f32; 2 per lane and instruction)."""
+    rate = ctypes.c_double(0.0)
+    _check(lib().rt_calibrate_valu_packed(waves_per_simd, iters, kind, ctypes.byref(rate)), "rt_calibrate_valu_packed")
+    return rate.value
 
 
 # rt_split_probe's out[] layout (the RT_PROBE_* enum of include/rtcuda_amd.h)

@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "rt_bvh.h"
+#include "rt_ref_tree.h"
 
 namespace {
 struct V3 { float x, y, z; };
@@ -281,5 +282,21 @@ int rt_hostwalk_trace(void *h, int mode, int n_rays, const float *o3, const floa
     g_walk_stats[2] += st_tris;
     g_walk_stats[3] += st_leaves;
     return failures;
+}
+// The reference's own tree as the product builds it for RT_FLAG_REFERENCE_WALK (rt_ref_tree.h), for a node-by-node
+// comparison with the oracle's restatement of Bvh::Bvh (tests/test_host_logic.py).  Call with bounds6 == nullptr for the
+// sizes: returns the node count; *depth receives the tree depth.  prims: reference position -> caller's triangle index.
+int rt_ref_tree_export(const float *tri9, int n, float *bounds6, int *count, int *link, int *prims, int *depth) {
+    const rtref::Tree t = rtref::build(tri9, n);
+    if (depth) *depth = t.depth;
+    if (bounds6) {
+        for (size_t i = 0; i < t.nodes.size(); i++) {
+            memcpy(bounds6 + 6 * i, t.nodes[i].box.b, 24);
+            count[i] = t.nodes[i].count;
+            link[i] = t.nodes[i].link;
+        }
+        for (size_t i = 0; i < t.prims.size(); i++) prims[i] = t.prims[i];
+    }
+    return (int)t.nodes.size();
 }
 }

@@ -58,6 +58,7 @@
 #include "../../include/rtcuda_amd.h"
 #include "rt_bvh.h"
 #include "rt_device.h"
+#include "rt_ref_tree.h"
 
 using namespace rt;
 
@@ -100,6 +101,12 @@ struct DScene {
     // records 12/each][per-light precomputed {1/area, unit normal} 4/each]
     const float *tables;
     int tab_dwords;
+    // RT_FLAG_REFERENCE_WALK only (null otherwise; no other kernel reads them): the reference's own binary tree
+    // (rt_ref_tree.h) as 32-byte nodes {bounds[6], count, link} = 2 x float4, and its primitive order mapped to this
+    // scene's leaf-order triangle indices
+    const float4 *ref_nodes;
+    const int *ref_prims;
+    int ref_n_prims;
 };
 __device__ __host__ inline int tab_off_lights(int n_mats) { return 5 * n_mats; }
 __device__ __host__ inline int tab_off_ltri(int n_mats, int n_lights) { return 5 * n_mats + 8 * n_lights; }
@@ -951,6 +958,118 @@ __device__ __forceinline__ void inner_step(const DScene &sc, V3 o, V3 inv, float
     }
 }
 
+// ============================================================================ RT_FLAG_REFERENCE_WALK
+// The reference's own traversal over its own tree (rt_ref_tree.h), decision for decision -- opt-in, never timed:
+//   * AABBIntersector (aabb_intersector.cuh:14-36): octant from the sign of d, 1 / d as an IEEE division with |d|
+//     clamped away from 0, scaled origin (-o) * (1 / d); per slab inv * bound + scaled_origin as a separately rounded
+//     multiplication and addition (this file is built with -ffp-contract=off); hit iff entry <= exit -- on the exact,
+//     unpadded boxes, with no clamp to [0, tmax].  This is the test that loses about one accepted hit in 10^7 rays;
+//   * Bvh::traverse (bvh.cuh:251-303 / :306-357): the two children of a node are tested left then right, a leaf
+//     child is intersected on the spot (left leaf before right leaf), of two inner children the one with the smaller
+//     entry distance is descended first (ties: the left one) and the other one's children index is pushed;
+//   * intersect_leaf (:222-236 / :239-248): triangles in the reference's primitive order; closest hit accepts
+//     t <= tmax, so the LATER tested of two hits at equal t wins (triangle.cuh:49); any hit returns at the first
+//     accepted triangle that is not the excluded one.
+// A lane runs its whole ray here in one go (a plain per-lane loop with a private stack of 32 entries -- the
+// reference's DeviceStack has 29, device_stack.cuh:4-11, for a tree of depth <= 30): no speculation, no reordering.
+// `tri`: best hit so far / excluded triangle, as everywhere else (leaf-order index); ANY sets hu = 1 when occluded.
+struct RefSlab {
+    bool nx, ny, nz;  // octant: direction component negative
+    V3 inv, so;
+};
+__device__ inline RefSlab ref_slab(V3 o, V3 d) {
+    RefSlab s;
+    s.nx = d.x < 0;
+    s.ny = d.y < 0;
+    s.nz = d.z < 0;
+    s.inv = mk(1.f / ((fabsf(d.x) < kFltEps) ? copysignf(kFltEps, d.x) : d.x),
+               1.f / ((fabsf(d.y) < kFltEps) ? copysignf(kFltEps, d.y) : d.y),
+               1.f / ((fabsf(d.z) < kFltEps) ? copysignf(kFltEps, d.z) : d.z));
+    s.so = mul(neg(o), s.inv);
+    return s;
+}
+// node = {xmin, xmax, ymin, ymax | zmin, zmax, count, link}
+__device__ inline bool ref_box(const RefSlab &s, float4 n0, float4 n1, float &entry) {
+    const float ex = s.inv.x * (s.nx ? n0.y : n0.x) + s.so.x;
+    const float ey = s.inv.y * (s.ny ? n0.w : n0.z) + s.so.y;
+    const float ez = s.inv.z * (s.nz ? n1.y : n1.x) + s.so.z;
+    entry = fmaxf(ex, fmaxf(ey, ez));
+    const float xx = s.inv.x * (s.nx ? n0.x : n0.y) + s.so.x;
+    const float xy = s.inv.y * (s.ny ? n0.z : n0.w) + s.so.y;
+    const float xz = s.inv.z * (s.nz ? n1.x : n1.y) + s.so.z;
+    const float exit = fminf(xx, fminf(xy, xz));
+    return entry <= exit;
+}
+template <bool ANY>
+__device__ inline void reference_walk(const DScene &sc, V3 o, V3 d, float &tmax, int &tri, float &hu, float &hv) {
+    if (sc.ref_n_prims <= 0) return;
+    const float4 *__restrict__ nodes = sc.ref_nodes;
+    // true: the ray is finished (an occluder was found)
+    auto leaf = [&](int first, int count) -> bool {
+        for (int i = first; i < first + count; i++) {
+            const int k = sc.ref_prims[i];
+            const Tri tr = load_tri(sc.tris, k);
+            float t, u, v;
+            if (tri_intersect(tr, o, d, tmax, t, u, v)) {
+                if (ANY) {
+                    if (k != tri) {
+                        hu = 1.f;
+                        return true;
+                    }
+                } else {
+                    tmax = t;
+                    hu = u;
+                    hv = v;
+                    tri = k;
+                }
+            }
+        }
+        return false;
+    };
+    {
+        const float4 r1 = nodes[1];
+        if (__float_as_int(r1.z) > 0) {  // the root is a leaf (:252 / :307)
+            leaf(__float_as_int(r1.w), __float_as_int(r1.z));
+            return;
+        }
+    }
+    const RefSlab s = ref_slab(o, d);
+    int stk[32];
+    int sp = 0;
+    int left = __float_as_int(nodes[1].w);
+    // (a walk over a validated tree of n nodes ends after at most n / 2 pairs; the bound is a guard, not a schedule)
+    for (int guard = 0; guard < (1 << 24); guard++) {
+        const float4 a0 = nodes[2 * left], a1 = nodes[2 * left + 1], b0 = nodes[2 * left + 2], b1 = nodes[2 * left + 3];
+        const int lcount = __float_as_int(a1.z), llink = __float_as_int(a1.w);
+        const int rcount = __float_as_int(b1.z), rlink = __float_as_int(b1.w);
+        float el, er;
+        bool go_l = ref_box(s, a0, a1, el);
+        if (go_l && lcount > 0) {
+            if (leaf(llink, lcount)) return;
+            go_l = false;
+        }
+        bool go_r = ref_box(s, b0, b1, er);
+        if (go_r && rcount > 0) {
+            if (leaf(rlink, rcount)) return;
+            go_r = false;
+        }
+        if (go_l && go_r) {
+            const bool right_first = el > er;
+            stk[min(sp, 31)] = right_first ? llink : rlink;
+            sp++;
+            left = right_first ? rlink : llink;
+        } else if (go_l) {
+            left = llink;
+        } else if (go_r) {
+            left = rlink;
+        } else {
+            if (sp == 0) break;
+            sp--;
+            left = stk[min(sp, 31)];
+        }
+    }
+}
+
 enum { MODE_POOL = 0, MODE_TEST_CLOSEST = 2, MODE_TEST_ANY = 3 };
 
 struct TraceParams {
@@ -974,7 +1093,9 @@ struct TraceParams {
 // LDS layout (dynamic): [stack: (stack_cap + 1) x kBlock ints (push_if)][pending: kBlock ints]
 // MINW: minimum waves per SIMD the register budget is sized for (8 = 64 VGPRs: the renderer's build; the split probe
 // also times the builds with 80 / 96 / 128 VGPRs).
-template <int MODE, bool WIDE, int MINW = 8>
+// LITERAL (RT_FLAG_REFERENCE_WALK): a lane traverses its whole ray with reference_walk -- the scheduling around it
+// (chunks, refill, finalisation) is unchanged, WIDE is not looked at.
+template <int MODE, bool WIDE, int MINW = 8, bool LITERAL = false>
 __global__ void __launch_bounds__(kBlock, MINW) k_trace(DScene sc, DPools p, TraceParams tp, int stack_cap, int *overflow) {
     extern __shared__ int s_lds[];
     int *stack = s_lds + threadIdx.x;
@@ -1120,6 +1241,15 @@ __global__ void __launch_bounds__(kBlock, MINW) k_trace(DScene sc, DPools p, Tra
                 continue;
             }
         }
+        if (LITERAL) {
+            if (cur >= 0) {
+                const bool is_any = MODE == MODE_POOL ? (id & kAnyBit) != 0 : MODE == MODE_TEST_ANY;
+                if (is_any) reference_walk<true>(sc, o, d, tmax, tri, hu, hv);
+                else reference_walk<false>(sc, o, d, tmax, tri, hu, hv);
+                cur = kEntryDone;
+            }
+            continue;
+        }
         // ---- inner phase: step through node records until no lane holds an inner entry
         while (wave_ballot(cur >= 0) != 0) {
 #ifdef RT_TRACE_PROFILE
@@ -1244,11 +1374,15 @@ constexpr bool kSpeculate = RT_SPECULATE != 0;  // k_paths: postpone a leaf reac
 // while a shadow ray is traced, the slot's path ray and the radiance to deposit wait in 9 more
 // dwords of LDS; the hit record is rebuilt from (tri, hu, hv) inside the ADV block.
 // LDS layout (dynamic): [stack: (stack_cap + 1) x kBlock (push_if)][parked ray: 9 x kBlock][slot state: 12 + 1 x kBlock][sample sum: 3 x kBlock][tables]
-template <bool LDS_TABLES, bool WIDE, bool MAJORITY, int MIN_WAVES, bool DRAW_CIDS = false>
+// LITERAL (RT_FLAG_REFERENCE_WALK): the node block is a lane's WHOLE ray through reference_walk -- the reference's tree,
+// box test, order and tie rule; no triangle blocks, no speculation.  Everything around it (phases, ADV / GEN blocks, the
+// sample accumulator) is the same code.  Opt-in and never timed.
+template <bool LDS_TABLES, bool WIDE, bool MAJORITY, int MIN_WAVES, bool DRAW_CIDS = false, bool LITERAL = false>
 __global__ void __launch_bounds__(kBlock, MIN_WAVES)
 k_paths(DScene sc, DPools p, Camera cam_arg, AdvanceParams ap_arg, float *__restrict__ fb, DWaveRow *__restrict__ rows,
         int stack_cap, int *overflow, int adv_batch, int debug_no_deposit, unsigned long long *prof, int top_n,
-        int prio_period, int rot_wave, int rot_set, int gen_batch, int tri_follow, unsigned int *__restrict__ next_cid) {
+        int prio_period, int rot_wave, int rot_set, int gen_batch, int tri_follow, unsigned int *__restrict__ next_cid,
+        int half_fill) {
     // The GEN block exists where the chip is short of issue slots (4 waves per SIMD): there it takes a third of the
     // lanes out of the long ADV block (+3 %, and the ADV block no longer spills).  On small shards (2 waves per
     // SIMD) a slot-round is a latency chain and one more block in it costs 5 %: gen() stays inside ADV there.
@@ -1315,6 +1449,9 @@ k_paths(DScene sc, DPools p, Camera cam_arg, AdvanceParams ap_arg, float *__rest
         // (the grid is a power of two: W is, shard counts divide it, and the host halves from there)
         const unsigned b = (wave_in_grid + (wave_in_grid & 3u) * (unsigned)rot_wave + (unsigned)set * (unsigned)rot_set) &
                            (((unsigned)lanes_in_grid >> 6) - 1u);
+        // half_fill (small shards, experiment): only lanes 0..31 of a wave own slots -- twice the waves, each with half
+        // the chains: a wave's block stream gets shorter where issue slots are to spare
+        if (half_fill) return lane_in_wave < 32u ? set * (lanes_in_grid >> 1) + (int)(b * 32u + lane_in_wave) : 0x7fffffff;
         return set * lanes_in_grid + (int)(b * 64u + lane_in_wave);
     };
     int slot_set = 0;
@@ -1656,7 +1793,13 @@ k_paths(DScene sc, DPools p, Camera cam_arg, AdvanceParams ap_arg, float *__rest
             pf[2]++; pf[3] += n_want; pf[6] += n_adv;
             const unsigned long long pf_tn = __builtin_readcyclecounter();
 #endif
-            if (want) {
+            if (LITERAL) {
+                if (want) {
+                    if (is_any) reference_walk<true>(sc, o, d, tmax, tri, hu, hv);
+                    else reference_walk<false>(sc, o, d, tmax, tri, hu, hv);
+                    cur = kEntryDone;
+                }
+            } else if (want) {
                 // a bounded while-while: up to kNodePerStep consecutive node steps (2 triangle tests in the
                 // triangle block) per scheduling decision -- measured best at 8 / 2 (+22 % over 1 / 1; 4 / 2: +20 %)
                 auto step = [&]() {
@@ -1860,6 +2003,35 @@ __global__ void __launch_bounds__(256) k_valu_calibrate(float *__restrict__ out,
     }
     float r = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7)) + ((a8 + a9) + (a10 + a11)) + ((a12 + a13) + (a14 + a15));
     if (r == 12345.678f) out[blockIdx.x * blockDim.x + threadIdx.x] = r;  // (never true: keeps the chain alive)
+}
+
+// The same stream in packed fp32 (KIND 1: v_pk_fma_f32, 2: v_pk_mul_f32, 3: v_pk_add_f32): 16 independent chains on 16
+// aligned register PAIRS, two lane-operations per lane and instruction.  Answers one question before any hand-packing of
+// the shading arithmetic: does a packed instruction issue at the rate of a scalar one (2x the lane-operations), or at half?
+template <int KIND>
+__global__ void __launch_bounds__(256) k_valu_calibrate_pk(float *__restrict__ out, int iters, float seed) {
+    v2f a[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) a[k] = v2f{seed + (float)k, seed + 0.5f + (float)k};
+    const v2f m = {0.999f + seed * 1e-9f, 0.998f + seed * 1e-9f}, c = {1e-3f, 2e-3f};
+    for (int it = 0; it < iters; it++) {
+#define RT_PK16(OP, ARGS)                                                                                              \
+    __asm__ volatile(OP " %0, %0, " ARGS "\n" OP " %1, %1, " ARGS "\n" OP " %2, %2, " ARGS "\n" OP " %3, %3, " ARGS "\n"     \
+                     OP " %4, %4, " ARGS "\n" OP " %5, %5, " ARGS "\n" OP " %6, %6, " ARGS "\n" OP " %7, %7, " ARGS "\n"     \
+                     OP " %8, %8, " ARGS "\n" OP " %9, %9, " ARGS "\n" OP " %10, %10, " ARGS "\n" OP " %11, %11, " ARGS "\n" \
+                     OP " %12, %12, " ARGS "\n" OP " %13, %13, " ARGS "\n" OP " %14, %14, " ARGS "\n" OP " %15, %15, " ARGS  \
+                     : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]),      \
+                       "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]) \
+                     : "v"(m), "v"(c))
+        if (KIND == 1) RT_PK16("v_pk_fma_f32", "%16, %17");
+        else if (KIND == 2) RT_PK16("v_pk_mul_f32", "%16");
+        else RT_PK16("v_pk_add_f32", "%17");
+#undef RT_PK16
+    }
+    v2f r = a[0];
+#pragma unroll
+    for (int k = 1; k < 16; k++) r = r + a[k];
+    if (r.x + r.y == 12345.678f) out[blockIdx.x * blockDim.x + threadIdx.x] = r.x;  // (never true: keeps the chains alive)
 }
 
 // ============================================================================ split probe (rt_split_probe)
@@ -2176,6 +2348,14 @@ struct rt_scene {
     int *d_order = nullptr;       // leaf order -> original
     std::vector<int> h_order;     // leaf order -> original
     std::vector<int> h_inverse;   // original -> leaf order
+    // RT_FLAG_REFERENCE_WALK: the reference's own tree (rt_ref_tree.h), built and uploaded by the first render that asks
+    // for it (ensure_ref_tree) from the caller's triangles kept here
+    std::vector<float> h_tri9;
+    mutable std::mutex ref_mutex;
+    mutable bool ref_ready = false;
+    mutable float4 *d_ref_nodes = nullptr;
+    mutable int *d_ref_prims = nullptr;
+    mutable int ref_nodes_count = 0, ref_depth = 0;
     rt_scene() = default;
     rt_scene(const rt_scene &) = delete;
     rt_scene &operator=(const rt_scene &) = delete;
@@ -2188,6 +2368,8 @@ struct rt_scene {
         (void)hipFree(d_lights);
         (void)hipFree(d_order);
         (void)hipFree(d_tables);
+        (void)hipFree(d_ref_nodes);
+        (void)hipFree(d_ref_prims);
     }
     DScene dev() const {
         DScene s;
@@ -2202,6 +2384,9 @@ struct rt_scene {
         s.num_mats = n_mats;
         s.tables = d_tables;
         s.tab_dwords = tab_dwords;
+        s.ref_nodes = d_ref_nodes;
+        s.ref_prims = d_ref_prims;
+        s.ref_n_prims = ref_ready ? n_tris : 0;
         return s;
     }
 };
@@ -2345,6 +2530,68 @@ bool validate_quads(const std::vector<rtbvh::Pair> &quads, int n_tris) {
     return visited == nr / 2 && tris == n_tris;
 }
 
+// RT_FLAG_REFERENCE_WALK: build the reference's tree from the caller's triangles, check its structure (a malformed tree
+// would hang the walk: every node reached exactly once, children adjacent, every primitive position in exactly one
+// leaf, depth within the walk's private stack) and upload it.  Once per scene, on the scene's device.
+int ensure_ref_tree(const rt_scene *scene) {
+    std::lock_guard<std::mutex> lock(scene->ref_mutex);
+    if (scene->ref_ready) return 0;
+    const int n = scene->n_tris;
+    if ((int)scene->h_tri9.size() != 9 * n) return fail("RT_FLAG_REFERENCE_WALK: the scene holds no triangle copy");
+    const rtref::Tree t = rtref::build(scene->h_tri9.data(), n);
+    const int nn = (int)t.nodes.size();
+    if (n > 0) {
+        std::vector<char> seen_node((size_t)nn, 0), seen_prim((size_t)n, 0);
+        std::vector<std::pair<int, int>> todo{{0, 0}};  // (node, depth)
+        int visited = 0, prims = 0;
+        seen_node[0] = 1;
+        while (!todo.empty()) {
+            const auto [k, dep] = todo.back();
+            todo.pop_back();
+            visited++;
+            const rtref::Node &nd = t.nodes[(size_t)k];
+            if (nd.count > 0) {
+                if (nd.link < 0 || nd.link + nd.count > n) return fail("RT_FLAG_REFERENCE_WALK: malformed leaf");
+                for (int i = nd.link; i < nd.link + nd.count; i++) {
+                    if (seen_prim[i]) return fail("RT_FLAG_REFERENCE_WALK: primitive in two leaves");
+                    seen_prim[i] = 1;
+                    prims++;
+                }
+            } else {
+                if (nd.count < 0 || nd.link <= 0 || nd.link + 1 >= nn || seen_node[nd.link] || seen_node[nd.link + 1] || dep >= rtref::kMaxDepth)
+                    return fail("RT_FLAG_REFERENCE_WALK: malformed inner node");
+                seen_node[nd.link] = seen_node[nd.link + 1] = 1;
+                todo.push_back({nd.link, dep + 1});
+                todo.push_back({nd.link + 1, dep + 1});
+            }
+        }
+        if (visited != nn || prims != n) return fail("RT_FLAG_REFERENCE_WALK: tree does not cover the scene");
+        for (int i = 0; i < n; i++)
+            if (t.prims[i] < 0 || t.prims[i] >= n) return fail("RT_FLAG_REFERENCE_WALK: bad primitive order");
+    }
+    std::vector<int> prim_leaf((size_t)std::max(n, 1), 0);  // reference primitive position -> this scene's leaf-order index
+    for (int i = 0; i < n; i++) prim_leaf[i] = scene->h_inverse[t.prims[i]];
+    float4 *dn = nullptr;
+    int *dp = nullptr;
+    HIP_TRY(hipMalloc((void **)&dn, sizeof(rtref::Node) * (size_t)std::max(nn, 1)));
+    if (hipMalloc((void **)&dp, sizeof(int) * prim_leaf.size()) != hipSuccess) {
+        (void)hipFree(dn);
+        return fail("RT_FLAG_REFERENCE_WALK: out of device memory");
+    }
+    if (hipMemcpy(dn, t.nodes.data(), sizeof(rtref::Node) * (size_t)nn, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(dp, prim_leaf.data(), sizeof(int) * prim_leaf.size(), hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipFree(dn);
+        (void)hipFree(dp);
+        return fail("RT_FLAG_REFERENCE_WALK: upload failed");
+    }
+    scene->d_ref_nodes = dn;
+    scene->d_ref_prims = dp;
+    scene->ref_nodes_count = nn;
+    scene->ref_depth = t.depth;
+    scene->ref_ready = true;
+    return 0;
+}
+
 // Device temporaries and events of one host call: released on EVERY return path (HIP_TRY returns early on errors)
 struct DevScope {
     std::vector<void *> ptrs;
@@ -2471,7 +2718,7 @@ int get_context(int n, int lane, Context **out) {
     if (dev_alloc(*c, p.base, (size_t)A_COUNT * n)) return 1;
     if (dev_alloc(*c, c->rng_backup, (size_t)6 * n)) return 1;
     if (dev_alloc(*c, c->d_ctr, 1)) return 1;
-    c->n_rows = ((n + kBlock - 1) / kBlock) * (kBlock / 64);
+    c->n_rows = 2 * ((n + kBlock - 1) / kBlock) * (kBlock / 64);  // (x 2: RT_HALF_WAVES launches twice the waves)
     if (dev_alloc(*c, c->d_rows, (size_t)c->n_rows)) return 1;
     if (dev_alloc(*c, c->d_jump, (size_t)20 * 800)) return 1;
     HIP_TRY(hipMemcpy(c->d_jump, jump_powers().data(), sizeof(uint32_t) * 20 * 800, hipMemcpyHostToDevice));
@@ -2500,6 +2747,12 @@ static int lds_stack_cap(const rt_scene *scene, int limit) {
     do {                                                                                                   \
         if (wide) hipLaunchKernelGGL((k_trace<MODE, true>), grid, dim3(kBlock), lds, stream, __VA_ARGS__);   \
         else hipLaunchKernelGGL((k_trace<MODE, false>), grid, dim3(kBlock), lds, stream, __VA_ARGS__);       \
+    } while (0)
+// ... or, with RT_FLAG_REFERENCE_WALK, the build that walks the reference's tree (the node format does not matter then)
+#define RT_LAUNCH_TRACE_REF(MODE, literal, wide, grid, lds, stream, ...)                                                  \
+    do {                                                                                                                  \
+        if (literal) hipLaunchKernelGGL((k_trace<MODE, false, 8, true>), grid, dim3(kBlock), lds, stream, __VA_ARGS__);     \
+        else RT_LAUNCH_TRACE(MODE, wide, grid, lds, stream, __VA_ARGS__);                                                 \
     } while (0)
 
 // Global overflow part of the traversal stacks: `levels` entries for each of kOverStride lanes.  Every OWNER of
@@ -2561,6 +2814,8 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
     // slots; camera ray `cid` of the rank has the global key cid * shard_count + shard_index, so the keys of a pixel's
     // samples are the same set whatever the shard count (see AdvanceParams)
     const bool per_sample = (flags & RT_FLAG_RNG_PER_SAMPLE) != 0;
+    const bool literal = (flags & RT_FLAG_REFERENCE_WALK) != 0;
+    if (literal && per_sample) return fail("rt_render_shard: RT_FLAG_REFERENCE_WALK is a parity mode and RT_FLAG_RNG_PER_SAMPLE is not: pick one");
     if (per_sample) {
         if (spp % shard_count != 0) return fail("rt_render_shard: RT_FLAG_RNG_PER_SAMPLE needs num_samples divisible by shard_count");
         spp /= shard_count;
@@ -2571,6 +2826,7 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
     if (dev != scene->device) return fail("rt_render_shard: scene was created on another device");
+    if (literal && ensure_ref_tree(scene)) return 1;
     const int n = per_sample ? kW : kW / shard_count;
     const int slot_lo = per_sample ? 0 : shard_index * n;
     Context *cp = nullptr;
@@ -2703,12 +2959,16 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
         const int dbg = (flags & 0x100u) ? 1 : 0;
         unsigned long long *paths_prof = nullptr;
 #ifdef RT_TRACE_PROFILE
-        const size_t prof_bytes = 192 + 32 * (size_t)(grid_for(n) * (kBlock / 64));
+        const size_t prof_bytes = 192 + 32 * (size_t)(2 * grid_for(n) * (kBlock / 64));  // (x 2: RT_HALF_WAVES)
         HIP_TRY(hipMalloc((void **)&paths_prof, prof_bytes));
         HIP_TRY(hipMemset(paths_prof, 0, prof_bytes));
 #endif
         // all workgroups resident at once (4 per CU at <= 128 VGPRs), lane count a divisor of n
         int paths_blocks = grid_for(n);
+        // RT_HALF_WAVES=1 (experiment, shards of <= 1/8 of the slots): 32 slots per wave instead of 64, twice the waves
+        int half_fill = 0;
+        if (const char *e = getenv("RT_HALF_WAVES")) half_fill = (atoi(e) != 0 && 2 * paths_blocks <= 1024 && !per_sample) ? 1 : 0;
+        if (half_fill) paths_blocks *= 2;
         {
             int want = 1024;
             if (const char *e = getenv("RT_PATHS_BLOCKS")) want = std::max(1, atoi(e));
@@ -2735,8 +2995,12 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
         // node block and no trip through the loop head after ADV / GEN: 20 and GEN 6 are 1 % ahead of 24 and 8); the
         // 2-waves-per-SIMD shards want 30..38 (24: -2.5 %)
         int adv_batch = few_blocks ? 34 : 20;
-        if (const char *e = getenv("RT_ADV_BATCH")) adv_batch = std::max(1, std::min(64, atoi(e)));
         int gen_batch = 6;  // lanes waiting for the GEN block before it runs (unless nothing else can); flat 4..8
+        if (half_fill) {  // (half the lanes per wave: half the thresholds)
+            adv_batch /= 2;
+            gen_batch /= 2;
+        }
+        if (const char *e = getenv("RT_ADV_BATCH")) adv_batch = std::max(1, std::min(64, atoi(e)));
         if (const char *e = getenv("RT_GEN_BATCH")) gen_batch = std::max(1, std::min(64, atoi(e)));
         int tri_follow = 1;  // a triangle block right behind a node block when this many lanes hold a leaf by then; 0 = never
         if (const char *e = getenv("RT_TRI_FOLLOW")) tri_follow = std::max(0, std::min(64, atoi(e)));
@@ -2767,16 +3031,30 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
     do {                                                                                                               \
         if (few_blocks)                                                                                                \
             hipLaunchKernelGGL((k_paths<T, WD, MJ, 2>), grid_paths, block, lds_paths, st, sc, c.pools, cam, ap, d_sum,   \
-                               c.d_rows, paths_cap, d_over2, adv_batch, dbg, paths_prof, top_n, prio_rotate, rot_wave, rot_set, gen_batch, tri_follow, &c.d_ctr->pad2[0]); \
+                               c.d_rows, paths_cap, d_over2, adv_batch, dbg, paths_prof, top_n, prio_rotate, rot_wave, rot_set, gen_batch, tri_follow, &c.d_ctr->pad2[0], half_fill); \
         else                                                                                                           \
             hipLaunchKernelGGL((k_paths<T, WD, MJ, 4>), grid_paths, block, lds_paths, st, sc, c.pools, cam, ap, d_sum,   \
-                               c.d_rows, paths_cap, d_over2, adv_batch, dbg, paths_prof, 0, prio_rotate, rot_wave, rot_set, gen_batch, tri_follow, &c.d_ctr->pad2[0]);     \
+                               c.d_rows, paths_cap, d_over2, adv_batch, dbg, paths_prof, 0, prio_rotate, rot_wave, rot_set, gen_batch, tri_follow, &c.d_ctr->pad2[0], half_fill);     \
     } while (0)
-        if (per_sample && !few_blocks) {
+        if (literal) {
+            // RT_FLAG_REFERENCE_WALK: the build whose node block is the reference's own walk
+#define RT_LAUNCH_REF(T)                                                                                               \
+    do {                                                                                                               \
+        if (few_blocks)                                                                                                \
+            hipLaunchKernelGGL((k_paths<T, false, true, 2, false, true>), grid_paths, block, lds_paths, st, sc, c.pools, cam, ap, d_sum, \
+                               c.d_rows, paths_cap, d_over2, adv_batch, dbg, paths_prof, 0, prio_rotate, rot_wave, rot_set, gen_batch, tri_follow, &c.d_ctr->pad2[0], half_fill); \
+        else                                                                                                           \
+            hipLaunchKernelGGL((k_paths<T, false, true, 4, false, true>), grid_paths, block, lds_paths, st, sc, c.pools, cam, ap, d_sum, \
+                               c.d_rows, paths_cap, d_over2, adv_batch, dbg, paths_prof, 0, prio_rotate, rot_wave, rot_set, gen_batch, tri_follow, &c.d_ctr->pad2[0], half_fill); \
+    } while (0)
+            if (lds_tables) RT_LAUNCH_REF(true);
+            else RT_LAUNCH_REF(false);
+#undef RT_LAUNCH_REF
+        } else if (per_sample && !few_blocks) {
             // per-sample streams: the build in which the waves draw their camera rays from the frame's counter
 #define RT_LAUNCH_DRAW(T, WD)                                                                                          \
     hipLaunchKernelGGL((k_paths<T, WD, true, 4, true>), grid_paths, block, lds_paths, st, sc, c.pools, cam, ap, d_sum,  \
-                       c.d_rows, paths_cap, d_over2, adv_batch, dbg, paths_prof, 0, prio_rotate, rot_wave, rot_set, gen_batch, tri_follow, &c.d_ctr->pad2[0])
+                       c.d_rows, paths_cap, d_over2, adv_batch, dbg, paths_prof, 0, prio_rotate, rot_wave, rot_set, gen_batch, tri_follow, &c.d_ctr->pad2[0], half_fill)
             if (lds_tables && scene->wide) RT_LAUNCH_DRAW(true, true);
             else if (lds_tables) RT_LAUNCH_DRAW(true, false);
             else if (scene->wide) RT_LAUNCH_DRAW(false, true);
@@ -2840,7 +3118,7 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
                 else
                     hipLaunchKernelGGL(k_advance<false>, grid, block, 0, st, sc, c.pools, cam, ap, d_sum, c.d_ctr, c.d_rows);
                 HIP_TRY(hipEventRecord(e1, st));
-                RT_LAUNCH_TRACE(MODE_POOL, scene->wide, grid_trace, lds_bytes, st, sc, c.pools, tpp, stack_cap, d_over);
+                RT_LAUNCH_TRACE_REF(MODE_POOL, literal, scene->wide, grid_trace, lds_bytes, st, sc, c.pools, tpp, stack_cap, d_over);
                 HIP_TRY(hipEventRecord(e2, st));
                 HIP_TRY(hipEventRecord(e3, st));
             } else {
@@ -2848,7 +3126,7 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
                     hipLaunchKernelGGL(k_advance<true>, grid, block, 0, st, sc, c.pools, cam, ap, d_sum, c.d_ctr, c.d_rows);
                 else
                     hipLaunchKernelGGL(k_advance<false>, grid, block, 0, st, sc, c.pools, cam, ap, d_sum, c.d_ctr, c.d_rows);
-                RT_LAUNCH_TRACE(MODE_POOL, scene->wide, grid_trace, lds_bytes, st, sc, c.pools, tpp, stack_cap, d_over);
+                RT_LAUNCH_TRACE_REF(MODE_POOL, literal, scene->wide, grid_trace, lds_bytes, st, sc, c.pools, tpp, stack_cap, d_over);
             }
             rounds++;
         }
@@ -2882,7 +3160,7 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
                 HIP_TRY(hipStreamSynchronize(st));
                 if (c.h_ctr[0].round_shades == 0) break;
             }
-            RT_LAUNCH_TRACE(MODE_POOL, scene->wide, grid_trace, lds_bytes, st, sc, c.pools, tpp, stack_cap, d_over);
+            RT_LAUNCH_TRACE_REF(MODE_POOL, literal, scene->wide, grid_trace, lds_bytes, st, sc, c.pools, tpp, stack_cap, d_over);
             HIP_TRY(hipGetLastError());
         }
     }
@@ -3114,6 +3392,7 @@ int rt_scene_create(const float *tri_p0p1p2, int n_tris, const int32_t *tri_mate
     if (n_tris > 0 && !bvh.quads.empty() && !validate_quads(bvh.quads, n_tris))
         return fail("rt_scene_create: the 4-wide BVH is malformed (structure, or an absent child without its +inf box)");
     sc->n_tris = n_tris;
+    if (n_tris > 0) sc->h_tri9.assign(tri_p0p1p2, tri_p0p1p2 + 9 * (size_t)n_tris);  // (RT_FLAG_REFERENCE_WALK builds its tree from these)
     sc->wide = true;  // 4-wide nodes (two pair-style records each): half the dependent fetches per ray; RT_BVH_WIDE=0: 2-wide
     if (const char *e = getenv("RT_BVH_WIDE")) sc->wide = atoi(e) != 0;
     // a tree too deep for the 4-wide walk's stack (up to 3 entries per level) may still fit the 2-wide walk's (1 per level):
@@ -3341,9 +3620,16 @@ int rt_render(const rt_scene *scene, const rt_camera *camera, int width, int hei
 
 int rt_trace_closest(const rt_scene *scene, int n, const float *origin_xyz, const float *dir_xyz, const float *tmax,
                      int32_t *hit_tri, float *t, float *u, float *v) {
+    return rt_trace_closest_flags(scene, 0u, n, origin_xyz, dir_xyz, tmax, hit_tri, t, u, v);
+}
+
+int rt_trace_closest_flags(const rt_scene *scene, uint32_t flags, int n, const float *origin_xyz, const float *dir_xyz,
+                           const float *tmax, int32_t *hit_tri, float *t, float *u, float *v) {
     if (!scene || n < 0 || (n > 0 && (!origin_xyz || !dir_xyz || !tmax || !hit_tri || !t || !u || !v)))
         return fail("rt_trace_closest: bad argument");
     if (n == 0) return 0;
+    const bool literal = (flags & RT_FLAG_REFERENCE_WALK) != 0;
+    if (literal && ensure_ref_tree(scene)) return 1;
     float *d_o, *d_d, *d_tm, *d_t, *d_u, *d_v;
     int *d_h;
     DevScope tmp;
@@ -3371,7 +3657,7 @@ int rt_trace_closest(const rt_scene *scene, int n, const float *origin_xyz, cons
         tp.out_u = d_u;
         tp.out_v = d_v;
         DPools none{};
-        RT_LAUNCH_TRACE(MODE_TEST_CLOSEST, scene->wide, dim3(test_grid), sizeof(int) * kBlock * (size_t)(stack_cap + 2), nullptr,
+        RT_LAUNCH_TRACE_REF(MODE_TEST_CLOSEST, literal, scene->wide, dim3(test_grid), sizeof(int) * kBlock * (size_t)(stack_cap + 2), nullptr,
                         scene->dev(), none, tp, stack_cap, d_over);
     }
     HIP_TRY(hipGetLastError());
@@ -3384,9 +3670,16 @@ int rt_trace_closest(const rt_scene *scene, int n, const float *origin_xyz, cons
 
 int rt_trace_any(const rt_scene *scene, int n, const float *origin_xyz, const float *dir_xyz, const float *tmax,
                  const int32_t *excluded_tri, int32_t *occluded) {
+    return rt_trace_any_flags(scene, 0u, n, origin_xyz, dir_xyz, tmax, excluded_tri, occluded);
+}
+
+int rt_trace_any_flags(const rt_scene *scene, uint32_t flags, int n, const float *origin_xyz, const float *dir_xyz,
+                       const float *tmax, const int32_t *excluded_tri, int32_t *occluded) {
     if (!scene || n < 0 || (n > 0 && (!origin_xyz || !dir_xyz || !tmax || !excluded_tri || !occluded)))
         return fail("rt_trace_any: bad argument");
     if (n == 0) return 0;
+    const bool literal = (flags & RT_FLAG_REFERENCE_WALK) != 0;
+    if (literal && ensure_ref_tree(scene)) return 1;
     std::vector<int> excl(n);
     for (int i = 0; i < n; i++) {
         int e = excluded_tri[i];
@@ -3417,7 +3710,7 @@ int rt_trace_any(const rt_scene *scene, int n, const float *origin_xyz, const fl
         tp.excluded = d_e;
         tp.out_i = d_occ;
         DPools none{};
-        RT_LAUNCH_TRACE(MODE_TEST_ANY, scene->wide, dim3(test_grid), sizeof(int) * kBlock * (size_t)(stack_cap + 2), nullptr,
+        RT_LAUNCH_TRACE_REF(MODE_TEST_ANY, literal, scene->wide, dim3(test_grid), sizeof(int) * kBlock * (size_t)(stack_cap + 2), nullptr,
                         scene->dev(), none, tp, stack_cap, d_over);
     }
     HIP_TRY(hipGetLastError());
@@ -3500,6 +3793,36 @@ int rt_calibrate_valu(int waves_per_simd, int iters, double *out_lane_ops_per_s,
     HIP_TRY(hipGetLastError());
     *out_lane_ops_per_s = best;
     if (out_wave_instr) *out_wave_instr = (double)blocks * 4.0 * 16.0 * (double)iters;  // v_fma_f32 wave-instructions per launch
+    return 0;
+}
+
+int rt_calibrate_valu_packed(int waves_per_simd, int iters, int kind, double *out_lane_ops_per_s) {
+    if (waves_per_simd < 1 || waves_per_simd > 8 || iters < 1 || kind < 1 || kind > 3 || !out_lane_ops_per_s)
+        return fail("rt_calibrate_valu_packed: bad argument");
+    int dev = 0, cus = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    const int blocks = cus * waves_per_simd;
+    float *d_out = nullptr;
+    DevScope tmp;
+    if (tmp.alloc(d_out, (size_t)blocks * 256)) return 1;
+    HIP_TRY(hipEventCreate(&tmp.e0));
+    HIP_TRY(hipEventCreate(&tmp.e1));
+    double best = 0.0;
+    for (int r = 0; r < 7; r++) {  // (first launch untimed; the best of six)
+        HIP_TRY(hipEventRecord(tmp.e0, nullptr));
+        if (kind == 1) hipLaunchKernelGGL(k_valu_calibrate_pk<1>, dim3(blocks), dim3(256), 0, nullptr, d_out, iters, 1.f);
+        else if (kind == 2) hipLaunchKernelGGL(k_valu_calibrate_pk<2>, dim3(blocks), dim3(256), 0, nullptr, d_out, iters, 1.f);
+        else hipLaunchKernelGGL(k_valu_calibrate_pk<3>, dim3(blocks), dim3(256), 0, nullptr, d_out, iters, 1.f);
+        HIP_TRY(hipEventRecord(tmp.e1, nullptr));
+        HIP_TRY(hipEventSynchronize(tmp.e1));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, tmp.e0, tmp.e1));
+        const double lane_ops = (double)blocks * 256.0 * 16.0 * 2.0 * (double)iters;  // two lane-operations per lane and instruction
+        if (r > 0 && ms > 0.f) best = std::max(best, lane_ops / (ms * 1e-3));
+    }
+    HIP_TRY(hipGetLastError());
+    *out_lane_ops_per_s = best;
     return 0;
 }
 

@@ -163,3 +163,58 @@ def test_a_failing_rank_does_not_strand_its_peers(tmp_path):
     assert (tmp_path / "fail0.txt").read_text() == "1 0"  # rank 0 did not fail itself, but knows
     assert (tmp_path / "fail1.txt").read_text() == "1 0"
     assert rtdist.agree_on_failure(True) is True and rtdist.agree_on_failure(False) is False  # single process
+
+
+# ----------------------------------------------------------------------------- `python bench.py --gpus N` without a launcher
+def _run_worker(*extra, timeout=240):
+    import json
+    import subprocess
+    worker = os.path.join(ROOT, "tests", "selflaunch_worker.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, worker] + list(extra), capture_output=True, text=True, timeout=timeout, env=env)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    return p.returncode, [json.loads(ln) for ln in lines], p.stderr
+
+
+def test_self_launch_starts_its_own_ranks_and_relays_rank_zero(oracle):
+    """What `python bench.py --gpus 2` does when the driver starts it WITHOUT torch.distributed.run: the parent (no torch, no
+    HIP) starts the ranks itself (rtcuda_amd.dist.self_launch), rank 0's one JSON line is the parent's output, exit code 0.
+    The ranks here render with the CPU oracle over gloo (tests/selflaunch_worker.py mirrors bench.py's N > 1 flow): both
+    ranks are seen by the backend, each owns half the camera rays, the totals summed over the ranks equal the unsharded
+    frame's, and rank 0 holds the whole post-processed image."""
+    w, h, spp = 1024, 600, 1  # 614 400 camera rays: more than W / 2, so rank 1's slots serve some of them
+    rc, lines, err = _run_worker("--ranks", "2", "--width", str(w), "--height", str(h), "--spp", str(spp), "--steps", "1")
+    assert rc == 0, err[-2000:]
+    assert len(lines) == 1  # one line, from rank 0
+    out = lines[0]
+    assert out["n_ranks"] == 2 and out["ranks_seen"] == 2 and out["failed"] is False
+    assert [r[1] for r in out["per_rank"]] == [0, 1]
+    assert [r[0] for r in out["per_rank"]] == [1 << 19, w * h * spp - (1 << 19)]  # slots [0, W/2) and [W/2, W)
+    assert out["totals"] == out["totals_unsharded"]
+    assert out["image_max_abs_diff"] < 1e-5 and out["image_sum"] > 0
+
+
+def test_self_launch_reports_a_dead_rank_instead_of_hanging(oracle):
+    """A rank that dies before its first collective: its peer would wait in init_process_group / the reduce for ever.  The
+    parent gives the peer a grace period, terminates it (by PID) and exits non-zero with the dead rank's code."""
+    import time
+    t0 = time.monotonic()
+    rc, lines, _ = _run_worker("--ranks", "2", "--fail-rank", "1", "--grace", "3")
+    assert rc == 7
+    assert lines == []
+    assert time.monotonic() - t0 < 120
+
+
+def test_bench_py_starts_ranks_itself_and_fails_loudly_without_a_gpu():
+    """bench.py itself, as the driver invokes it (`python3 bench.py --gpus 2 ...`, no launcher): it must get as far as its
+    ranks -- each of which refuses to run without the HIP library's GPU (there is no CPU fallback) -- and exit non-zero."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: the N > 1 flow is exercised by the GPU rehearsal instead")
+    assert p.returncode != 0
+    assert p.stderr.count("bench.py needs a GPU") == 2  # both ranks were started and said so
+    assert "launch with torch.distributed.run" not in p.stderr

@@ -223,8 +223,9 @@ def test_full_pool_k_paths_build_does_not_spill_vector_registers():
         # k_paths<LDS_TABLES = true, WIDE = true (bench) / false, MAJORITY = true, MIN_WAVES = 4, DRAW_CIDS = false>: the
         # reference-mode builds; DRAW_CIDS = true: the per-sample-RNG builds (fewer registers: at least 4 waves)
         for draw in (0, 1):
-            if (f"Function Name: _Z7k_pathsILb1ELb1ELb1ELi4ELb{draw}E" in line
-                    or f"Function Name: _Z7k_pathsILb1ELb0ELb1ELi4ELb{draw}E" in line):
+            # (... LITERAL = false: the RT_FLAG_REFERENCE_WALK builds are opt-in, never timed, and do spill)
+            if (f"Function Name: _Z7k_pathsILb1ELb1ELb1ELi4ELb{draw}ELb0EE" in line
+                    or f"Function Name: _Z7k_pathsILb1ELb0ELb1ELi4ELb{draw}ELb0EE" in line):
                 block = "\n".join(lines[k:k + 12])
                 m_spill = re.search(r"VGPRs Spill: (\d+)", block)
                 m_occ = re.search(r"Occupancy \[waves/SIMD\]: (\d+)", block)
@@ -284,3 +285,56 @@ np.savez(sys.argv[1], tri=tri, t=t, nodes=st[1], rays=st[0])
     assert np.array_equal(out["0"]["tri"], out["2"]["tri"]) and np.array_equal(out["0"]["t"], out["2"]["t"])
     assert (out["0"]["tri"] >= 0).mean() > 0.4
     assert out["2"]["nodes"] < 0.97 * out["0"]["nodes"]  # measured: -7 % on these primary rays, -10 % over whole paths
+
+
+# ----------------------------------------------------------------------------- RT_FLAG_REFERENCE_WALK: the reference's tree
+def _ref_tree(L, tris):
+    tris = np.ascontiguousarray(tris, np.float32).reshape(-1, 9)
+    n = tris.shape[0]
+    L.rt_ref_tree_export.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 5
+    depth = ctypes.c_int(0)
+    nn = L.rt_ref_tree_export(tris.ctypes.data, n, None, None, None, None, ctypes.byref(depth))
+    bounds = np.zeros((nn, 6), np.float32)
+    count, link, prims = np.zeros(nn, np.int32), np.zeros(nn, np.int32), np.zeros(max(n, 1), np.int32)
+    L.rt_ref_tree_export(tris.ctypes.data, n, bounds.ctypes.data, count.ctypes.data, link.ctypes.data, prims.ctypes.data,
+                         ctypes.byref(depth))
+    return bounds, count, link, prims[:n], depth.value
+
+
+@pytest.mark.parametrize("variant", ["matte", "sixteen_lights", "four_bunnies"])
+def test_reference_tree_of_the_product_is_the_oracles_node_for_node(oracle, variant):
+    """The tree RT_FLAG_REFERENCE_WALK walks (rt_ref_tree.h, the product's own builder after bvh.cuh:30-219) against the
+    oracle's restatement of the same constructor: every node's bounds, primitive count and child / first-primitive index,
+    and the primitive order -- bit for bit -- plus the BVH statistics SURVEY Appendix C records for these scenes."""
+    from rtcuda_amd import scenes
+    arrays = scenes.cornell_bunny(variant)
+    L = _hostcheck()
+    bounds, count, link, prims, depth = _ref_tree(L, arrays.tris)
+    ob, oc, oi, op = oracle.scene(arrays).nodes()
+    assert bounds.shape == ob.shape and np.array_equal(bounds.view(np.uint32), ob.view(np.uint32))
+    assert np.array_equal(count, oc) and np.array_equal(link, oi) and np.array_equal(prims, op)
+    expect = {"matte": (75687, 69463, 20), "sixteen_lights": (75701, 69477, 20), "four_bunnies": (302715, 277816, 22)}[variant]
+    assert (bounds.shape[0], prims.shape[0], depth) == expect  # "BVH has N nodes and M primitives, with max_depth = D"
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 7, 200])
+def test_reference_tree_tiny_and_coincident(oracle, n):
+    """Small and degenerate inputs (equal centres: the order std::sort leaves among equal keys is part of the tree)."""
+    from rtcuda_amd.scenes import SceneArrays
+    rng = np.random.default_rng(100 + n)
+    tris = rng.uniform(0, 1, (max(n, 1), 9)).astype(np.float32)[:n]
+    if n >= 7:
+        tris[3] = tris[1]          # coincident triangles
+        tris[5, 0::3] = tris[2, 0::3]  # equal x coordinates: ties on one axis only
+    L = _hostcheck()
+    bounds, count, link, prims, depth = _ref_tree(L, tris)
+    if n == 0:
+        assert bounds.shape[0] == 1 and count[0] == 0
+        return
+    from rtcuda_amd import scenes
+    base = scenes.cornell_bunny("matte", bunny=False)
+    arrays = SceneArrays(tris=tris, tri_material=np.zeros(n, np.int32), tri_light=np.full(n, -1, np.int32),
+                         materials=base.materials, lights=base.lights[:0])
+    ob, oc, oi, op = oracle.scene(arrays).nodes()
+    assert np.array_equal(bounds.view(np.uint32), ob.view(np.uint32))
+    assert np.array_equal(count, oc) and np.array_equal(link, oi) and np.array_equal(prims, op)

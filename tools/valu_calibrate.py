@@ -22,4 +22,11 @@ for waves in (1, 2, 4, 8):
     out[f"waves_per_simd_{waves}"] = {"lane_ops_per_s": rate, "T_lane_ops_per_s": round(rate / 1e12, 2),
                                       "frac_of_spec_peak": round(rate / (256 * 4 * 32 * 2.4e9), 4),
                                       "wave_instructions_per_launch": winstr}
+# Packed fp32 (round 4): the same 16 chains on register pairs.  `x_scalar` = lane-operations/s relative to the v_fma_f32
+# stream at the same occupancy: 2.0 means a packed instruction issues at the rate of a scalar one.
+for kind, name in ((1, "v_pk_fma_f32"), (2, "v_pk_mul_f32"), (3, "v_pk_add_f32")):
+    for waves in (1, 2, 4, 8):
+        rate = api.calibrate_valu_packed(waves, 20000, kind)
+        base = out[f"waves_per_simd_{waves}"]["lane_ops_per_s"]
+        out[f"{name}_waves_per_simd_{waves}"] = {"T_lane_ops_per_s": round(rate / 1e12, 2), "x_scalar": round(rate / base, 3)}
 print(json.dumps(out))
