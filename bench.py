@@ -302,6 +302,17 @@ def main():
             "parallelism": f"every rank: all 2^20 slots, {spp // world} of the {spp} samples of every pixel" if world > 1 else "1 GPU"}
         ps.close()
 
+    # ---- a per-sample HEADLINE (--rng-mode per_sample) is checked against one untimed reference-mode frame: the same path
+    # statistics (a lost or duplicated chunk of camera-ray ids, or a wrong stream key, would move them) -- ADVICE r3
+    if per_sample_headline and args.debug_flags == 0:
+        ref = Config(env, arrays, w, h, spp, args.max_bounces, base_flags, args.deterministic)
+        ref.step()
+        ref_totals = ref.frame_totals()
+        ref.close()
+        if head_totals["camera_rays"] != w * h * spp or any(
+                abs(head_totals[k] - ref_totals[k]) > 0.005 * ref_totals[k] for k in ("shade_events", "any_rays")):
+            invalid = "per_sample frame: camera rays or per-sample event rates differ from the reference-mode frame's"
+
     # ---- BASELINE configs 3, 5, 4: a few frames each, totals against the committed oracle totals
     extras = None
     if not args.no_extras and not per_sample_headline and args.debug_flags == 0 and (w, h) == (1920, 1080):

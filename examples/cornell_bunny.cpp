@@ -3,14 +3,30 @@
 // Unlike main.cu, which hard-codes 600 x 600 x 10 and "../bun_zipper.ply", sizes and paths are arguments.
 //
 //   make -C rtcuda_amd/csrc example
-//   examples/cornell_bunny [width height spp [bun_zipper.ply [image.ppm [matte|full_bsdf|four_bunnies|sixteen_lights]]]]
+//   examples/cornell_bunny [--devices 0,1,...] [width height spp [bun_zipper.ply [image.ppm [matte|full_bsdf|four_bunnies|sixteen_lights]]]]
+// --devices: several GPUs of the node behind the one render() call (rt_render_multi; the reference drives one device);
+// a device may be listed twice, e.g. `--devices 0,0` on a one-GPU box.
 #include <cstdlib>
+#include <cstring>
 #include <iostream>
 #include <string>
+#include <vector>
 
 #include "rtcuda/cornell_bunny.hpp"
 
 int main(int argc, char **argv) {
+    std::vector<int> devices;
+    if (argc > 2 && strcmp(argv[1], "--devices") == 0) {
+        for (const char *q = argv[2]; *q;) {
+            char *end = nullptr;
+            long v = strtol(q, &end, 10);
+            if (end == q) break;
+            devices.push_back((int)v);
+            q = (*end == ',') ? end + 1 : end;
+        }
+        argv += 2;
+        argc -= 2;
+    }
     const int width = argc > 1 ? atoi(argv[1]) : 600, height = argc > 2 ? atoi(argv[2]) : 600;
     const int num_samples = argc > 3 ? atoi(argv[3]) : 10, max_bounces = 10;  // main.cu:168-170
     const std::string ply = argc > 4 ? argv[4] : "data/bun_zipper.ply";
@@ -32,8 +48,10 @@ int main(int argc, char **argv) {
         std::vector<Vec3> framebuffer;
         rt_stats st;
         profiler.start("Rendering");
-        render(width, height, num_samples, max_bounces, camera, scene, framebuffer, 1, &st);
+        if (devices.empty()) render(width, height, num_samples, max_bounces, camera, scene, framebuffer, 1, &st);
+        else render(width, height, num_samples, max_bounces, camera, scene, framebuffer, devices, 1, &st);
         profiler.stop();
+        if (!devices.empty()) std::cout << "rendered as " << st.reserved[3] << " device shard(s)" << std::endl;
         std::cout << "render loop " << st.seconds_render * 1e3 << " ms, "
                   << (double)width * height * num_samples / st.seconds_render / 1e6 << " Msamples/s" << std::endl;
         profiler.start("Writing image");

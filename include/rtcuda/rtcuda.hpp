@@ -26,6 +26,7 @@
 #include <cassert>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <cfloat>
@@ -307,14 +308,49 @@ inline rt_scene *realise(const Scene &scene) {
 // the first time a Scene is rendered.  prepare() does it ahead of time, so a driver can time the two apart.
 inline void prepare(const Scene &scene) { (void)rtcuda_detail::realise(scene); }
 
+// A driver that must keep the reference's exact call (main.cu:173) can still reach several GPUs: RTCUDA_DEVICES="0,1,2,3" in
+// the environment sends the seven-argument render() below through the multi-device path (rt_render_multi).
+inline std::vector<int> devices_from_env() {
+    std::vector<int> d;
+    if (const char *e = std::getenv("RTCUDA_DEVICES")) {
+        const char *q = e;
+        while (*q) {
+            char *end = nullptr;
+            long v = std::strtol(q, &end, 10);
+            if (end == q) break;
+            d.push_back((int)v);
+            q = (*end == ',') ? end + 1 : end;
+        }
+    }
+    return d;
+}
+
 // render.cuh:366-367.  `seed` is the reference's hard-coded RAND_SEED = 1 (render.cuh:417).
 inline void render(int width, int height, int num_samples, int max_bounces, Camera camera, Scene scene,
                    std::vector<Vec3> &framebuffer, uint64_t seed = 1, rt_stats *stats = nullptr) {
     rt_scene *h = rtcuda_detail::realise(scene);
     framebuffer.resize((size_t)width * height);
     static_assert(sizeof(Vec3) == 12, "Vec3 must be three packed floats");
+    const std::vector<int> devices = devices_from_env();
+    if (!devices.empty()) {
+        rtcuda_detail::check(rt_render_multi(h, &camera.pod, width, height, num_samples, max_bounces, seed, 0, devices.data(),
+                                             (int)devices.size(), reinterpret_cast<float *>(framebuffer.data()), stats), "render");
+        return;
+    }
     rtcuda_detail::check(rt_render(h, &camera.pod, width, height, num_samples, max_bounces, seed, 0,
                                    reinterpret_cast<float *>(framebuffer.data()), stats), "render");
+}
+
+// The same call over several GPUs of the node (rt_render_multi): slot-range shards, one host thread per device, the
+// shards' sums added on devices[0].  No reference counterpart -- render.cuh:366-367 is one device.  `devices` are HIP device
+// ordinals (their number must divide 1048576); `flags`: RT_FLAG_* of rtcuda_amd.h.
+inline void render(int width, int height, int num_samples, int max_bounces, Camera camera, Scene scene,
+                   std::vector<Vec3> &framebuffer, const std::vector<int> &devices, uint64_t seed = 1, rt_stats *stats = nullptr,
+                   uint32_t flags = 0) {
+    rt_scene *h = rtcuda_detail::realise(scene);
+    framebuffer.resize((size_t)width * height);
+    rtcuda_detail::check(rt_render_multi(h, &camera.pod, width, height, num_samples, max_bounces, seed, flags, devices.data(),
+                                         (int)devices.size(), reinterpret_cast<float *>(framebuffer.data()), stats), "render");
 }
 
 #endif  // RTCUDA_HPP

@@ -78,7 +78,8 @@ typedef struct rt_stats {
     int64_t reserved[7];     /* reserved[0] = launches actually sampled by the event timer;
                                 reserved[1] = 1 when the frame ran as one persistent k_paths launch (then
                                 seconds_trace is that launch's duration and launches_trace is 1);
-                                reserved[2] = BVH node records that launch staged in LDS (small shards only) */
+                                reserved[2] = BVH node records that launch staged in LDS (small shards only);
+                                reserved[3] = rt_render_multi: number of device shards behind these totals */
 } rt_stats;
 
 /* Flags for rt_render / rt_render_shard */
@@ -141,6 +142,21 @@ int rt_camera_make(const float lookfrom[3], const float lookat[3], const float u
 int rt_render(const rt_scene *scene, const rt_camera *camera, int width, int height, int num_samples,
               int max_bounces, uint64_t seed, uint32_t flags, float *out_rgb, rt_stats *stats);
 
+/* The same call over several GPUs of one node, in ONE process (no reference counterpart: render.cuh:366-367 drives one
+ * device from one thread).  devices[0 .. n_devices) are HIP device ordinals; n_devices must divide W (1, 2, 4, 8, ...).
+ * The scene is replicated onto every listed device on first use (the replicas belong to `scene` and die with it), one
+ * host thread per device renders slot shard k of n_devices (see rt_render_shard) into a raw-sum buffer on its own
+ * device, the shards' sums are copied to devices[0] (peer copies over xGMI), added there in shard order, post-processed
+ * and copied to out_rgb (HOST, as rt_render).  A device may be listed more than once (its shards then run side by side
+ * on it) -- which is also how the path is tested on a one-GPU box.  With RT_FLAG_DETERMINISTIC the result is bit-equal
+ * to rt_render's with the same flag, whatever the device list.  stats: counts summed over the shards, times the
+ * maximum over the shards, reserved[3] = n_devices.  The calling thread's current device is left as it was.
+ * (The process-per-GPU deployment -- rt_render_shard under torch.distributed / RCCL, bench.py -- is the other way to
+ * the same image; this entry point is for a C++ driver that wants all GPUs behind one call.) */
+int rt_render_multi(const rt_scene *scene, const rt_camera *camera, int width, int height, int num_samples,
+                    int max_bounces, uint64_t seed, uint32_t flags, const int *devices, int n_devices, float *out_rgb,
+                    rt_stats *stats);
+
 /* Multi-GPU building block: render only the camera rays owned by path slots
  * [shard_index*W/shard_count, (shard_index+1)*W/shard_count) -- slot s serves exactly the camera
  * rays c with c % W == s, so shards are disjoint and their raw sums add up to the 1-GPU image.
@@ -200,6 +216,16 @@ int rt_calibrate_valu(int waves_per_simd, int iters, double *out_lane_ops_per_s,
 /* The same measurement with PACKED fp32 instructions (kind 1: v_pk_fma_f32, 2: v_pk_mul_f32, 3: v_pk_add_f32) on aligned
  * register pairs; lane-operations are counted as two per lane and instruction.  No reference counterpart. */
 int rt_calibrate_valu_packed(int waves_per_simd, int iters, int kind, double *out_lane_ops_per_s);
+
+/* How long ONE wave needs per instruction of a given kind, with `waves_per_simd` waves on every SIMD: out_seconds = best launch
+ * time of a kernel in which every wave issues *out_wave_instr_per_wave instructions of kind (16 independent chains per lane
+ * unless noted): 0 v_fma_f32 (VOP3), 1 v_fmac_f32, 2 v_mul_f32, 3 v_add_f32, 4 v_mov_b32, 5 v_xor_b32, 6 v_lshlrev_b32,
+ * 7 v_max_f32, 8 v_rcp_f32, 9 v_sqrt_f32, 10 v_cndmask_b32, 11 v_mul_f32 + dependent v_add_f32, 12 ONE dependent chain of
+ * v_fma_f32, 13 one dependent chain of v_mul_f32, 14 v_mul_f32 with a literal, 15 v_mul_f32 with an SGPR operand,
+ * 16 v_fma_f32 with two SGPR operands, 17 v_cndmask_b32 with an SGPR-pair mask, 18 v_cmp_lt_f32 -> vcc, 19 v_cmp_lt_f32 +
+ * dependent v_cndmask_b32, 20 v_bfi_b32, 21 v_and_b32, 22 - 25 three v_mul_f32 + one v_cndmask_b32 / v_max_f32 / v_mul_f32 /
+ * v_mov_b32 per chain (an instruction's cost inside a mix).  No reference counterpart (tools/issue_probe.py). */
+int rt_probe_issue(int kind, int waves_per_simd, int iters, double *out_seconds, double *out_wave_instr_per_wave);
 
 /* Measurement tool for the design question "one persistent kernel, or the reference's stage split (render.cuh:428-449:
  * init/mat/gen kernels and ah/ch kernels with dense queues between them)?".  Runs the round-per-launch pipeline of the

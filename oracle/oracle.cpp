@@ -52,6 +52,7 @@
 #include <cstdio>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <numeric>
 #include <stack>
 #include <vector>
@@ -924,9 +925,20 @@ RayLog g_raylog;
 // are allowed to generate camera rays (used to check partition invariance: the image is the sum of
 // the shards because slot s only ever serves camera rays c == s (mod W)); the full render is
 // [0, W).  fb_sum receives the raw sums, fb_out (optional) the post-processed image.
+// fb_fixed (optional, 3 P int64, zeroed by the caller): the PRODUCT's order-independent accumulation beside the reference's
+// float sums -- what RT_FLAG_DETERMINISTIC produces (rtcuda_amd.hip: deposit / acc_add / acc_flush): the contributions of
+// one camera ray (bounce-0 emission, then the unoccluded shadow rays in path order) are summed in three floats and that sum
+// is converted to 2^-30 fixed point (round to nearest even, non-finite sums dropped, magnitudes clamped to 2^31) and added
+// to the pixel; camera rays of the FINAL generation (which the product runs on its lockstep round pipeline) convert every
+// contribution on its own.  Integer adds commute, so the result is one well-defined array per (frame, seed): the tests hold
+// the GPU's fixed-point sums to a committed hash of it (tests/golden/full_size_image_hashes.json).
+inline long long to_fixed(float x) {
+    if (!(fabsf(x) <= 2147483648.f)) x = (x == x) ? copysignf(2147483648.f, x) : 0.f;
+    return llrintf(x * 1073741824.f);
+}
 void render_literal(const Scene &sc, const Camera &cam, int width, int height, int spp, int max_bounces,
                     uint64_t seed, int slot_lo, int slot_hi, int threads, float *fb_sum, float *fb_out,
-                    RenderStats *stats, int32_t *iter_counts, int iter_cap) {
+                    RenderStats *stats, int32_t *iter_counts, int iter_cap, long long *fb_fixed = nullptr) {
     const int W = kW;
     const int P = width * height;
     int cam_start = 0;
@@ -958,6 +970,34 @@ void render_literal(const Scene &sc, const Camera &cam, int width, int height, i
     p.ch_c.resize(3 * (size_t)W);
     p.rng.resize(W);
     std::vector<V3> fb(P, mk(0, 0, 0));  // init_framebuffer :61-66
+    // fixed-point twin (see above): per-slot sum of the current camera ray, and whether that ray is of the final generation
+    const int last_gen = (int)(((long long)cam_end + W - 1) / W) - 1;
+    std::vector<V3> acc(fb_fixed ? W : 0, mk(0, 0, 0));
+    std::vector<char> acc_direct(fb_fixed ? W : 0, 0);
+    auto fixed_add = [&](int pixel, float r, float g, float b) {
+        long long *q = fb_fixed + 3 * (size_t)pixel;
+        const long long v[3] = {to_fixed(r), to_fixed(g), to_fixed(b)};
+        for (int k = 0; k < 3; k++) {
+#pragma omp atomic
+            q[k] += v[k];
+        }
+    };
+    auto fixed_contribute = [&](int s, int pixel, V3 L) {  // one contribution of slot s's current camera ray
+        if (acc_direct[s]) {
+            fixed_add(pixel, L.x, L.y, L.z);
+        } else {
+            acc[s].x += L.x;
+            acc[s].y += L.y;
+            acc[s].z += L.z;
+        }
+    };
+    auto fixed_flush = [&](int s, int pixel) {  // the camera ray of slot s has ended: its sum -> its pixel
+        V3 &a = acc[s];
+        if (a.x != 0.f || a.y != 0.f || a.z != 0.f) {  // (a NaN compares unequal to 0: it is passed on, and dropped by to_fixed)
+            fixed_add(pixel, a.x, a.y, a.z);
+            a = mk(0, 0, 0);
+        }
+    };
     RenderStats st;
     memset(&st, 0, sizeof(st));
     double t0 = now_s();
@@ -965,12 +1005,16 @@ void render_literal(const Scene &sc, const Camera &cam, int width, int height, i
     // (the W states are a function of the seed alone: kept from one render to the next -- a test suite renders dozens
     // of frames with seed 1 and the walk is serial)
     {
+        static std::mutex cache_lock;  // (ctypes releases the GIL: two renders may arrive here together)
         static std::vector<Xorwow> cached;
         static uint64_t cached_seed = 0;
-        if (cached.size() != (size_t)W || cached_seed != seed) {
+        static bool cached_valid = false;
+        std::lock_guard<std::mutex> hold(cache_lock);
+        if (!cached_valid || cached.size() != (size_t)W || cached_seed != seed) {
             cached.resize(W);
             xorwow_init_range(seed, 0, W, cached.data());
             cached_seed = seed;
+            cached_valid = true;
         }
         memcpy(p.rng.data(), cached.data(), sizeof(Xorwow) * (size_t)W);
     }
@@ -999,6 +1043,7 @@ void render_literal(const Scene &sc, const Camera &cam, int width, int height, i
                         px.y += sc.lights[li].L.y;
                         px.z += sc.lights[li].L.z;
                         st.emission_adds++;
+                        if (fb_fixed) fixed_contribute(s, p.pixel_idx[s], sc.lights[li].L);
                     }
                 }
             }
@@ -1123,6 +1168,7 @@ void render_literal(const Scene &sc, const Camera &cam, int width, int height, i
 #pragma omp parallel for num_threads(threads) schedule(static, 4096)
         for (int tid = 0; tid < n_gen; tid++) {
             int cid = cam_start + tid;
+            if (fb_fixed) fixed_flush(p.gen_c[tid], p.pixel_idx[p.gen_c[tid]]);  // the slot's previous camera ray is over
             if (cid >= cam_end) continue;
             int s = p.gen_c[tid];
             if (s < slot_lo || s >= slot_hi) {
@@ -1137,6 +1183,7 @@ void render_literal(const Scene &sc, const Camera &cam, int width, int height, i
             int j = pixel / width;
             Xorwow rs = p.rng[s];
             p.pixel_idx[s] = pixel;
+            if (fb_fixed) acc_direct[s] = (cid / W == last_gen) ? 1 : 0;
             float jx = rnd(rs);  // x first, then y
             float jy = rnd(rs);
             p.ray[s] = camera_get_ray(cam, (i + jx) / width, (j + jy) / height);
@@ -1199,6 +1246,7 @@ void render_literal(const Scene &sc, const Camera &cam, int width, int height, i
                     px.y += p.ah_L[s].y;
                     px.z += p.ah_L[s].z;
                     st.ah_adds++;
+                    if (fb_fixed) fixed_contribute(s, p.pixel_idx[ah_id], p.ah_L[s]);
                 }
         }
         // ---- ch() :297-328
@@ -1253,9 +1301,12 @@ void render_literal(const Scene &sc, const Camera &cam, int width, int height, i
                     px.y += p.ch_L[s].y;
                     px.z += p.ch_L[s].z;
                     st.ch_adds++;
+                    if (fb_fixed) fixed_contribute(s, p.pixel_idx[rid], p.ch_L[s]);
                 }
         }
     }
+    if (fb_fixed)
+        for (int s = 0; s < W; s++) fixed_flush(s, p.pixel_idx[s]);  // (nothing is pending here by construction: a safeguard)
     st.seconds_loop = now_s() - t1;
     st.n_iter_records = nrec;
     st.ch_rays = sc.st_closest.rays;
@@ -1537,6 +1588,11 @@ void orc_raylog_fetch_closest(float *od6, int32_t *tri, float *t) {
     memcpy(t, g_raylog.closest_t.data(), sizeof(float) * g_raylog.closest_t.size());
 }
 
+// The NEXT orc_render call also fills `fb_fixed` (width * height * 3 int64, zeroed by the caller) with the product's
+// fixed-point accumulation of the same frame (see render_literal).  One-shot: cleared by that call.
+static long long *g_fb_fixed_next = nullptr;
+void orc_render_also_fixed(long long *fb_fixed) { g_fb_fixed_next = fb_fixed; }
+
 // literal render.  stats_out: RenderStats as 20 int64/double slots (see oracle.py);
 // iter_counts: iter_cap x 4 int32 (mat, gen, ah, ch)
 void orc_render(orc_scene *h, const float *cam12, int width, int height, int spp, int max_bounces,
@@ -1551,7 +1607,8 @@ void orc_render(orc_scene *h, const float *cam12, int width, int height, int spp
     RenderStats st;
     if (threads < 1) threads = 1;
     render_literal(sc, c, width, height, spp, max_bounces, seed, slot_lo, slot_hi, threads, fb_sum, fb_out, &st,
-                   iter_counts, iter_cap);
+                   iter_counts, iter_cap, g_fb_fixed_next);
+    g_fb_fixed_next = nullptr;
     if (stats_out) {
         double *o = stats_out;
         o[0] = (double)st.iterations;

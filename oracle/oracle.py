@@ -300,13 +300,19 @@ class OracleScene:
         return occ
 
     def render(self, cam12, width, height, spp, max_bounces=10, seed=1, slot_lo=0, slot_hi=1 << 20,
-               threads=1, collect_stats=False, iter_cap=4096):
-        """Literal wavefront render.  Returns (image (h,w,3) post-processed, raw sums (h,w,3), stats)."""
+               threads=1, collect_stats=False, iter_cap=4096, fixed_out=None):
+        """Literal wavefront render.  Returns (image (h,w,3) post-processed, raw sums (h,w,3), stats).
+        ``fixed_out``: a zeroed (h, w, 3) int64 array that also receives the product's fixed-point accumulation of the frame
+        (RT_FLAG_DETERMINISTIC's sums: oracle.cpp render_literal)."""
         cam12 = np.ascontiguousarray(cam12, np.float32)
         fb_sum = np.zeros((height, width, 3), np.float32)
         fb_out = np.zeros((height, width, 3), np.float32)
         st = np.zeros(20, np.float64)
         it = np.zeros((iter_cap, 4), np.int32)
+        if fixed_out is not None:
+            assert fixed_out.dtype == np.int64 and fixed_out.shape == (height, width, 3) and fixed_out.flags["C_CONTIGUOUS"]
+            self.o.lib.orc_render_also_fixed.argtypes = [ctypes.c_void_p]
+            self.o.lib.orc_render_also_fixed(_ptr(fixed_out))
         self.o.lib.orc_render(self.h, _ptr(cam12), width, height, spp, max_bounces, seed, slot_lo, slot_hi,
                               threads, int(collect_stats), _ptr(fb_sum), _ptr(fb_out), _ptr(st), _ptr(it),
                               iter_cap)
@@ -333,3 +339,11 @@ def fnv1a64_words(a: np.ndarray) -> int:
         h ^= w
         h = (h * 0x100000001B3) & 0xFFFFFFFFFFFFFFFF
     return h
+
+
+def sums_hash(fixed: np.ndarray) -> str:
+    """64-bit hash of a frame's int64 fixed-point sums (the first 16 hex digits of SHA-256 over the little-endian bytes, row-major,
+    top row first, RGB interleaved): what tests/golden/full_size_image_hashes.json holds per frame and oracle mode."""
+    import hashlib
+    a = np.ascontiguousarray(fixed, dtype="<i8")
+    return hashlib.sha256(a.tobytes()).hexdigest()[:16]

@@ -27,10 +27,10 @@ FLAG_RNG_PER_SAMPLE = 4  # NOT the reference's random numbers (see include/rtcud
 FLAG_REFERENCE_WALK = 8  # opt-in parity mode: the reference's own tree, box test, order and tie rule (never benchmarked)
 
 EXPORTS = [
-    "rt_scene_create", "rt_scene_destroy", "rt_scene_info", "rt_scene_build_info", "rt_camera_make", "rt_render",
+    "rt_scene_create", "rt_scene_destroy", "rt_scene_info", "rt_scene_build_info", "rt_camera_make", "rt_render", "rt_render_multi",
     "rt_render_shard", "rt_render_shard_fixed", "rt_post_process", "rt_post_process_fixed", "rt_trace_closest", "rt_trace_any",
     "rt_trace_closest_flags", "rt_trace_any_flags", "rt_xorwow_states",
-    "rt_measure_copy_bandwidth", "rt_calibrate_valu", "rt_calibrate_valu_packed", "rt_split_probe", "rt_last_error", "rt_version", "rt_build_id",
+    "rt_measure_copy_bandwidth", "rt_calibrate_valu", "rt_calibrate_valu_packed", "rt_probe_issue", "rt_split_probe", "rt_last_error", "rt_version", "rt_build_id",
 ]
 
 
@@ -112,6 +112,7 @@ def lib():
     L.rt_scene_build_info.argtypes = [vp, ctypes.POINTER(ci), ctypes.POINTER(ctypes.c_double)]
     L.rt_camera_make.argtypes = [vp, vp, vp, cf, cf, vp]
     L.rt_render.argtypes = [vp, vp, ci, ci, ci, ci, ctypes.c_uint64, ctypes.c_uint32, vp, ctypes.POINTER(RtStats)]
+    L.rt_render_multi.argtypes = [vp, vp, ci, ci, ci, ci, ctypes.c_uint64, ctypes.c_uint32, vp, ci, vp, ctypes.POINTER(RtStats)]
     L.rt_render_shard.argtypes = [vp, vp, ci, ci, ci, ci, ctypes.c_uint64, ci, ci, ctypes.c_uint32, vp, vp,
                                   ctypes.POINTER(RtStats)]
     L.rt_post_process.argtypes = [vp, ci, ci, vp]
@@ -125,6 +126,7 @@ def lib():
     L.rt_measure_copy_bandwidth.argtypes = [ctypes.c_int64, ci, ctypes.POINTER(ctypes.c_double)]
     L.rt_calibrate_valu.argtypes = [ci, ci, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
     L.rt_calibrate_valu_packed.argtypes = [ci, ci, ci, ctypes.POINTER(ctypes.c_double)]
+    L.rt_probe_issue.argtypes = [ci, ci, ci, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
     L.rt_split_probe.argtypes = [vp, vp, ci, ci, ci, ci, ctypes.c_uint64, ctypes.c_int64, vp, ci]
     _lib = L
     return L
@@ -199,6 +201,19 @@ class Scene:
         _check(lib().rt_render(self.h, _p(cam), width, height, spp, max_bounces, seed, flags, _p(out),
                                ctypes.byref(st)), "rt_render")
         return out, st.as_dict()
+
+    def render_multi(self, camera: np.ndarray, width: int, height: int, spp: int, devices, max_bounces: int = 10,
+                     seed: int = 1, flags: int = 0):
+        """Whole frame over the listed devices in this one process (rt_render_multi) -> (image, stats)."""
+        cam = np.ascontiguousarray(camera, np.float32)
+        dev = np.ascontiguousarray(devices, np.int32)
+        out = np.zeros((height, width, 3), np.float32)
+        st = RtStats()
+        _check(lib().rt_render_multi(self.h, _p(cam), width, height, spp, max_bounces, seed, flags, _p(dev), int(dev.shape[0]),
+                                     _p(out), ctypes.byref(st)), "rt_render_multi")
+        d = st.as_dict()
+        d["device_shards"] = int(st.reserved[3])
+        return out, d
 
     def render_shard(self, camera: np.ndarray, width: int, height: int, spp: int, shard_index: int,
                      shard_count: int, d_sum_ptr: int, max_bounces: int = 10, seed: int = 1, flags: int = 0,
@@ -289,6 +304,20 @@ def calibrate_valu_packed(waves_per_simd: int = 4, iters: int = 20000, kind: int
     rate = ctypes.c_double(0.0)
     _check(lib().rt_calibrate_valu_packed(waves_per_simd, iters, kind, ctypes.byref(rate)), "rt_calibrate_valu_packed")
     return rate.value
+
+
+PROBE_ISSUE_KINDS = ["v_fma_f32", "v_fmac_f32", "v_mul_f32", "v_add_f32", "v_mov_b32", "v_xor_b32", "v_lshlrev_b32", "v_max_f32",
+                     "v_rcp_f32", "v_sqrt_f32", "v_cndmask_b32", "v_mul_f32 -> v_add_f32 (dependent pair)", "v_fma_f32, one dependent chain",
+                     "v_mul_f32, one dependent chain", "v_mul_f32 literal", "v_mul_f32 sgpr", "v_fma_f32 2 sgprs",
+                     "v_cndmask_b32 sgpr-pair mask", "v_cmp_lt_f32 -> vcc", "v_cmp_lt_f32 -> v_cndmask_b32 (dependent pair)", "v_bfi_b32",
+                     "v_and_b32", "mix 3 v_mul + 1 v_cndmask", "mix 3 v_mul + 1 v_max", "mix 4 v_mul", "mix 3 v_mul + 1 v_mov"]
+
+
+def probe_issue(kind: int, waves_per_simd: int, iters: int = 20000):
+    """(seconds of the best launch, instructions every wave issued) of the issue probe (rt_probe_issue)."""
+    sec, n = ctypes.c_double(0.0), ctypes.c_double(0.0)
+    _check(lib().rt_probe_issue(kind, waves_per_simd, iters, ctypes.byref(sec), ctypes.byref(n)), "rt_probe_issue")
+    return sec.value, n.value
 
 
 # rt_split_probe's out[] layout (the RT_PROBE_* enum of include/rtcuda_amd.h)

@@ -1634,7 +1634,11 @@ k_paths(DScene sc, DPools p, Camera cam_arg, AdvanceParams ap_arg, float *__rest
                     if (cid_next == cid_end) {
                         unsigned base = 0;
                         if (lane_id() == 0) base = atomicAdd(next_cid, (unsigned)kCidChunk);
-                        cid_next = (int)min(__builtin_amdgcn_readfirstlane(base), 0x7fffff00u);  // (past the frame's end: "none left")
+                        // (past the frame's end: "none left".  The clamp leaves room for cid_end = cid_next + kCidChunk below
+                        // INT_MAX; ids that large are never rendered anyway: render_shard_impl refuses frames whose camera-ray
+                        // ids come within 13 W of 2^31, and a wave overshoots the frame's end by at most one chunk)
+                        static_assert(0x7ffff000u + (unsigned)kCidChunk < 0x7fffffffu, "cid_end must not overflow int");
+                        cid_next = (int)min(__builtin_amdgcn_readfirstlane(base), 0x7ffff000u);
                         cid_end = cid_next + kCidChunk;
                     }
                     const int take = min(need - served, cid_end - cid_next);
@@ -1844,7 +1848,7 @@ k_paths(DScene sc, DPools p, Camera cam_arg, AdvanceParams ap_arg, float *__rest
                 // the wave ~30 register moves per test); the only branches left are the rare ones (a tie between two hits;
                 // a pop from the overflow column).
                 int pd = pend, cu = cur;
-                int ks[kTriPerStep];
+                int ks[kTriPerStep] = {};  // (0 = a valid triangle address for lanes that have nothing to fetch)
                 bool act[kTriPerStep];
                 Tri tr[kTriPerStep];
 #pragma unroll
@@ -1963,6 +1967,16 @@ __global__ void k_post_process_fixed(const long long *__restrict__ sums, float *
     if (i < n_values) out[i] = sqrtf((float)((double)sums[i] * (1.0 / 1073741824.0)) * inv_spp);
 }
 
+// rt_render_multi: dst += src over the raw sums of two shards (fp32 sums, or the int64 fixed-point sums of RT_FLAG_DETERMINISTIC)
+__global__ void k_accumulate_f32(float *__restrict__ dst, const float *__restrict__ src, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] += src[i];
+}
+__global__ void k_accumulate_i64(long long *__restrict__ dst, const long long *__restrict__ src, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] += src[i];
+}
+
 // ---- stage-level test kernels
 __global__ void k_test_draw(DPools p, int n, int draws, uint32_t *__restrict__ state6, float *__restrict__ uni) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2032,6 +2046,85 @@ __global__ void __launch_bounds__(256) k_valu_calibrate_pk(float *__restrict__ o
 #pragma unroll
     for (int k = 1; k < 16; k++) r = r + a[k];
     if (r.x + r.y == 12345.678f) out[blockIdx.x * blockDim.x + threadIdx.x] = r.x;  // (never true: keeps the chains alive)
+}
+
+// Issue probe (rt_probe_issue): the calibration stream with OTHER instructions -- how long one wave needs per instruction
+// of a given kind, alone on its SIMD and beside 1 / 3 / 7 other waves.  A block of k_paths takes the same time whether its
+// SIMD holds one wave or four, i.e. the kernel is bound by what ONE wave can issue, and that depends on
+// the instruction: this probe is how it was measured.  16 independent chains per lane unless the kind says "chain".
+#define RT_P16(L) L(0) L(1) L(2) L(3) L(4) L(5) L(6) L(7) L(8) L(9) L(10) L(11) L(12) L(13) L(14) L(15)
+#define RT_PL_FMA(k) "v_fma_f32 %" #k ", %" #k ", %16, %17\n"
+#define RT_PL_FMAC(k) "v_fmac_f32 %" #k ", %16, %17\n"
+#define RT_PL_MUL(k) "v_mul_f32 %" #k ", %16, %" #k "\n"
+#define RT_PL_ADD(k) "v_add_f32 %" #k ", %17, %" #k "\n"
+#define RT_PL_MOV(k) "v_mov_b32 %" #k ", %16\n"
+#define RT_PL_XOR(k) "v_xor_b32 %" #k ", %16, %" #k "\n"
+#define RT_PL_SHL(k) "v_lshlrev_b32 %" #k ", 1, %" #k "\n"
+#define RT_PL_MAX(k) "v_max_f32 %" #k ", %16, %" #k "\n"
+#define RT_PL_RCP(k) "v_rcp_f32 %" #k ", %" #k "\n"
+#define RT_PL_SQRT(k) "v_sqrt_f32 %" #k ", %" #k "\n"
+#define RT_PL_CND(k) "v_cndmask_b32 %" #k ", %" #k ", %16, vcc\n"
+#define RT_PL_MULADD(k) "v_mul_f32 %" #k ", %16, %" #k "\n v_add_f32 %" #k ", %17, %" #k "\n"
+#define RT_PL_CHAIN_FMA(k) "v_fma_f32 %0, %0, %16, %17\n"
+#define RT_PL_CHAIN_MUL(k) "v_mul_f32 %0, %16, %0\n"
+#define RT_PL_MUL_LIT(k) "v_mul_f32 %" #k ", 0x3f7fbe77, %" #k "\n"
+#define RT_PL_MUL_SGPR(k) "v_mul_f32 %" #k ", %18, %" #k "\n"
+#define RT_PL_FMA_SGPR(k) "v_fma_f32 %" #k ", %" #k ", %18, %19\n"
+#define RT_PL_CND_SGPR(k) "v_cndmask_b32_e64 %" #k ", %" #k ", %16, %20\n"
+#define RT_PL_CMP(k) "v_cmp_lt_f32_e32 vcc, %16, %" #k "\n"
+#define RT_PL_CMP_CND(k) "v_cmp_lt_f32_e32 vcc, %17, %" #k "\n v_cndmask_b32_e32 %" #k ", %" #k ", %16, vcc\n"
+#define RT_PL_BFI(k) "v_bfi_b32 %" #k ", %16, %17, %" #k "\n"
+#define RT_PL_AND(k) "v_and_b32_e32 %" #k ", %16, %" #k "\n"
+#define RT_PL_MIX_CND(k) "v_mul_f32_e32 %" #k ", %16, %" #k "\n v_mul_f32_e32 %" #k ", %16, %" #k "\n v_mul_f32_e32 %" #k ", %16, %" #k "\n v_cndmask_b32_e32 %" #k ", %" #k ", %17, vcc\n"
+#define RT_PL_MIX_MAX(k) "v_mul_f32_e32 %" #k ", %16, %" #k "\n v_mul_f32_e32 %" #k ", %16, %" #k "\n v_mul_f32_e32 %" #k ", %16, %" #k "\n v_max_f32_e32 %" #k ", %17, %" #k "\n"
+#define RT_PL_MIX_MUL(k) "v_mul_f32_e32 %" #k ", %16, %" #k "\n v_mul_f32_e32 %" #k ", %16, %" #k "\n v_mul_f32_e32 %" #k ", %16, %" #k "\n v_mul_f32_e32 %" #k ", %17, %" #k "\n"
+#define RT_PL_MIX_MOV(k) "v_mul_f32_e32 %" #k ", %16, %" #k "\n v_mul_f32_e32 %" #k ", %16, %" #k "\n v_mul_f32_e32 %" #k ", %16, %" #k "\n v_mov_b32_e32 %" #k ", %" #k "\n"
+enum { kProbeKinds = 26 };
+template <int KIND>
+__global__ void __launch_bounds__(256) k_probe_issue(float *__restrict__ out, int iters, float seed) {
+    float a0 = seed, a1 = seed + 1.f, a2 = seed + 2.f, a3 = seed + 3.f, a4 = seed + 4.f, a5 = seed + 5.f, a6 = seed + 6.f,
+          a7 = seed + 7.f, a8 = seed + 8.f, a9 = seed + 9.f, a10 = seed + 10.f, a11 = seed + 11.f, a12 = seed + 12.f,
+          a13 = seed + 13.f, a14 = seed + 14.f, a15 = seed + 15.f;
+    const float m = 0.999f + seed * 1e-9f, c = 1e-3f;
+    const float sm = __builtin_amdgcn_readfirstlane(m), sc = __builtin_amdgcn_readfirstlane(c);
+    const unsigned long long lane_mask = __builtin_amdgcn_ballot_w64(seed + (float)(threadIdx.x & 1) > 1.5f);  // (an SGPR pair)
+#define RT_PROBE_ASM(L)                                                                                                   \
+    __asm__ volatile(RT_P16(L)                                                                                            \
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(a8), "+v"(a9),     \
+                       "+v"(a10), "+v"(a11), "+v"(a12), "+v"(a13), "+v"(a14), "+v"(a15)                                       \
+                     : "v"(m), "v"(c), "s"(sm), "s"(sc), "s"(lane_mask)                                                          \
+                     : "vcc")
+    for (int k = 0; k < iters; k++) {
+        if (KIND == 0) RT_PROBE_ASM(RT_PL_FMA);
+        else if (KIND == 1) RT_PROBE_ASM(RT_PL_FMAC);
+        else if (KIND == 2) RT_PROBE_ASM(RT_PL_MUL);
+        else if (KIND == 3) RT_PROBE_ASM(RT_PL_ADD);
+        else if (KIND == 4) RT_PROBE_ASM(RT_PL_MOV);
+        else if (KIND == 5) RT_PROBE_ASM(RT_PL_XOR);
+        else if (KIND == 6) RT_PROBE_ASM(RT_PL_SHL);
+        else if (KIND == 7) RT_PROBE_ASM(RT_PL_MAX);
+        else if (KIND == 8) RT_PROBE_ASM(RT_PL_RCP);
+        else if (KIND == 9) RT_PROBE_ASM(RT_PL_SQRT);
+        else if (KIND == 10) RT_PROBE_ASM(RT_PL_CND);
+        else if (KIND == 11) RT_PROBE_ASM(RT_PL_MULADD);
+        else if (KIND == 12) RT_PROBE_ASM(RT_PL_CHAIN_FMA);
+        else if (KIND == 13) RT_PROBE_ASM(RT_PL_CHAIN_MUL);
+        else if (KIND == 14) RT_PROBE_ASM(RT_PL_MUL_LIT);
+        else if (KIND == 15) RT_PROBE_ASM(RT_PL_MUL_SGPR);
+        else if (KIND == 16) RT_PROBE_ASM(RT_PL_FMA_SGPR);
+        else if (KIND == 17) RT_PROBE_ASM(RT_PL_CND_SGPR);
+        else if (KIND == 18) RT_PROBE_ASM(RT_PL_CMP);
+        else if (KIND == 19) RT_PROBE_ASM(RT_PL_CMP_CND);
+        else if (KIND == 20) RT_PROBE_ASM(RT_PL_BFI);
+        else if (KIND == 21) RT_PROBE_ASM(RT_PL_AND);
+        else if (KIND == 22) RT_PROBE_ASM(RT_PL_MIX_CND);
+        else if (KIND == 23) RT_PROBE_ASM(RT_PL_MIX_MAX);
+        else if (KIND == 24) RT_PROBE_ASM(RT_PL_MIX_MUL);
+        else RT_PROBE_ASM(RT_PL_MIX_MOV);
+    }
+#undef RT_PROBE_ASM
+    float r = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7)) + ((a8 + a9) + (a10 + a11)) + ((a12 + a13) + (a14 + a15));
+    if (r == 12345.678f) out[blockIdx.x * blockDim.x + threadIdx.x] = r;  // (never true: keeps the chains alive)
 }
 
 // ============================================================================ split probe (rt_split_probe)
@@ -2351,6 +2444,12 @@ struct rt_scene {
     // RT_FLAG_REFERENCE_WALK: the reference's own tree (rt_ref_tree.h), built and uploaded by the first render that asks
     // for it (ensure_ref_tree) from the caller's triangles kept here
     std::vector<float> h_tri9;
+    // rt_render_multi: what a replica of this scene on another device is created from, and the replicas made so far
+    std::vector<int32_t> h_tri_material, h_tri_light;
+    std::vector<rt_material> h_materials;
+    std::vector<rt_light> h_lights;
+    mutable std::mutex replica_mutex;
+    mutable std::vector<rt_scene *> replicas;  // owned; at most one per device
     mutable std::mutex ref_mutex;
     mutable bool ref_ready = false;
     mutable float4 *d_ref_nodes = nullptr;
@@ -2360,6 +2459,7 @@ struct rt_scene {
     rt_scene(const rt_scene &) = delete;
     rt_scene &operator=(const rt_scene &) = delete;
     ~rt_scene() {  // (every early return of rt_scene_create goes through here: nothing leaks on an error path)
+        for (rt_scene *r : replicas) delete r;
         (void)hipFree(d_nodes);
         (void)hipFree(d_tris);
         (void)hipFree(d_tri_info);
@@ -3393,6 +3493,10 @@ int rt_scene_create(const float *tri_p0p1p2, int n_tris, const int32_t *tri_mate
         return fail("rt_scene_create: the 4-wide BVH is malformed (structure, or an absent child without its +inf box)");
     sc->n_tris = n_tris;
     if (n_tris > 0) sc->h_tri9.assign(tri_p0p1p2, tri_p0p1p2 + 9 * (size_t)n_tris);  // (RT_FLAG_REFERENCE_WALK builds its tree from these)
+    if (n_tris > 0) sc->h_tri_material.assign(tri_material, tri_material + n_tris);
+    if (n_tris > 0 && tri_light) sc->h_tri_light.assign(tri_light, tri_light + n_tris);
+    if (n_materials > 0) sc->h_materials.assign(materials, materials + n_materials);
+    if (n_lights > 0) sc->h_lights.assign(lights, lights + n_lights);
     sc->wide = true;  // 4-wide nodes (two pair-style records each): half the dependent fetches per ray; RT_BVH_WIDE=0: 2-wide
     if (const char *e = getenv("RT_BVH_WIDE")) sc->wide = atoi(e) != 0;
     // a tree too deep for the 4-wide walk's stack (up to 3 entries per level) may still fit the 2-wide walk's (1 per level):
@@ -3618,6 +3722,150 @@ int rt_render(const rt_scene *scene, const rt_camera *camera, int width, int hei
     return rc;
 }
 
+// The scene as it exists on `device`: the scene itself, or a replica created there from the host copies (once per device).
+static const rt_scene *scene_on_device(const rt_scene *scene, int device) {
+    if (scene->device == device) return scene;
+    std::lock_guard<std::mutex> lock(scene->replica_mutex);
+    for (const rt_scene *r : scene->replicas)
+        if (r->device == device) return r;
+    int saved = 0;
+    if (hipGetDevice(&saved) != hipSuccess || hipSetDevice(device) != hipSuccess) {
+        fail("rt_render_multi: cannot select device " + std::to_string(device));
+        return nullptr;
+    }
+    rt_scene *rep = nullptr;
+    const int rc = rt_scene_create(scene->h_tri9.data(), scene->n_tris, scene->h_tri_material.data(),
+                                   scene->h_tri_light.empty() ? nullptr : scene->h_tri_light.data(), scene->h_materials.data(),
+                                   scene->n_mats, scene->h_lights.data(), scene->n_lights, &rep);
+    (void)hipSetDevice(saved);
+    if (rc != 0) return nullptr;
+    scene->replicas.push_back(rep);
+    return rep;
+}
+
+int rt_render_multi(const rt_scene *scene, const rt_camera *camera, int width, int height, int num_samples,
+                    int max_bounces, uint64_t seed, uint32_t flags, const int *devices, int n_devices, float *out_rgb,
+                    rt_stats *stats) {
+    if (!scene || !camera || !out_rgb) return fail("rt_render_multi: null argument");
+    if (!devices || n_devices < 1) return fail("rt_render_multi: empty device list");
+    if (width <= 0 || height <= 0) return fail("rt_render_multi: bad dimensions");
+    if ((long long)width * height > (long long)(0x7fffffff / 3)) return fail("rt_render_multi: width*height exceeds 715827882 pixels");
+    if (kW % n_devices != 0) return fail("rt_render_multi: the number of devices must divide 1048576 (1, 2, 4, 8, ...)");
+    int n_visible = 0;
+    HIP_TRY(hipGetDeviceCount(&n_visible));
+    for (int k = 0; k < n_devices; k++)
+        if (devices[k] < 0 || devices[k] >= n_visible)
+            return fail("rt_render_multi: devices[" + std::to_string(k) + "] = " + std::to_string(devices[k]) + " but " +
+                        std::to_string(n_visible) + " device(s) are visible");
+    const bool fixed = (flags & RT_FLAG_DETERMINISTIC) != 0;
+    const uint32_t shard_flags = (flags & ~kFlagFixedFb) | (fixed ? kFlagFixedFb : 0u);
+    const size_t n_values = 3 * (size_t)width * height;
+    const size_t sum_bytes = n_values * (fixed ? sizeof(long long) : sizeof(float));
+    int caller_device = 0;
+    HIP_TRY(hipGetDevice(&caller_device));
+    // every device's copy of the scene, before any thread starts (replicas are created under the scene's lock)
+    std::vector<const rt_scene *> on_dev(n_devices, nullptr);
+    for (int k = 0; k < n_devices; k++) {
+        on_dev[k] = scene_on_device(scene, devices[k]);
+        if (!on_dev[k]) return 1;
+    }
+    struct Buffers {  // everything released on every return path, each pointer on the device it was allocated on
+        std::vector<void *> ptr;
+        std::vector<int> dev;
+        int home = 0;
+        ~Buffers() {
+            for (size_t k = 0; k < ptr.size(); k++) {
+                (void)hipSetDevice(dev[k]);
+                (void)hipFree(ptr[k]);
+            }
+            (void)hipSetDevice(home);
+        }
+        void *alloc(int device, size_t bytes) {
+            void *q = nullptr;
+            if (hipSetDevice(device) != hipSuccess || hipMalloc(&q, bytes) != hipSuccess) return nullptr;
+            ptr.push_back(q);
+            dev.push_back(device);
+            return q;
+        }
+    } buf;
+    buf.home = caller_device;
+    const int dev0 = devices[0];
+    // shard k renders into its own raw-sum buffer on ITS device; shards 1.. land in a staging buffer on devices[0]
+    std::vector<void *> d_sum(n_devices, nullptr), d_stage(n_devices, nullptr);
+    for (int k = 0; k < n_devices; k++) {
+        d_sum[k] = buf.alloc(devices[k], sum_bytes);
+        if (!d_sum[k]) return fail("rt_render_multi: out of device memory on device " + std::to_string(devices[k]));
+        if (k > 0) {
+            d_stage[k] = devices[k] == dev0 ? d_sum[k] : buf.alloc(dev0, sum_bytes);  // (same device: the buffer is its own staging)
+            if (!d_stage[k]) return fail("rt_render_multi: out of device memory on device " + std::to_string(dev0));
+        }
+    }
+    float *d_out = fixed ? (float *)buf.alloc(dev0, n_values * sizeof(float)) : (float *)d_sum[0];
+    if (!d_out) return fail("rt_render_multi: out of device memory");
+    // ---- one host thread per device (render.cuh's render() is one thread on one device: this is the multi-device form of
+    // the same call): select the device, zero the shard's sums, render slot shard k of n, hand the sums to devices[0]
+    std::vector<rt_stats> sub(n_devices);
+    std::vector<int> rc(n_devices, 0);
+    std::vector<std::string> err(n_devices);
+    std::vector<std::thread> th;
+    for (int k = 0; k < n_devices; k++)
+        th.emplace_back([&, k] {
+            auto bail = [&](const char *what) { rc[k] = 1; err[k] = std::string("rt_render_multi: ") + what + " (device " + std::to_string(devices[k]) + ")"; };
+            if (hipSetDevice(devices[k]) != hipSuccess) return bail("hipSetDevice failed");
+            hipStream_t st;
+            if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return bail("stream create failed");
+            if (hipMemsetAsync(d_sum[k], 0, sum_bytes, st) != hipSuccess) {
+                bail("memset failed");
+            } else {
+                rc[k] = render_shard_impl(on_dev[k], camera, width, height, num_samples, max_bounces, seed, k, n_devices, shard_flags,
+                                          (float *)d_sum[k], st, &sub[k], /* a context of its own per shard: */ 8 + k);
+                if (rc[k]) err[k] = g_last_error;
+                else if (k > 0 && d_stage[k] != d_sum[k] &&
+                         hipMemcpyPeerAsync(d_stage[k], dev0, d_sum[k], devices[k], sum_bytes, st) != hipSuccess)
+                    bail("peer copy of the shard's sums failed");
+            }
+            if (hipStreamSynchronize(st) != hipSuccess && rc[k] == 0) bail("stream synchronise failed");
+            (void)hipStreamDestroy(st);
+        });
+    for (auto &t : th) t.join();
+    for (int k = 0; k < n_devices; k++)
+        if (rc[k]) return fail(err[k]);
+    // ---- on devices[0]: add the shards' sums in shard order (a fixed order: the result does not depend on which device
+    // finished first), post-process (render.cuh:330-338), copy out
+    HIP_TRY(hipSetDevice(dev0));
+    const int nv = (int)n_values;
+    for (int k = 1; k < n_devices; k++) {
+        if (fixed) hipLaunchKernelGGL(k_accumulate_i64, dim3((nv + 255) / 256), dim3(256), 0, nullptr, (long long *)d_sum[0], (const long long *)d_stage[k], nv);
+        else hipLaunchKernelGGL(k_accumulate_f32, dim3((nv + 255) / 256), dim3(256), 0, nullptr, (float *)d_sum[0], (const float *)d_stage[k], nv);
+    }
+    HIP_TRY(hipGetLastError());
+    int prc = fixed ? rt_post_process_fixed((const int64_t *)d_sum[0], d_out, width * height, num_samples, nullptr)
+                    : rt_post_process(d_out, width * height, num_samples, nullptr);
+    if (prc) return prc;
+    HIP_TRY(hipMemcpy(out_rgb, d_out, n_values * sizeof(float), hipMemcpyDeviceToHost));
+    if (stats) {
+        rt_stats tot = sub[0];
+        for (int k = 1; k < n_devices; k++) {
+            tot.camera_rays += sub[k].camera_rays;
+            tot.shade_events += sub[k].shade_events;
+            tot.closest_rays += sub[k].closest_rays;
+            tot.any_rays += sub[k].any_rays;
+            tot.emission_adds += sub[k].emission_adds;
+            tot.shadow_adds += sub[k].shadow_adds;
+            tot.rr_draws += sub[k].rr_draws;
+            tot.iterations = std::max(tot.iterations, sub[k].iterations);
+            tot.launches_trace += sub[k].launches_trace;
+            tot.seconds_trace = std::max(tot.seconds_trace, sub[k].seconds_trace);
+            tot.seconds_advance = std::max(tot.seconds_advance, sub[k].seconds_advance);
+            tot.seconds_render = std::max(tot.seconds_render, sub[k].seconds_render);  // the devices render side by side
+            tot.seconds_rng_init = std::max(tot.seconds_rng_init, sub[k].seconds_rng_init);
+        }
+        tot.reserved[3] = n_devices;
+        *stats = tot;
+    }
+    return 0;
+}
+
 int rt_trace_closest(const rt_scene *scene, int n, const float *origin_xyz, const float *dir_xyz, const float *tmax,
                      int32_t *hit_tri, float *t, float *u, float *v) {
     return rt_trace_closest_flags(scene, 0u, n, origin_xyz, dir_xyz, tmax, hit_tri, t, u, v);
@@ -3823,6 +4071,41 @@ int rt_calibrate_valu_packed(int waves_per_simd, int iters, int kind, double *ou
     }
     HIP_TRY(hipGetLastError());
     *out_lane_ops_per_s = best;
+    return 0;
+}
+
+int rt_probe_issue(int kind, int waves_per_simd, int iters, double *out_seconds, double *out_wave_instr_per_wave) {
+    if (kind < 0 || kind >= kProbeKinds || waves_per_simd < 1 || waves_per_simd > 8 || iters < 1 || !out_seconds)
+        return fail("rt_probe_issue: bad argument");
+    int dev = 0, cus = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    const int blocks = cus * waves_per_simd;
+    float *d_out = nullptr;
+    DevScope tmp;
+    if (tmp.alloc(d_out, (size_t)blocks * 256)) return 1;
+    HIP_TRY(hipEventCreate(&tmp.e0));
+    HIP_TRY(hipEventCreate(&tmp.e1));
+    double best = 1e30;
+    for (int r = 0; r < 5; r++) {  // (first launch untimed; the best of four)
+        HIP_TRY(hipEventRecord(tmp.e0, nullptr));
+        switch (kind) {
+#define RT_CASE(K) case K: hipLaunchKernelGGL(k_probe_issue<K>, dim3(blocks), dim3(256), 0, nullptr, d_out, iters, 1.f); break;
+            RT_CASE(0) RT_CASE(1) RT_CASE(2) RT_CASE(3) RT_CASE(4) RT_CASE(5) RT_CASE(6) RT_CASE(7) RT_CASE(8) RT_CASE(9)
+            RT_CASE(10) RT_CASE(11) RT_CASE(12) RT_CASE(13) RT_CASE(14) RT_CASE(15) RT_CASE(16) RT_CASE(17) RT_CASE(18) RT_CASE(19)
+            RT_CASE(20) RT_CASE(21) RT_CASE(22) RT_CASE(23) RT_CASE(24) RT_CASE(25)
+#undef RT_CASE
+        }
+        HIP_TRY(hipEventRecord(tmp.e1, nullptr));
+        HIP_TRY(hipEventSynchronize(tmp.e1));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, tmp.e0, tmp.e1));
+        if (r > 0 && ms > 0.f) best = std::min(best, (double)ms * 1e-3);
+    }
+    HIP_TRY(hipGetLastError());
+    *out_seconds = best;
+    if (out_wave_instr_per_wave)
+        *out_wave_instr_per_wave = (kind >= 22 ? 64.0 : (kind == 11 || kind == 19) ? 32.0 : 16.0) * (double)iters;
     return 0;
 }
 

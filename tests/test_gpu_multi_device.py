@@ -1,0 +1,108 @@
+"""rt_render_multi -- several GPUs of one node behind ONE call in ONE process (C-ABI, C++ render() overload).  -m gpu.
+
+No reference counterpart: render() (render.cuh:366-367, called once from main.cu:173) drives one device from one thread.
+The path is: scene replicated per device, one host thread per device, slot-range shards (the partition the N-process path
+uses: rtcuda_amd/dist.py), the shards' raw sums copied to devices[0] and added in shard order, post-process there.
+A device may be listed more than once -- its shards then run side by side on it -- which is what a one-GPU box can test:
+every line of the path except the peer copy between two different devices runs here.
+
+Bar: in RT_FLAG_DETERMINISTIC arithmetic the image is BIT-EQUAL to rt_render's whatever the device list; event totals equal;
+in the default (float atomics) arithmetic RMS < 2e-6.
+"""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+KEYS = ("camera_rays", "shade_events", "closest_rays", "any_rays", "emission_adds", "shadow_adds", "rr_draws")
+
+
+@pytest.fixture(scope="module")
+def api():
+    from rtcuda_amd import api as _api
+    _api.lib()
+    return _api
+
+
+@pytest.fixture(scope="module")
+def gpu_full(api):
+    from rtcuda_amd import scenes
+    sc = api.Scene(scenes.cornell_bunny("full_bsdf"))
+    yield sc
+    sc.close()
+
+
+@pytest.mark.parametrize("devices", [[0], [0, 0], [0, 0, 0, 0], [0] * 8])
+def test_multi_device_render_is_bit_equal_to_the_single_device_render(api, gpu_full, devices):
+    """3.96 generations of the full-BSDF scene.  [0] * 8 launches the small-shard build of k_paths eight times side by side."""
+    w, h, spp = 480, 270, 32
+    cam = api.make_camera(aspect=w / h)
+    ref, st_ref = gpu_full.render(cam, w, h, spp, flags=api.FLAG_DETERMINISTIC)
+    img, st = gpu_full.render_multi(cam, w, h, spp, devices, flags=api.FLAG_DETERMINISTIC)
+    assert st["device_shards"] == len(devices)
+    for k in KEYS:
+        assert st[k] == st_ref[k], k
+    assert st["camera_rays"] == w * h * spp
+    assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))
+    # default arithmetic (float atomics per shard, float adds in shard order on devices[0])
+    img_f, st_f = gpu_full.render_multi(cam, w, h, spp, devices)
+    ref_f, _ = gpu_full.render(cam, w, h, spp)
+    assert all(st_f[k] == st_ref[k] for k in KEYS)
+    nan = np.isnan(ref_f)
+    assert np.array_equal(np.isnan(img_f), nan)
+    d = np.where(nan, 0.0, img_f.astype(np.float64) - np.where(nan, 0.0, ref_f))
+    assert np.sqrt(np.mean(d ** 2)) < 2e-6
+
+
+def test_multi_device_render_in_the_other_modes(api, gpu_full):
+    """RT_FLAG_REFERENCE_WALK (each replica... here: the one scene builds the reference's tree once) and RT_FLAG_RNG_PER_SAMPLE
+    (every shard renders ALL slots at spp / n) through the same entry point, each bit-equal to its single-device render."""
+    w, h, spp = 300, 200, 48
+    cam = api.make_camera(aspect=w / h)
+    for extra in (api.FLAG_REFERENCE_WALK, api.FLAG_RNG_PER_SAMPLE):
+        F = api.FLAG_DETERMINISTIC | extra
+        ref, st_ref = gpu_full.render(cam, w, h, spp, flags=F)
+        img, st = gpu_full.render_multi(cam, w, h, spp, [0, 0, 0, 0], flags=F)
+        assert all(st[k] == st_ref[k] for k in KEYS), extra
+        assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), extra
+
+
+def test_multi_device_render_rejects_bad_device_lists(api, gpu_full):
+    cam = api.make_camera(aspect=1.0)
+    for bad in ([0, 0, 0], [99], [-1], []):
+        with pytest.raises(api.RtError):
+            gpu_full.render_multi(cam, 32, 32, 4, bad)
+    with pytest.raises(api.RtError):  # per-sample streams split the SAMPLES over the shards
+        gpu_full.render_multi(cam, 32, 32, 5, [0, 0], flags=api.FLAG_RNG_PER_SAMPLE)
+    img, st = gpu_full.render_multi(cam, 32, 32, 4, [0, 0])  # ... and the scene is still usable
+    assert st["camera_rays"] == 32 * 32 * 4 and np.isfinite(img).all()
+
+
+def test_cpp_driver_reaches_several_devices_through_render(api, tmp_path):
+    """examples/cornell_bunny --devices 0,0 (the render() overload with a device list) and RTCUDA_DEVICES=0,0 (the
+    reference's unchanged seven-argument call, main.cu:173) write the PPM of the single-device run."""
+    exe = os.path.join(ROOT, "examples", "cornell_bunny")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "rtcuda_amd", "csrc"), "example"])
+    w, h, spp = 96, 96, 12  # (one generation: 110 592 camera rays)
+    ply = os.path.join(ROOT, "data", "bun_zipper.ply")
+
+    def run(name, pre=(), env=None):
+        out = tmp_path / name
+        log = subprocess.run([exe, *pre, str(w), str(h), str(spp), ply, str(out), "full_bsdf"], cwd=ROOT, check=True,
+                             capture_output=True, text=True, env=env).stdout
+        tok = out.read_text().split()
+        assert tok[:4] == ["P3", str(w), str(h), "255"]
+        return np.array(tok[4:], np.int64).reshape(h, w, 3), log
+    one, _ = run("one.ppm")
+    two, log2 = run("two.ppm", pre=("--devices", "0,0"))
+    assert "rendered as 2 device shard(s)" in log2
+    env = dict(os.environ, RTCUDA_DEVICES="0,0,0,0")
+    four, _ = run("four.ppm", env=env)
+    for got in (two, four):  # identical contributions; the order of the float adds may flip a quantisation boundary
+        assert (got != one).mean() < 1e-3 and np.abs(got - one).max() <= 1

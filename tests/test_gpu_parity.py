@@ -159,7 +159,8 @@ def _rms(a, b):
     return np.sqrt(np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2, axis=(0, 1)))
 
 
-@pytest.mark.parametrize("w,h,spp", [(64, 36, 8), (64, 64, 4), (32, 32, 16)])
+# (256 x 256 x 4: BASELINE config 1's exact workload -- "bun_zipper.ply, 256x256, 4 spp, diffuse-only" -- on the HIP path)
+@pytest.mark.parametrize("w,h,spp", [(64, 36, 8), (64, 64, 4), (32, 32, 16), (256, 256, 4)])
 def test_render_matches_oracle_matte(api, oracle, gpu_matte, cpu_matte, w, h, spp):
     cam = default_camera(oracle, w / h)
     img_c, sum_c, st_c = cpu_matte.render(cam, w, h, spp, threads=8)

@@ -120,6 +120,25 @@ def test_image_goldens_matte(oracle_libm, bunny_matte, rec):
     assert np.isfinite(img).all()
 
 
+@pytest.mark.xfail(strict=False, reason="SURVEY Appendix C's FNV-1a-64 image hashes are not reproduced: the survey session's hash "
+                                        "definition (or its libm) cannot be recovered offline; counts and mean RGB do match")
+@pytest.mark.parametrize("rec", [r for r in APPX["images_matte"] if r["w"] * r["h"] <= 4096],
+                         ids=lambda r: f"{r['w']}x{r['h']}x{r['spp']}")
+def test_appendix_c_image_hashes(oracle_libm, bunny_matte, rec):
+    """The image hashes of SURVEY Appendix C ("FNV-1a-64 over the fp32 words", libm-dependent) are the one family of
+    known answers the oracle does NOT reproduce.  Tried: the libm flavour with one thread -- whose
+    deposits are applied in exactly the serial launch order of the survey's shim (init() emission in slot order, then ah()
+    and ch() in compacted queue order: render.cuh:98-103,291-293,321-326) -- hashed as bytes, as 32-bit words, big-endian,
+    FNV-1 and FNV-1a, over the post-processed image and over the raw sums, rows flipped, as doubles.  The same renders DO
+    reproduce Appendix C's iteration tables, event totals and mean RGB to all nine printed digits (test_image_goldens_matte),
+    so what differs is the hash definition or ulp-level libm output of the survey's session, neither recoverable here.
+    This test keeps the comparison visible: it is an expected failure, and an XPASS would mean the definition was found."""
+    from oracle.oracle import fnv1a64_words
+    w, h = rec["w"], rec["h"]
+    img, _, _ = oracle_libm.scene(bunny_matte).render(default_camera(oracle_libm, w / h), w, h, rec["spp"], threads=1)
+    assert "%016x" % fnv1a64_words(img) == rec["fnv_recorded_by_survey"]
+
+
 @pytest.mark.parametrize("variant", ["full_bsdf", "four_bunnies", "sixteen_lights"])
 def test_image_goldens_variants(oracle_libm, variant):
     from rtcuda_amd import scenes

@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/$TAG/$SCENE
 rm -rf $O && mkdir -p $O
 python3 -c "from rtcuda_amd import api; print(api.build_id())" > $O/build_id.txt   # the build these counters belong to
-B="bench.py --scene $SCENE --spp $SPP --no-cpu-baseline $*"
+B="bench.py --scene $SCENE --spp $SPP --no-cpu-baseline --no-extras $*"   # (--no-extras: every k_paths dispatch of the process is this frame's)
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $B --steps 3 --warmup 1 > $O/stats.log 2>&1
 echo "$SCENE stats done"
 P="$B --steps 1 --warmup 0 --no-kernel-timing"
