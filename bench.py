@@ -35,6 +35,8 @@ Rank 0 prints ONE JSON line with the contract fields plus
   per_sample    the same frame in the per-sample RNG mode (NOT the reference's random numbers; labelled so)
   extra_configs BASELINE configs 3, 4 and 5 (matte x 1024 spp, four bunnies x 256, sixteen lights x 512), a few frames
                 each, event totals against the committed oracle totals
+  reference_walk_mode  the headline frame once under RT_FLAG_REFERENCE_WALK (opt-in parity mode, not the timed kernels):
+                its rate, and its event totals against the committed totals of the oracle's LITERAL mode
 """
 import argparse
 import json
@@ -258,6 +260,7 @@ def main():
         ones = rtdist.sum_over_ranks([1])[0]
         per_rank = rtdist.gather_from_ranks([int(head.last["camera_rays"]), int(round(1e6 * agg["seconds_trace"] / max(agg["launches_trace"], 1))),
                                              dev_index])
+        frame_copy = head.fb.clone() if rank == 0 else None  # (the reduce timing below overwrites rank 0's buffer)
         torch.cuda.synchronize()
         dist.barrier()
         t0 = time.perf_counter()
@@ -332,6 +335,53 @@ def main():
                            "event_totals_equal_committed_oracle_totals": e_equal, "totals_summed_over_ranks": e_totals})
             cfg.close()
 
+    # ---- the headline frame ONCE in the opt-in parity mode RT_FLAG_REFERENCE_WALK (the reference's own tree, box test, order
+    # and tie rule): its event totals against the committed totals of the oracle's LITERAL mode -- the one mode in which the
+    # image is the reference algorithm's ray for ray, also on the rays its slab test loses.  Never the timed kernels.
+    ref_walk = None
+    if not args.no_extras and not per_sample_headline and args.debug_flags == 0:
+        cfg = Config(env, arrays, w, h, spp, args.max_bounces, base_flags | api.FLAG_REFERENCE_WALK, args.deterministic)
+        r_elapsed, r_agg, r_fail = cfg.timed(1, 0, False)
+        r_totals = cfg.frame_totals()
+        r_failed = rtdist.agree_on_failure(bool(r_fail))
+        r_want = golden_totals(args.scene, w, h, spp, "oracle_literal") if args.max_bounces == 10 else None
+        r_equal = (all(r_totals[k] == v for k, v in r_want.items()) and r_totals["camera_rays"] == w * h * spp) if r_want else None
+        ref_walk = {"what": "RT_FLAG_REFERENCE_WALK, one frame (first use: includes building and uploading the reference's tree), "
+                            "opt-in parity mode: NOT the timed kernels",
+                    "value": None if (r_failed or r_equal is False) else round(float(w) * h * spp / r_elapsed / 1e6, 3),
+                    "unit": "Msamples/s", "ms_per_frame": round(1e3 * r_elapsed, 3),
+                    "event_totals_equal_committed_LITERAL_oracle_totals": r_equal, "totals_summed_over_ranks": r_totals}
+        cfg.close()
+        if r_equal is False:
+            invalid = "RT_FLAG_REFERENCE_WALK: the frame's event totals differ from the committed literal-oracle totals"
+
+    # ---- N > 1: the SAME frame through the in-process multi-device entry point (rt_render_multi: one host thread per GPU
+    # in ONE process, peer copies to devices[0]) -- on rank 0, while the other ranks wait at the final barrier.  This is the
+    # path a C++ driver reaches with render(..., devices) / RTCUDA_DEVICES; here it runs on the node's real GPUs.
+    in_process = None
+    if world > 1 and not args.no_extras and not per_sample_headline and args.debug_flags == 0 and rank == 0:
+        devices = [k % n_dev for k in range(world)]
+        try:
+            t0 = time.perf_counter()
+            _, st_first = head.scene.render_multi(head.cam, w, h, spp, devices, max_bounces=args.max_bounces, seed=1)
+            t_first = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            img_m, st_m = head.scene.render_multi(head.cam, w, h, spp, devices, max_bounces=args.max_bounces, seed=1)
+            t_second = time.perf_counter() - t0
+            ref_img = frame_copy.view(h, w, 3).cpu().numpy()  # rank 0's reduced, post-processed frame of the last headline step
+            m = ~(np.isnan(img_m) | np.isnan(ref_img))
+            in_process = {
+                "what": "rt_render_multi on rank 0 over the same devices (the other ranks idle at a barrier): host buffers in and "
+                        "out, so the wall time includes allocation, the 24.9 MB copy back and -- first call -- the scene replicas",
+                "devices": devices, "device_shards": st_m["device_shards"],
+                "wall_ms_first_call": round(1e3 * t_first, 2), "wall_ms": round(1e3 * t_second, 2),
+                "device_ms_slowest_shard": round(1e3 * st_m["seconds_render"], 3),
+                "Msamples_per_s_wall": round(float(w) * h * spp / t_second / 1e6, 1),
+                "event_totals_equal_the_rank_sharded_frame": all(int(st_m[k]) == head_totals[k] for k in TOTAL_KEYS),
+                "rms_vs_the_rank_sharded_frame": float(np.sqrt(np.mean((img_m[m].astype(np.float64) - ref_img[m]) ** 2)))}
+        except Exception as e:  # noqa: BLE001 -- reported in the line, never fatal for it
+            in_process = {"error": str(e), "devices": devices}
+
     if rank == 0:
         samples = float(w) * h * spp * args.steps
         value = samples / elapsed / 1e6
@@ -363,6 +413,9 @@ def main():
             out["multi_gpu"] = multi
         out["per_sample"] = sub_per_sample
         out["extra_configs"] = extras
+        out["reference_walk_mode"] = ref_walk
+        if in_process is not None:
+            out["multi_gpu"]["in_process_rt_render_multi"] = in_process
         # ---- CPU baseline (rank 0, N = 1 only): the oracle on a bounded sample of the same workload
         np_c, tt_c, np_a, tt_a = APPX_C[args.scene]
         np_src = "SURVEY.md Appendix C"
@@ -525,8 +578,6 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    if invalid and rank == 0:
-        raise SystemExit(4)
 
 
 if __name__ == "__main__":

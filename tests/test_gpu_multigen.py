@@ -180,6 +180,27 @@ def test_small_shard_build_of_the_persistent_kernel_matches_oracle(api, oracle):
     assert _rms(out.cpu().numpy().reshape(h, w, 3), img_c).max() < 2e-6
 
 
+def test_half_populated_waves_knob_gives_the_same_shard(api, oracle, monkeypatch):
+    """RT_HALF_WAVES=1 (an experiment knob, measured slower at 1/8 and kept: profiles/r04_experiments.md): 32 slots per wave
+    and twice the workgroups on shards of <= 1/8 of the slots -- the full-pool build of k_paths with idle upper half-waves.
+    Same slots, same chains: the shard's event totals and fixed-point sums must not move."""
+    import torch
+    w, h, spp = 480, 270, 32
+    gpu, _ = _scenes(api, oracle, "full_bsdf")
+    cam = api.make_camera(aspect=w / h)
+    keys = ("camera_rays", "shade_events", "closest_rays", "any_rays", "emission_adds", "shadow_adds", "rr_draws")
+    for shards, r in ((8, 3), (16, 9)):
+        a = torch.zeros(h * w * 3, dtype=torch.int64, device="cuda")
+        st_a = gpu.render_shard_fixed(cam, w, h, spp, r, shards, a.data_ptr())
+        monkeypatch.setenv("RT_HALF_WAVES", "1")
+        b = torch.zeros_like(a)
+        st_b = gpu.render_shard_fixed(cam, w, h, spp, r, shards, b.data_ptr())
+        monkeypatch.delenv("RT_HALF_WAVES")
+        torch.cuda.synchronize()
+        assert all(st_a[k] == st_b[k] for k in keys), (shards, st_a, st_b)
+        assert torch.equal(a, b), shards
+
+
 def test_lds_top_of_tree_on_small_shards(api, oracle, monkeypatch):
     """BVH nodes staged through LDS (north star; `top` / `top_n` of inner_step): the small-shard build of k_paths copies
     the first records of the tree -- its top levels in breadth-first order -- into LDS and walks them from there.  On by
