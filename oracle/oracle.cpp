@@ -8,7 +8,13 @@
 // built or run in this image (nvcc, cuRAND, CUB absent), so nothing the reference itself produced pins
 // this restatement: its pins are the known answers SURVEY.md Appendix C records
 // (tests/golden/appendix_c.json, tests/test_oracle_pins.py) and the committed outputs of its own two
-// modes (tests/golden/render_goldens.npz).
+// modes (tests/golden/render_goldens.npz).  Of Appendix C's answers, the XORWOW states and draws, the
+// camera / triangle / offset / heuristic bit patterns, the BVH statistics, the per-iteration queue counts,
+// the event totals and the mean RGB of nine renders reproduce exactly; its FNV-1a-64 IMAGE HASHES DO NOT
+// (libm flavour, one thread, serial deposit order; bytes / words / big-endian, FNV-1 and FNV-1a, image and
+// raw sums: none matches -- the survey session's hash definition or libm ulps cannot be recovered offline;
+// DESIGN.md section 3).  The XORWOW step and the 2^67 subsequence jump are also held against rocRAND's
+// independent engine (tests/cpp/xorwow_rocrand_check.cpp).
 //
 // What it restates (file:line into the reference tree; nothing is copied, every function is
 // re-written from the behaviour read there):
@@ -38,7 +44,8 @@
 //
 // Parity status: the reference ships no tests, golden images or fixtures, and it cannot be
 // built here (needs nvcc + cuRAND + CUB; none present, and stand-ins are not allowed), so this
-// oracle is pinned ONLY by the known-answer values SURVEY.md Appendix C records.
+// oracle is pinned ONLY by the known-answer values SURVEY.md Appendix C records (minus its image
+// hashes, see above).
 //
 // Build: see oracle/Makefile (g++ -O2 -std=c++17 -ffp-contract=off -fwrapv -fopenmp).
 

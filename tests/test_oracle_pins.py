@@ -156,6 +156,36 @@ def test_image_goldens_variants(oracle_libm, variant):
     assert st["max_stack"] <= 14
 
 
+def test_xorwow_step_and_subsequence_jump_against_rocrands_engine(oracle, tmp_path):
+    """An implementation of the third-party generator that this project did not write: rocRAND's `xorwow_engine` (ROCm image,
+    /opt/rocm/include/rocrand/rocrand_xorwow.h) is the same XORWOW -- same xorshift step, same Weyl increment, same 2^67-draw
+    subsequences applied with ITS OWN precomputed GF(2) matrices -- and differs from cuRAND only in the seed-scramble
+    constants.  Started on the host from the oracle's cuRAND-scrambled state of a seed (tests/cpp/xorwow_rocrand_check.cpp), it
+    must reach the oracle's curand_init(seed, k, 0) state and draws for every k tried.  What stays unverifiable offline is
+    the scramble itself: five constants."""
+    import shutil
+    import subprocess
+    hipcc = "/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else shutil.which("hipcc")
+    if not hipcc or not os.path.exists("/opt/rocm/include/rocrand/rocrand_xorwow.h"):
+        pytest.skip("no hipcc / rocRAND headers in this environment")
+    exe = str(tmp_path / "xorwow_rocrand_check")
+    subprocess.check_call([hipcc, "-O1", "-std=c++17", "--offload-arch=gfx950", "-I/opt/rocm/include",
+                           os.path.join(HERE, "cpp", "xorwow_rocrand_check.cpp"), "-o", exe], stderr=subprocess.DEVNULL)
+    ks = [0, 1, 2, 3, 5, 64, 4095, 12345, 524288, 1048575]
+    for seed in (1, 12345, 0xDEADBEEFCAFE):
+        base = oracle.xorwow_init(seed, 0)
+        out = subprocess.run([exe] + [str(int(x)) for x in base] + ["4"] + [str(k) for k in ks], capture_output=True,
+                             text=True, check=True).stdout.splitlines()
+        assert len(out) == len(ks)
+        for line, k in zip(out, ks):
+            t = [int(x) for x in line.split()]
+            assert t[0] == k
+            mine = oracle.xorwow_init(seed, k)
+            assert np.array_equal(np.array(t[1:7], np.uint32), mine), (seed, k)
+            raw, _ = oracle.xorwow_draw(mine.copy(), 4)
+            assert [int(x) for x in raw] == t[7:], (seed, k)
+
+
 def test_pinned_math_accuracy(oracle):
     """rt_sincosf / rt_pow5f (the pinned stand-ins for sincosf / powf(x,5)) are within 2 ulp on their ranges."""
     xs = np.concatenate([np.linspace(0, 2 * np.pi, 20001), [1e-7, np.pi / 2, np.pi, 6.2831855]]).astype(np.float32)
