@@ -196,3 +196,59 @@ def test_every_full_baseline_frame_equals_the_literal_oracle_under_the_reference
     if "oracle_literal_nan_pixels" in frame:
         nan_pixels = int(torch.isnan(fb).view(-1, 3).any(dim=1).sum().item())
         assert nan_pixels == frame["oracle_literal_nan_pixels"]
+
+
+def _tiny_scenes():
+    """(name, arrays): the bare Cornell box (12 triangles: a tree of depth 4) with a point light only / one area light + one
+    point light / no light at all, one single triangle (the root is a leaf: bvh.cuh:252,307), and no triangle at all."""
+    from rtcuda_amd import scenes
+    out = []
+    for kind in ("point", "mixed", "none"):
+        a = scenes.cornell_bunny("matte", bunny=False)
+        if kind == "point":
+            lights = np.zeros(1, scenes.LIGHT_DTYPE)
+            lights[0] = (scenes.POINT_LIGHT, (0.7, 0.15, -0.6), -1, (0.5, 0.5, 0.5))
+            a.lights, a.tri_light = lights, np.full(a.n_tris, -1, np.int32)
+        elif kind == "mixed":
+            lights = np.zeros(2, scenes.LIGHT_DTYPE)
+            lights[0] = a.lights[0]
+            lights[1] = (scenes.POINT_LIGHT, (0.3, 0.8, -0.3), -1, (0.2, 0.3, 0.4))
+            a.lights, a.tri_light = lights, np.where(a.tri_light == 0, 0, -1).astype(np.int32)
+        else:
+            a.lights, a.tri_light = np.zeros(0, scenes.LIGHT_DTYPE), np.full(a.n_tris, -1, np.int32)
+        out.append((kind, a))
+    base = scenes.cornell_bunny("matte", bunny=False)
+    out.append(("one_triangle", scenes.SceneArrays(tris=base.tris[8:9].copy(), tri_material=np.array([2], np.int32),
+                                                   tri_light=np.array([-1], np.int32), materials=base.materials,
+                                                   lights=np.zeros(0, scenes.LIGHT_DTYPE))))
+    out.append(("empty", scenes.SceneArrays(tris=np.zeros((0, 9), np.float32), tri_material=np.zeros(0, np.int32),
+                                            tri_light=np.zeros(0, np.int32), materials=base.materials,
+                                            lights=np.zeros(0, scenes.LIGHT_DTYPE))))
+    return out
+
+
+@pytest.mark.parametrize("name,arrays", _tiny_scenes(), ids=[n for n, _ in _tiny_scenes()])
+def test_reference_walk_on_tiny_and_degenerate_scenes(api, oracle, name, arrays):
+    """The reference's tree at its edges -- a root that is a leaf, a tree of a dozen triangles, no triangle at all -- and the
+    light code paths (point light: no excluded triangle; no lights: no shadow rays) under RT_FLAG_REFERENCE_WALK, alone and
+    through rt_render_multi: event totals and fixed-point sums equal to the literal oracle's."""
+    import torch
+    w, h, spp = 48, 48, 8
+    want = np.zeros((h, w, 3), np.int64)
+    _, _, st_c = oracle.scene(arrays).render(default_camera(oracle, 1.0), w, h, spp, threads=usable_cpus(), fixed_out=want)
+    gpu = api.Scene(arrays)
+    cam = api.make_camera(aspect=1.0)
+    got = torch.zeros(h * w * 3, dtype=torch.int64, device="cuda")
+    st = gpu.render_shard_fixed(cam, w, h, spp, 0, 1, got.data_ptr(), flags=api.FLAG_REFERENCE_WALK)
+    torch.cuda.synchronize()
+    assert st["camera_rays"] == w * h * spp
+    for kg, kc in EVENTS:
+        assert st[kg] == st_c[kc], (name, kg, st[kg], st_c[kc])
+    assert np.array_equal(got.cpu().numpy().reshape(h, w, 3), want)
+    img_m, st_m = gpu.render_multi(cam, w, h, spp, [0, 0], flags=api.FLAG_REFERENCE_WALK | api.FLAG_DETERMINISTIC)
+    img_1, _ = gpu.render(cam, w, h, spp, flags=api.FLAG_REFERENCE_WALK | api.FLAG_DETERMINISTIC)
+    assert all(st_m[kg] == st_c[kc] for kg, kc in EVENTS)
+    assert np.array_equal(img_m.view(np.uint32), img_1.view(np.uint32))
+    if name in ("none", "empty"):
+        assert st["any_rays"] == 0 and not img_1.any()
+    gpu.close()

@@ -12,6 +12,7 @@ bash tools/profile_scene.sh $TAG sixteen_lights 256
 bash tools/profile_scene.sh $TAG matte 256
 # one rank's shard of an 8-GPU run, on one GPU
 mkdir -p $O/shard8
+python3 -c "from rtcuda_amd import api; print(api.build_id())" > $O/shard8/build_id.txt
 timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_LDS GRBM_GUI_ACTIVE --output-format csv -d $O/shard8/pmc_sq1 -- python3 tools/shard_breakdown.py 8 > $O/shard8/pmc_sq1.log 2>&1
 timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS --output-format csv -d $O/shard8/pmc_sq2 -- python3 tools/shard_breakdown.py 8 > $O/shard8/pmc_sq2.log 2>&1
 timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQ_WAIT_INST_LDS SQ_INSTS_SMEM SQ_INSTS_FLAT SQ_INSTS_SENDMSG SQ_INST_LEVEL_SMEM SQ_INSTS_BRANCH --output-format csv -d $O/shard8/pmc_sq3 -- python3 tools/shard_breakdown.py 8 > $O/shard8/pmc_sq3.log 2>&1 || echo "sq3 pass failed (counter names)"
