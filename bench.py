@@ -434,6 +434,26 @@ def main():
                 "sample": f"same scene and camera at {w}x{h}, {args.cpu_spp} spp ({w * h * args.cpu_spp} samples), "
                           f"render loop only ({ost['seconds_loop']:.1f} s; RNG init {ost['seconds_rng_init']:.2f} s "
                           f"reported apart), literal wavefront schedule, OpenMP over queue entries"}
+            # BASELINE config 1 IN FULL ("bun_zipper.ply, 256x256, 4 spp, diffuse-only, CPU reference path"): the
+            # oracle on the whole frame, and the same frame on the HIP path beside it (one generation: the lockstep pipeline)
+            if not args.no_extras:
+                c1_arrays = scenes.cornell_bunny("matte")
+                c1_cam = orc.camera((0.5, 0.5, 1.5), (0.5, 0.5, 0.0), (0.0, 1.0, 0.0), 37.8, 1.0)
+                c1_img, _, c1_st = orc.scene(c1_arrays).render(c1_cam, 256, 256, 4, 10, 1, threads=cores)
+                c1_gpu = api.Scene(c1_arrays)
+                c1_gimg, c1_gst = c1_gpu.render(api.make_camera(aspect=1.0), 256, 256, 4)
+                c1_gimg, c1_gst = c1_gpu.render(api.make_camera(aspect=1.0), 256, 256, 4)  # (second call: RNG states cached)
+                c1_gpu.close()
+                out["cpu_baseline"]["config_1_full"] = {
+                    "workload": "BASELINE configs[0]: bun_zipper.ply 256x256, 4 spp, all matte (262 144 samples), whole frame",
+                    "cpu_Msamples_per_s": round(262144 / c1_st["seconds_loop"] / 1e6, 4), "cpu_seconds_loop": round(c1_st["seconds_loop"], 3),
+                    "cpu_iterations": int(c1_st["iterations"]),
+                    "gpu_Msamples_per_s": round(262144 / max(c1_gst["seconds_render"], 1e-9) / 1e6, 1),
+                    "gpu_ms": round(1e3 * c1_gst["seconds_render"], 3),
+                    "events_equal": all(int(c1_gst[g]) == int(c1_st[o]) for g, o in (("shade_events", "sum_mat"), ("any_rays", "sum_ah"),
+                                                                                     ("emission_adds", "emission_adds"), ("shadow_adds", "ah_adds"),
+                                                                                     ("rr_draws", "rr_draws"))),
+                    "rms_literal_oracle_vs_gpu": float(np.sqrt(np.mean((c1_img.astype(np.float64) - c1_gimg) ** 2)))}
             if ost["ch_rays"] > 0 and ost["ah_rays"] > 0:
                 np_c = ost["ch_node_pairs"] / ost["ch_rays"]
                 tt_c = ost["ch_tri_tests"] / ost["ch_rays"]
