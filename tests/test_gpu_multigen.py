@@ -441,6 +441,8 @@ FIXED_CASES = [
     ("sixteen_lights", 480, 270, 20, False),
     ("matte", 256, 256, 40, True),           # RT_FLAG_REFERENCE_WALK against the LITERAL oracle
     ("sixteen_lights", 480, 270, 20, True),
+    ("four_bunnies", 480, 270, 20, False),   # the deep tree (global overflow stack in k_paths) ...
+    ("four_bunnies", 480, 270, 20, True),    # ... and the reference's depth-22 tree
 ]
 
 
