@@ -602,13 +602,49 @@ __device__ __forceinline__ void advance_core(const DScene &sc, const float *tab,
 // the flipped unit normal and the material / light ids, so no triangle is gathered here.  The
 // kernel has no atomics on shared words and one barrier (the table staging): the shadow ray goes
 // to the slot's own record, event counts go to the wave's own counter row.
-template <bool LDS_TABLES>
+// SORT (material-sorted shading; opt-in with RT_SORT_SHADE=1): which slot a thread serves is decided per
+// workgroup by the MATERIAL the slot is about to shade with.  The 256 slots of the block are partitioned -- ballot + mbcnt
+// ranks per wave, wave offsets through 16 LDS counters -- into [matte | mirror | glass | nothing to shade] and thread t takes
+// the t-th slot of that order, so a wave runs one branch of Material::sample_f (material.cuh:60-109) instead of all three
+// (the reference shades in compacted-queue order, whatever the material: render.cuh:139-145).  A slot's computation does
+// not depend on the thread that runs it, and every per-slot array is indexed by the slot: results are unchanged (a GPU
+// test holds the fixed-point sums equal).  Measured on C2's whole frame through the round pipeline (RT_PERSISTENT=0):
+// k_advance takes 87 ms sorted against 70 ms in slot order (frame 535 vs 517 ms, profiles/r04_experiments.md) -- the kernel
+// streams 36 arrays of slot state and is bound by that traffic; the sort costs a dependent load phase and two barriers in
+// front of it and scatters the accesses inside the block's window, while the divergence it removes (three short branches of
+// sample_f) was not what the kernel waited for.  So slot order stays the default, here as in the persistent kernel.
+template <bool LDS_TABLES, bool SORT = false>
 __global__ void __launch_bounds__(kBlock)
 k_advance(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__ fb, DCounters *__restrict__ ctr,
           DWaveRow *__restrict__ rows) {
     __shared__ float s_tab[LDS_TABLES ? kTabDwordsMax : 1];
+    __shared__ int s_perm[SORT ? kBlock : 1];
+    __shared__ int s_count[SORT ? 16 : 1];  // [kind][wave of the block]
 
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (SORT) {
+        int kind = 3;  // nothing to shade: gen(), an idle or finished slot, a thread past the end
+        if (i < ap.n) {
+            const int b = p.bounces(i), hi = p.hit_info(i);
+            if (b != kDone && b != kParked && hi >= 0 && b < ap.max_bounces)  // init() will route it to mat() (render.cuh:109,128-130)
+                kind = min(max(__float_as_int(sc.tables[5 * (hi & 0xffff) + 4]), 0), 2);
+        }
+        const unsigned wave = threadIdx.x >> 6;
+        unsigned rank = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const unsigned long long m = wave_ballot(kind == k);
+            if (kind == k) rank = prefix_popc(m);
+            if (lane_id() == 0) s_count[4 * k + wave] = (int)__popcll(m);
+        }
+        __syncthreads();
+        int base = 0;
+        for (int q = 0; q < 16; q++)  // everything of a smaller kind, and of this kind in the waves before this one
+            base += (q < 4 * kind + (int)wave) ? s_count[q] : 0;
+        s_perm[base + (int)rank] = (int)threadIdx.x;
+        __syncthreads();
+        i = blockIdx.x * blockDim.x + s_perm[threadIdx.x];
+    }
     const bool in_range = i < ap.n;
     // ---- issue all per-slot loads up front
     SlotState st;
@@ -2842,6 +2878,19 @@ static int lds_stack_cap(const rt_scene *scene, int limit) {
     return cap;
 }
 
+// launches k_advance<LDS tables?, material-sorted?> for one round (uses grid, block, sc, c, cam, ap, lds_tables of the caller)
+static bool sort_shade() {
+    const char *e = getenv("RT_SORT_SHADE");
+    return e ? atoi(e) != 0 : false;  // (measured on C2's round pipeline: 535 ms sorted, 517 ms in slot order -- see k_advance)
+}
+#define RT_LAUNCH_ADVANCE(stream, fbptr)                                                                                         \
+    do {                                                                                                                         \
+        if (lds_tables && sort_shade()) hipLaunchKernelGGL((k_advance<true, true>), grid, block, 0, stream, sc, c.pools, cam, ap, fbptr, c.d_ctr, c.d_rows);   \
+        else if (lds_tables) hipLaunchKernelGGL((k_advance<true, false>), grid, block, 0, stream, sc, c.pools, cam, ap, fbptr, c.d_ctr, c.d_rows);             \
+        else if (sort_shade()) hipLaunchKernelGGL((k_advance<false, true>), grid, block, 0, stream, sc, c.pools, cam, ap, fbptr, c.d_ctr, c.d_rows);           \
+        else hipLaunchKernelGGL((k_advance<false, false>), grid, block, 0, stream, sc, c.pools, cam, ap, fbptr, c.d_ctr, c.d_rows);                            \
+    } while (0)
+
 // launches k_trace<MODE, wide?> -- the node format is a property of the scene
 #define RT_LAUNCH_TRACE(MODE, wide, grid, lds, stream, ...)                                                \
     do {                                                                                                   \
@@ -3138,6 +3187,8 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
     } while (0)
         if (literal) {
             // RT_FLAG_REFERENCE_WALK: the build whose node block is the reference's own walk
+            // (full pool: the 4-wave build although it spills 53 VGPRs -- measured 1 082 ms for C2's frame against 1 412 ms
+            // for the spill-free 2-wave build at half the occupancy)
 #define RT_LAUNCH_REF(T)                                                                                               \
     do {                                                                                                               \
         if (few_blocks)                                                                                                \
@@ -3213,19 +3264,13 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
                 hipEvent_t e0, e1, e2, e3;
                 if (next_event(&e0) || next_event(&e1) || next_event(&e2) || next_event(&e3)) return 1;
                 HIP_TRY(hipEventRecord(e0, st));
-                if (lds_tables)
-                    hipLaunchKernelGGL(k_advance<true>, grid, block, 0, st, sc, c.pools, cam, ap, d_sum, c.d_ctr, c.d_rows);
-                else
-                    hipLaunchKernelGGL(k_advance<false>, grid, block, 0, st, sc, c.pools, cam, ap, d_sum, c.d_ctr, c.d_rows);
+                RT_LAUNCH_ADVANCE(st, d_sum);
                 HIP_TRY(hipEventRecord(e1, st));
                 RT_LAUNCH_TRACE_REF(MODE_POOL, literal, scene->wide, grid_trace, lds_bytes, st, sc, c.pools, tpp, stack_cap, d_over);
                 HIP_TRY(hipEventRecord(e2, st));
                 HIP_TRY(hipEventRecord(e3, st));
             } else {
-                if (lds_tables)
-                    hipLaunchKernelGGL(k_advance<true>, grid, block, 0, st, sc, c.pools, cam, ap, d_sum, c.d_ctr, c.d_rows);
-                else
-                    hipLaunchKernelGGL(k_advance<false>, grid, block, 0, st, sc, c.pools, cam, ap, d_sum, c.d_ctr, c.d_rows);
+                RT_LAUNCH_ADVANCE(st, d_sum);
                 RT_LAUNCH_TRACE_REF(MODE_POOL, literal, scene->wide, grid_trace, lds_bytes, st, sc, c.pools, tpp, stack_cap, d_over);
             }
             rounds++;
@@ -3249,10 +3294,7 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
         for (int j = 0; j <= max_bounces + 1; j++) {
             ap.round = (int)(rounds & 0x3fffffff);
             HIP_TRY(hipMemsetAsync(&c.d_ctr->round_shades, 0, sizeof(unsigned), st));
-            if (lds_tables)
-                hipLaunchKernelGGL(k_advance<true>, grid, block, 0, st, sc, c.pools, cam, ap, d_sum, c.d_ctr, c.d_rows);
-            else
-                hipLaunchKernelGGL(k_advance<false>, grid, block, 0, st, sc, c.pools, cam, ap, d_sum, c.d_ctr, c.d_rows);
+            RT_LAUNCH_ADVANCE(st, d_sum);
             HIP_TRY(hipGetLastError());
             rounds++;
             if (j > 0) {
@@ -4194,8 +4236,7 @@ int rt_split_probe(const rt_scene *scene, const rt_camera *camera, int width, in
         ap.round = rounds;
         double t = 0.0;
         HIP_TRY(hipEventRecord(pb.e0, nullptr));
-        if (lds_tables) hipLaunchKernelGGL(k_advance<true>, grid, block, 0, nullptr, sc, c.pools, cam, ap, fb, c.d_ctr, c.d_rows);
-        else hipLaunchKernelGGL(k_advance<false>, grid, block, 0, nullptr, sc, c.pools, cam, ap, fb, c.d_ctr, c.d_rows);
+        RT_LAUNCH_ADVANCE(nullptr, fb);
         if (timed(t)) return 1;
         if (rounds == 0) t_adv0 = t;  // every slot generates: gen() alone
         else t_adv += t;

@@ -296,6 +296,22 @@ def test_round_pipeline_and_scheduling_variants_agree_over_generations(api, orac
         assert st_p[k] == st_r[k], k
     assert st_r["iterations"] > st_p["iterations"]
     assert _rms(img_p, img_r).max() < 2e-6
+    # material-sorted shading (k_advance<.., SORT>: a workgroup's slots partitioned by material kind with ballot + mbcnt;
+    # RT_SORT_SHADE=1, measured slower and off by default) against slot order: which thread serves a slot changes nothing
+    import torch
+    det = {}
+    for sort in ("1", "0"):
+        monkeypatch.setenv("RT_PERSISTENT", "0")
+        monkeypatch.setenv("RT_SORT_SHADE", sort)
+        buf = torch.zeros(h * w * 3, dtype=torch.int64, device="cuda")
+        st_s = gpu.render_shard_fixed(cam, w, h, spp, 0, 1, buf.data_ptr())
+        torch.cuda.synchronize()
+        monkeypatch.delenv("RT_PERSISTENT")
+        monkeypatch.delenv("RT_SORT_SHADE")
+        for k in keys:
+            assert st_s[k] == st_p[k], (sort, k)
+        det[sort] = buf
+    assert torch.equal(det["1"], det["0"])
     for env in ({"RT_MAJORITY": "0"}, {"RT_ADV_BATCH": "7", "RT_GEN_BATCH": "1"}, {"RT_PRIO_ROTATE": "0"},
                 {"RT_PATHS_BLOCKS": "256"}, {"RT_SPLIT": "2"}):
         for k, v in env.items():
