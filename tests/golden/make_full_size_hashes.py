@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The ORACLE's image of the six full BASELINE frames, as 64-bit hashes -> tests/golden/full_size_image_hashes.json.
 
-CPU only (no GPU, no HIP library): for each frame and oracle mode (watertight / literal) one whole-frame render of
+Fixture generator (test infrastructure, like make_golden.py); CPU only (no GPU, no HIP library): for each frame and oracle mode (watertight / literal) one whole-frame render of
 oracle/oracle.cpp with the product's fixed-point accumulation beside the float sums (render_literal, `fb_fixed`), hashed by
 oracle.sums_hash.  The GPU suite renders the same frames with RT_FLAG_DETERMINISTIC (default kernels -> watertight hashes,
 RT_FLAG_REFERENCE_WALK -> literal hashes) and compares hashes: full-size image parity, bit for bit, in 10 s of GPU time.
@@ -9,13 +9,13 @@ The event totals of every render are checked against the committed totals (tests
 the way -- a mismatch aborts.  Minutes of CPU per frame and mode; results are written after every render, and frames
 already in the file are skipped (the run can be resumed).
 
-usage: oracle_full_size_hashes.py [--threads N] [--only scene:spp[:mode]] ..."""
+usage: python tests/golden/make_full_size_hashes.py [--threads N] [--only scene:spp[:mode]] ..."""
 import json
 import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 from oracle.oracle import Oracle, sums_hash, usable_cpus  # noqa: E402
@@ -35,7 +35,7 @@ while argv:
     elif a == "--only":
         only.append(tuple(argv.pop(0).split(":")))
 done = json.load(open(OUT)) if os.path.exists(OUT) else {
-    "source": "tools/oracle_full_size_hashes.py: oracle/oracle.cpp, pinned flavour, whole frames, seed 1, max_bounces 10; "
+    "source": "tests/golden/make_full_size_hashes.py: oracle/oracle.cpp, pinned flavour, whole frames, seed 1, max_bounces 10; "
               "sums_sha256_64 = first 16 hex digits of SHA-256 over the little-endian int64 fixed-point sums (2^-30), row-major",
     "frames": []}
 have = {(f["scene"], f["spp"], f["mode"]) for f in done["frames"]}

@@ -505,7 +505,7 @@ def _full_size_hashes():
                          ids=lambda f: f"{f['scene']}_{f['width']}x{f['height']}x{f['spp']}_{f['mode']}")
 def test_every_full_baseline_frame_image_hash(api, frame):
     """Full-size image parity inside the GPU suite: the int64 fixed-point sums of a whole BASELINE frame (6 220 800 values)
-    hashed to 64 bits and compared with the committed hash of the ORACLE's array for that frame (tools/oracle_full_size_hashes.py:
+    hashed to 64 bits and compared with the committed hash of the ORACLE's array for that frame (tests/golden/make_full_size_hashes.py:
     minutes of CPU per frame; tests/golden/full_size_image_hashes.json).  `mode` watertight: the default kernels; `mode`
     literal: RT_FLAG_REFERENCE_WALK.  Equal hashes = every pixel of the frame bit-equal to the oracle's."""
     import torch
