@@ -10,15 +10,20 @@ bash tools/profile_scene.sh $TAG full_bsdf 256
 bash tools/profile_scene.sh $TAG four_bunnies 256
 bash tools/profile_scene.sh $TAG sixteen_lights 256
 bash tools/profile_scene.sh $TAG matte 256
-# one rank's shard of an 8-GPU run, on one GPU
-mkdir -p $O/shard8
-python3 -c "from rtcuda_amd import api; print(api.build_id())" > $O/shard8/build_id.txt
-timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_LDS GRBM_GUI_ACTIVE --output-format csv -d $O/shard8/pmc_sq1 -- python3 tools/shard_breakdown.py 8 > $O/shard8/pmc_sq1.log 2>&1
-timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS --output-format csv -d $O/shard8/pmc_sq2 -- python3 tools/shard_breakdown.py 8 > $O/shard8/pmc_sq2.log 2>&1
-timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQ_WAIT_INST_LDS SQ_INSTS_SMEM SQ_INSTS_FLAT SQ_INSTS_SENDMSG SQ_INST_LEVEL_SMEM SQ_INSTS_BRANCH --output-format csv -d $O/shard8/pmc_sq3 -- python3 tools/shard_breakdown.py 8 > $O/shard8/pmc_sq3.log 2>&1 || echo "sq3 pass failed (counter names)"
-python3 tools/pmc_summary.py $O/shard8/pmc_sq1 $O/shard8/pmc_sq2 $O/shard8/pmc_sq3 > $O/shard8/pmc_summary.json
-rm -rf $O/shard8/pmc_sq1 $O/shard8/pmc_sq2 $O/shard8/pmc_sq3
-echo "shard8 done"
+# one rank's shard of a 2-, 4- and 8-GPU run, on one GPU (the entries an N-GPU bench line prices rank 0's k_paths with)
+for R in 2 4 8; do
+  S=$O/shard$R
+  mkdir -p $S
+  python3 -c "from rtcuda_amd import api; print(api.build_id())" > $S/build_id.txt
+  timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_LDS GRBM_GUI_ACTIVE --output-format csv -d $S/pmc_sq1 -- python3 tools/shard_breakdown.py $R > $S/pmc_sq1.log 2>&1
+  timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS --output-format csv -d $S/pmc_sq2 -- python3 tools/shard_breakdown.py $R > $S/pmc_sq2.log 2>&1
+  if [ $R = 8 ]; then
+    timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQ_WAIT_INST_LDS SQ_INSTS_SMEM SQ_INSTS_FLAT SQ_INSTS_SENDMSG SQ_INST_LEVEL_SMEM SQ_INSTS_BRANCH --output-format csv -d $S/pmc_sq3 -- python3 tools/shard_breakdown.py $R > $S/pmc_sq3.log 2>&1 || echo "sq3 pass failed (counter names)"
+  fi
+  python3 tools/pmc_summary.py $S/pmc_sq1 $S/pmc_sq2 $( [ $R = 8 ] && echo $S/pmc_sq3 ) > $S/pmc_summary.json
+  rm -rf $S/pmc_sq1 $S/pmc_sq2 $S/pmc_sq3
+  echo "shard$R done"
+done
 timeout -k 10 300 python tools/shard_rate.py > $O/shard_rate.txt 2>&1; grep shards $O/shard_rate.txt
 # VALU calibration, plain and under the counters
 timeout -k 10 120 python tools/valu_calibrate.py > $O/valu_calibration.json 2> $O/valu_calibration.err; cat $O/valu_calibration.json

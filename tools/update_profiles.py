@@ -58,26 +58,27 @@ for scene in ("full_bsdf", "four_bunnies", "sixteen_lights", "matte"):
               scene, gui / 2.4e6, c["SQ_INSTS_VALU"], 100 * lane_util, 100 * 2 * c["SQ_INSTS_VALU"] / (1024 * gui),
               c["SQ_INSTS_VALU"] * 64 * lane_util, entry["hbm_bytes_per_launch"] / 1e9, 100 * entry["l2_hit_rate"],
               100 * c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], 100 * c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"]))
-# one rank's shard of an 8-GPU run (tools/refresh_profiles.sh: shard_breakdown.py 8 under the SQ counter passes; no FETCH / WRITE
-# pass, so no HBM traffic): the entry an 8-GPU bench line prices rank 0's k_paths with
-d8 = os.path.join(src, "shard8")
-if os.path.exists(os.path.join(d8, "pmc_summary.json")):
-    kname, c = counters(os.path.join(d8, "pmc_summary.json"))
-    bid = build_id_of(d8) or build_id_of(os.path.join(src, "full_bsdf"))
-    table["full_bsdf_1920x1080x256_n8"] = {
+# one rank's shard of a 2-, 4-, 8-GPU run (tools/refresh_profiles.sh: shard_breakdown.py R under the SQ counter passes; no
+# FETCH / WRITE pass, so no HBM traffic): the entries an N-GPU bench line prices rank 0's k_paths with
+for R in (2, 4, 8):
+    dR = os.path.join(src, f"shard{R}")
+    if not os.path.exists(os.path.join(dR, "pmc_summary.json")):
+        continue
+    kname, c = counters(os.path.join(dR, "pmc_summary.json"))
+    bid = build_id_of(dR) or build_id_of(os.path.join(src, "full_bsdf"))
+    table[f"full_bsdf_1920x1080x256_n{R}"] = {
         "kernel": "k_paths", "kernel_instance": kname, "build_id": bid,
         "SQ_INSTS_VALU": c["SQ_INSTS_VALU"], "SQ_ACTIVE_INST_VALU": c["SQ_ACTIVE_INST_VALU"],
         "SQ_THREAD_CYCLES_VALU": c["SQ_THREAD_CYCLES_VALU"], "SQ_INSTS_SALU": c["SQ_INSTS_SALU"],
         "SQ_WAVE_CYCLES": c["SQ_WAVE_CYCLES"], "SQ_WAIT_ANY": c["SQ_WAIT_ANY"], "SQ_WAIT_INST_ANY": c["SQ_WAIT_INST_ANY"],
         "kernel_cycles": c["GRBM_GUI_ACTIVE"] / 8.0, "hbm_bytes_per_launch": None,
-        "note": f"rocprofv3 --pmc passes of `tools/shard_breakdown.py 8` (slot shard 0 of 8 of the full-BSDF frame on one MI355X: what "
-                f"every rank of an 8-GPU run renders; tools/refresh_profiles.sh; profiles/{tag}_shard8_pmc.json); no HBM pass"}
+        "note": f"rocprofv3 --pmc passes of `tools/shard_breakdown.py {R}` (slot shard 0 of {R} of the full-BSDF frame on one MI355X: what "
+                f"every rank of a {R}-GPU run renders; tools/refresh_profiles.sh; profiles/{tag}_shard{R}_pmc.json); no HBM pass"}
+    shutil.copy(os.path.join(dR, "pmc_summary.json"), os.path.join(dst, f"{tag}_shard{R}_pmc.json"))
 json.dump(table, open(table_path, "w"), indent=1)
 for name in ("bench_n1.json", "shard_rate.txt", "valu_calibration.json", "valu_calibration_pmc.json"):
     if os.path.exists(os.path.join(src, name)):
         shutil.copy(os.path.join(src, name), os.path.join(dst, f"{tag}_{name}"))
-if os.path.exists(os.path.join(src, "shard8", "pmc_summary.json")):
-    shutil.copy(os.path.join(src, "shard8", "pmc_summary.json"), os.path.join(dst, f"{tag}_shard8_pmc.json"))
 # shard-rate curve -> what bench.py echoes when n_gpus > 1
 rates, rates_ps = {}, {}
 p = os.path.join(src, "shard_rate.txt")
