@@ -378,27 +378,28 @@ def main():
     # path a C++ driver reaches with render(..., devices) / RTCUDA_DEVICES; here it runs on the node's real GPUs.
     in_process = None
     if world > 1 and not args.no_extras and not per_sample_headline and args.debug_flags == 0 and rank == 0:
+        import subprocess
         devices = [k % n_dev for k in range(world)]
+        what = ("rt_render_multi over the same devices, in a CHILD process of rank 0 (the other ranks idle at a barrier; a failure in "
+                "there costs this record, not the line): host buffers in and out, so the wall time includes allocation, the 24.9 MB "
+                "copy back and -- first call -- the scene replicas")
         try:
-            t0 = time.perf_counter()
-            _, st_first = head.scene.render_multi(head.cam, w, h, spp, devices, max_bounces=args.max_bounces, seed=1)
-            t_first = time.perf_counter() - t0
-            t0 = time.perf_counter()
-            img_m, st_m = head.scene.render_multi(head.cam, w, h, spp, devices, max_bounces=args.max_bounces, seed=1)
-            t_second = time.perf_counter() - t0
-            ref_img = frame_copy.view(h, w, 3).cpu().numpy()  # rank 0's reduced, post-processed frame of the last headline step
-            m = ~(np.isnan(img_m) | np.isnan(ref_img))
-            in_process = {
-                "what": "rt_render_multi on rank 0 over the same devices (the other ranks idle at a barrier): host buffers in and "
-                        "out, so the wall time includes allocation, the 24.9 MB copy back and -- first call -- the scene replicas",
-                "devices": devices, "device_shards": st_m["device_shards"],
-                "wall_ms_first_call": round(1e3 * t_first, 2), "wall_ms": round(1e3 * t_second, 2),
-                "device_ms_slowest_shard": round(1e3 * st_m["seconds_render"], 3),
-                "Msamples_per_s_wall": round(float(w) * h * spp / t_second / 1e6, 1),
-                "event_totals_equal_the_rank_sharded_frame": all(int(st_m[k]) == head_totals[k] for k in TOTAL_KEYS),
-                "rms_vs_the_rank_sharded_frame": float(np.sqrt(np.mean((img_m[m].astype(np.float64) - ref_img[m]) ** 2)))}
-        except Exception as e:  # noqa: BLE001 -- reported in the line, never fatal for it
-            in_process = {"error": str(e), "devices": devices}
+            child_env = {k: v for k, v in os.environ.items()
+                         if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "LOCAL_WORLD_SIZE")}
+            p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "multi_device_probe.py"), args.scene, str(w), str(h), str(spp),
+                                str(args.max_bounces), ",".join(str(d) for d in devices)], capture_output=True, text=True,
+                               timeout=240, env=child_env)
+            lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+            if p.returncode != 0 or not lines:
+                in_process = {"what": what, "devices": devices, "error": f"exit code {p.returncode}: {p.stderr[-400:]}"}
+            else:
+                rec = json.loads(lines[-1])
+                ref_mean = float(torch.nanmean(frame_copy.double()).item())
+                in_process = dict(rec, what=what,
+                                  event_totals_equal_the_rank_sharded_frame=all(rec["totals"][k] == head_totals[k] for k in TOTAL_KEYS),
+                                  image_mean_of_the_rank_sharded_frame=ref_mean)
+        except Exception as e:  # noqa: BLE001 -- reported in the line, never fatal for it (incl. the child's timeout)
+            in_process = {"what": what, "devices": devices, "error": str(e)}
 
     if rank == 0:
         samples = float(w) * h * spp * args.steps
