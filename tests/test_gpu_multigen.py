@@ -585,3 +585,35 @@ def test_full_baseline_frame_is_exactly_the_sum_of_its_slot_shards(api, shards):
     assert tot == {k: st_full[k] for k in keys}
     assert tot["camera_rays"] == w * h * spp
     assert torch.equal(acc, full)
+
+
+@pytest.mark.parametrize("scene,spp", [("matte", 1024), ("sixteen_lights", 512), ("four_bunnies", 256)])
+def test_eight_rank_shards_of_the_other_baseline_configs_add_up_to_the_oracles_totals(api, scene, spp):
+    """What every rank of the driver's 8-GPU run renders for bench.py's `extra_configs` (BASELINE configs 3, 5, 4), one rank
+    after the other on this GPU: the small-shard build of k_paths on each of the 8 slot ranges of the full frame.  The event
+    totals summed over the shards equal the committed oracle totals of the frame -- the check bench.py itself makes on the
+    node -- and the summed camera rays are the frame's."""
+    import json
+    import torch
+    from rtcuda_amd import scenes
+    here = os.path.dirname(os.path.abspath(__file__))
+    want = [f for f in json.load(open(os.path.join(here, "golden", "full_size_event_totals.json")))["frames"]
+            if (f["scene"], f["spp"]) == (scene, spp)][0]
+    w, h = 1920, 1080
+    if scene not in _scene_cache:
+        _scene_cache[scene] = api.Scene(scenes.cornell_bunny(scene))
+    gpu = _scene_cache[scene]
+    cam = api.make_camera(aspect=w / h)
+    fb = torch.zeros(h * w * 3, dtype=torch.float32, device="cuda")
+    keys = ("camera_rays", "shade_events", "any_rays", "emission_adds", "shadow_adds", "rr_draws")
+    tot = {k: 0 for k in keys}
+    for r in range(8):
+        st = gpu.render_shard(cam, w, h, spp, r, 8, fb.data_ptr())
+        for k in keys:
+            tot[k] += st[k]
+    torch.cuda.synchronize()
+    assert tot["camera_rays"] == w * h * spp
+    for k, v in want["oracle_watertight"].items():
+        assert tot[k] == v, (k, tot[k], v)
+    nan_pixels = int(torch.isnan(fb).view(-1, 3).any(dim=1).sum().item())
+    assert nan_pixels == want["oracle_nan_pixels"]
