@@ -15,7 +15,7 @@
 //     is how the work is sharded over GPUs.
 //   * One global condition remains -- the host loop stops at the first iteration in which nothing
 //     shades (render.cuh:436) -- and it can only bite in the final generation, which is therefore
-//     run in lockstep (one init() per slot per round, host-checked).
+//     run in lockstep (one init() per slot per round; the stop rule is evaluated on the device).
 //
 // Kernels:
 //   k_paths      everything before the final generation, ONE persistent launch per frame.  A lane
@@ -38,8 +38,9 @@
 //   * Two results that depend, in the reference, on the shape of its own tree are defined by the triangle
 //     list alone here: an accepted hit is never culled (conservative box test), and hits at exactly equal
 //     t go to the larger caller index (closest_hit_wins).  Traversal ORDER therefore never matters.
-//   * There are no host read-backs inside a frame except one 16-byte poll per lockstep round (the
-//     reference does four blocking 4-byte read-backs per iteration: render.cuh:433-434,444-445).
+//   * There are no host read-backs inside a frame (the reference does four blocking 4-byte read-backs per
+//     iteration: render.cuh:433-434,444-445): the persistent kernel needs none, and the lockstep rounds of the
+//     final generation carry their stop rule on the device (k_advance: `lock_shades`).
 //
 // No MFMA anywhere: there is no dense contraction on this path.
 #include <hip/hip_runtime.h>
@@ -83,6 +84,7 @@ constexpr int kBlock = 256;       // 4 waves per workgroup
 constexpr int kLdsStack = 16;          // traversal stack entries kept in LDS per lane
 constexpr int kOverStride = 1 << 20;   // lanes of the overflow stack (>= lanes of the largest grid that traverses)
 constexpr int kMaxStackBound = 160;    // deepest traversal stack a scene may need (3 per level + 1)
+constexpr int kLockRounds = 4096;      // lockstep rounds of the final generation a render context can count (max_bounces + 2)
 }  // namespace
 
 // ============================================================================ device structures
@@ -176,7 +178,7 @@ struct DPools {
 // the first version of k_advance.
 struct DCounters {
     int last_live_round;         // highest batch-closing round in which some slot still traced a ray
-    unsigned int round_shades;   // lockstep rounds only: mat() events of the round (the reference's n_mat)
+    unsigned int unused0;        // (round 3: the lockstep rounds' shade count, now per round in Context::d_lock)
     unsigned int pad2[2];
 };
 enum { C_CAMERA = 0, C_SHADE, C_CLOSEST, C_ANY, C_EMIT, C_SHADOW_ADD, C_RR, C_UNUSED, C_COUNT };
@@ -269,7 +271,8 @@ struct AdvanceParams {
     int round;
     int batch_mask;      // rounds with (round & batch_mask) == batch_mask close a host-polled batch
     int last_gen;        // index of the final camera-ray generation
-    int lockstep;        // 1: final generation, one init() per slot per round (literal reference schedule)
+    int lockstep;        // != 0: final generation, one init() per slot per round (literal reference schedule); 1 + the index of
+                         // the lockstep round (0 = the round that generates)
     int fb_fixed;        // framebuffer holds 64-bit fixed-point sums (see deposit())
     int w_over_spp;      // W / spp when spp divides W (then pixel = gen * w_over_spp + slot / spp: no 64-bit divide), else 0
     int dpx, dpy;        // w_over_spp = dpy * width + dpx: how a slot's pixel moves per generation; dpy < 0: not usable
@@ -616,7 +619,12 @@ __device__ __forceinline__ void advance_core(const DScene &sc, const float *tab,
 template <bool LDS_TABLES, bool SORT = false>
 __global__ void __launch_bounds__(kBlock)
 k_advance(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__ fb, DCounters *__restrict__ ctr,
-          DWaveRow *__restrict__ rows) {
+          DWaveRow *__restrict__ rows, unsigned int *__restrict__ lock_shades) {
+    // Lockstep rounds (final generation): the reference's host loop ends at the first iteration in which nothing shades
+    // (render.cuh:436).  The rounds are all enqueued at once; lock_shades[j] counts the mat() events of round j, and a round
+    // finds out on the device whether the render ended before it: round j >= 2 does nothing if round j - 1 shaded nothing
+    // (round 0 only generates; once a round is skipped it counts nothing, so every later one is skipped too).  No host poll.
+    if (ap.lockstep >= 3 && lock_shades[ap.lockstep - 2] == 0u) return;
     __shared__ float s_tab[LDS_TABLES ? kTabDwordsMax : 1];
     __shared__ int s_perm[SORT ? kBlock : 1];
     __shared__ int s_count[SORT ? 16 : 1];  // [kind][wave of the block]
@@ -674,7 +682,8 @@ k_advance(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__
     // Final generation: the reference stops the whole render at the first iteration in which no slot
     // shades (render.cuh:436), which can cut off slots that Russian roulette would have revived
     // later.  That is a global condition, so the last generation runs in lockstep: slots that finish
-    // generation last_gen - 1 park, and once all are parked the host drives one init() per round.
+    // generation last_gen - 1 park, and once all are parked the rounds run one init() per slot each (all enqueued at once:
+    // see the top of this kernel for how a round knows that the render ended before it).
     if (ap.lockstep && st.bounces == kParked) {
         st.bounces = ap.max_bounces;  // routes the slot to gen() below
         st.hit_info = -1;
@@ -746,7 +755,7 @@ k_advance(DScene sc, DPools p, Camera cam, AdvanceParams ap, float *__restrict__
     if ((ap.round & ap.batch_mask) == ap.batch_mask && traced != 0 && lane_id() == 0) ctr->last_live_round = ap.round;
     if (ap.lockstep) {
         unsigned long long sm = wave_ballot(out.did_shade);
-        if (sm != 0 && lane_id() == 0) atomicAdd(&ctr->round_shades, (unsigned)__popcll(sm));
+        if (sm != 0 && lane_id() == 0) atomicAdd(&lock_shades[ap.lockstep - 1], (unsigned)__popcll(sm));
     }
 }
 
@@ -1115,6 +1124,9 @@ struct TraceParams {
     float *fb;             // MODE_POOL: raw-sum framebuffer
     DWaveRow *rows;        // MODE_POOL: counter rows
     unsigned long long *prof;  // RT_TRACE_PROFILE builds only
+    // lockstep rounds: nothing to trace in a round that shaded nothing (see k_advance); null / 0 otherwise
+    const unsigned int *lock_shades;
+    int lock_round;
     // test modes
     const float *o3, *d3, *tmax;
     const int *order, *excluded;
@@ -1133,6 +1145,7 @@ struct TraceParams {
 // (chunks, refill, finalisation) is unchanged, WIDE is not looked at.
 template <int MODE, bool WIDE, int MINW = 8, bool LITERAL = false>
 __global__ void __launch_bounds__(kBlock, MINW) k_trace(DScene sc, DPools p, TraceParams tp, int stack_cap, int *overflow) {
+    if (MODE == MODE_POOL && tp.lock_shades != nullptr && tp.lock_round >= 1 && tp.lock_shades[tp.lock_round] == 0u) return;
     extern __shared__ int s_lds[];
     int *stack = s_lds + threadIdx.x;
     int *over = overflow + (blockIdx.x * kBlock + threadIdx.x);
@@ -2820,6 +2833,7 @@ struct Context {
     bool rng_valid = false;
     uint32_t *rng_backup = nullptr;  // 6 x n words
     std::vector<hipEvent_t> timing_events;
+    unsigned int *d_lock = nullptr;  // mat() events per lockstep round of the final generation (kLockRounds words)
     int *d_over = nullptr;  // overflow part of the traversal stacks of this context's grids (ensure_overflow)
     int over_levels = 0;
     std::mutex busy;  // a context (pools, counters, events) serves one render at a time
@@ -2854,6 +2868,7 @@ int get_context(int n, int lane, Context **out) {
     if (dev_alloc(*c, p.base, (size_t)A_COUNT * n)) return 1;
     if (dev_alloc(*c, c->rng_backup, (size_t)6 * n)) return 1;
     if (dev_alloc(*c, c->d_ctr, 1)) return 1;
+    if (dev_alloc(*c, c->d_lock, (size_t)kLockRounds)) return 1;
     c->n_rows = 2 * ((n + kBlock - 1) / kBlock) * (kBlock / 64);  // (x 2: RT_HALF_WAVES launches twice the waves)
     if (dev_alloc(*c, c->d_rows, (size_t)c->n_rows)) return 1;
     if (dev_alloc(*c, c->d_jump, (size_t)20 * 800)) return 1;
@@ -2885,10 +2900,10 @@ static bool sort_shade() {
 }
 #define RT_LAUNCH_ADVANCE(stream, fbptr)                                                                                         \
     do {                                                                                                                         \
-        if (lds_tables && sort_shade()) hipLaunchKernelGGL((k_advance<true, true>), grid, block, 0, stream, sc, c.pools, cam, ap, fbptr, c.d_ctr, c.d_rows);   \
-        else if (lds_tables) hipLaunchKernelGGL((k_advance<true, false>), grid, block, 0, stream, sc, c.pools, cam, ap, fbptr, c.d_ctr, c.d_rows);             \
-        else if (sort_shade()) hipLaunchKernelGGL((k_advance<false, true>), grid, block, 0, stream, sc, c.pools, cam, ap, fbptr, c.d_ctr, c.d_rows);           \
-        else hipLaunchKernelGGL((k_advance<false, false>), grid, block, 0, stream, sc, c.pools, cam, ap, fbptr, c.d_ctr, c.d_rows);                            \
+        if (lds_tables && sort_shade()) hipLaunchKernelGGL((k_advance<true, true>), grid, block, 0, stream, sc, c.pools, cam, ap, fbptr, c.d_ctr, c.d_rows, c.d_lock);   \
+        else if (lds_tables) hipLaunchKernelGGL((k_advance<true, false>), grid, block, 0, stream, sc, c.pools, cam, ap, fbptr, c.d_ctr, c.d_rows, c.d_lock);             \
+        else if (sort_shade()) hipLaunchKernelGGL((k_advance<false, true>), grid, block, 0, stream, sc, c.pools, cam, ap, fbptr, c.d_ctr, c.d_rows, c.d_lock);           \
+        else hipLaunchKernelGGL((k_advance<false, false>), grid, block, 0, stream, sc, c.pools, cam, ap, fbptr, c.d_ctr, c.d_rows, c.d_lock);                            \
     } while (0)
 
 // launches k_trace<MODE, wide?> -- the node format is a property of the scene
@@ -2955,6 +2970,7 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
                       float *d_sum, hipStream_t st, rt_stats *stats, int ctx_lane = 0) {
     if (!scene || !camera || !d_sum) return fail("rt_render_shard: null argument");
     if (width <= 0 || height <= 0 || spp <= 0 || max_bounces < 0) return fail("rt_render_shard: bad dimensions");
+    if (max_bounces + 2 > kLockRounds) return fail("rt_render_shard: max_bounces exceeds " + std::to_string(kLockRounds - 2));
     if (shard_count <= 0 || kW % shard_count != 0 || shard_index < 0 || shard_index >= shard_count)
         return fail("rt_render_shard: shard_count must divide 1048576 and 0 <= shard_index < shard_count");
     if ((long long)width * height > (long long)(0x7fffffff / 3))  // framebuffer values are indexed with 32 bits
@@ -2992,7 +3008,7 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
     {
         DCounters zero;
         zero.last_live_round = -1;
-        zero.round_shades = 0;
+        zero.unused0 = 0;
         zero.pad2[0] = zero.pad2[1] = 0;
         c.h_ctr[0] = zero;  // pinned staging
         HIP_TRY(hipMemcpyAsync(c.d_ctr, &c.h_ctr[0], sizeof(DCounters), hipMemcpyHostToDevice, st));
@@ -3289,25 +3305,35 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
     }
     // ---- final generation in lockstep (see k_advance): round 0 generates, every later round is one
     // reference iteration; the render ends at the first round in which nothing shades (render.cuh:436)
-    if (finished && !per_sample) {
-        ap.lockstep = 1;
-        for (int j = 0; j <= max_bounces + 1; j++) {
-            ap.round = (int)(rounds & 0x3fffffff);
-            HIP_TRY(hipMemsetAsync(&c.d_ctr->round_shades, 0, sizeof(unsigned), st));
+    // All max_bounces + 2 rounds are enqueued back to back; which of them still belong to the render is decided on the
+    // device (k_advance / k_trace look at lock_shades), and the host learns the number of rounds that ran afterwards.
+    const int n_lock = max_bounces + 2;
+    const bool ran_lockstep = finished && !per_sample;
+    if (ran_lockstep) {
+        HIP_TRY(hipMemsetAsync(c.d_lock, 0, sizeof(unsigned) * (size_t)n_lock, st));
+        for (int j = 0; j < n_lock; j++) {
+            ap.round = (int)((rounds + j) & 0x3fffffff);
+            ap.lockstep = 1 + j;
             RT_LAUNCH_ADVANCE(st, d_sum);
-            HIP_TRY(hipGetLastError());
-            rounds++;
-            if (j > 0) {
-                HIP_TRY(hipMemcpyAsync(&c.h_ctr[0], c.d_ctr, sizeof(DCounters), hipMemcpyDeviceToHost, st));
-                HIP_TRY(hipStreamSynchronize(st));
-                if (c.h_ctr[0].round_shades == 0) break;
-            }
+            tpp.lock_shades = c.d_lock;
+            tpp.lock_round = j;
             RT_LAUNCH_TRACE_REF(MODE_POOL, literal, scene->wide, grid_trace, lds_bytes, st, sc, c.pools, tpp, stack_cap, d_over);
-            HIP_TRY(hipGetLastError());
         }
+        HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(ev_stop, st));
     HIP_TRY(hipEventSynchronize(ev_stop));
+    if (ran_lockstep) {  // rounds that ran: up to and including the first one (after the generating round) that shaded nothing
+        std::vector<unsigned> h_lock((size_t)n_lock);
+        HIP_TRY(hipMemcpy(h_lock.data(), c.d_lock, sizeof(unsigned) * (size_t)n_lock, hipMemcpyDeviceToHost));
+        int ran = n_lock;
+        for (int j = 1; j < n_lock; j++)
+            if (h_lock[(size_t)j] == 0u) {
+                ran = j + 1;
+                break;
+            }
+        rounds += ran;
+    }
 #ifdef RT_TRACE_PROFILE
     {
         unsigned long long h[16];
