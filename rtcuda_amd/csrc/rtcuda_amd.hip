@@ -3021,11 +3021,16 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
     // entries in LDS, so it needs the deeper overflow
     if (ensure_overflow(c.d_over, c.over_levels, scene->stack_bound - std::min(stack_cap, lds_stack_cap(scene, 8)))) return 1;
     int *const d_over = c.d_over;
-    hipLaunchKernelGGL(k_pool_init, dim3(grid_for(n)), dim3(kBlock), 0, st, c.pools, n, max_bounces);
+    // Slots of this shard that ever get a camera ray: slot s serves the camera rays s, s + W, ..., so in a frame of fewer than
+    // W camera rays the slots from cam_end on never do anything -- the kernels of such a frame (it is nothing but the
+    // lockstep rounds: 256 x 256 x 4 uses a quarter of the slots) are launched over the live slots only.  Frames of more
+    // than one generation: all n.  (Per-sample streams: a lane draws its camera rays whatever its slot: all n.)
+    const int n_live = per_sample ? n : (int)std::max<long long>(1, std::min<long long>(n, cam_end - (long long)slot_lo));
+    hipLaunchKernelGGL(k_pool_init, dim3(grid_for(n_live)), dim3(kBlock), 0, st, c.pools, n_live, max_bounces);
     HIP_TRY(hipGetLastError());
 
     AdvanceParams ap;
-    ap.n = n;
+    ap.n = n_live;
     ap.slot_lo = slot_lo;
     ap.width = width;
     ap.height = height;
@@ -3068,7 +3073,7 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
     long long rounds = 0;
     int batch = 0;
     bool finished = false;
-    const dim3 grid(grid_for(n)), block(kBlock);
+    const dim3 grid(grid_for(n_live)), block(kBlock);
     // persistent trace kernels: as many workgroups as the chip keeps resident (never more than the
     // advance grid, whose wave count sizes the counter rows)
     int dev_cus = 0, occ_c = 0;
@@ -3080,9 +3085,9 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
     int per_cu = std::max(1, occ_c);
     if (const char *e = getenv("RT_TRACE_BLOCKS_PER_CU")) per_cu = std::max(1, std::min(per_cu, atoi(e)));
     const int resident = std::max(1, dev_cus * per_cu);
-    const dim3 grid_trace(std::min(grid_for(n), resident));
+    const dim3 grid_trace(std::min(grid_for(n_live), resident));
     TraceParams tpp{};
-    tpp.total = n;
+    tpp.total = n_live;
     tpp.fb = d_sum;
     tpp.rows = c.d_rows;
     tpp.debug_no_deposit = (flags & 0x100u) ? 1 : 0;
