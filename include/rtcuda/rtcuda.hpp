@@ -325,6 +325,16 @@ inline std::vector<int> devices_from_env() {
     return d;
 }
 
+// ... and the library's modes: RTCUDA_REFERENCE_WALK=1 (RT_FLAG_REFERENCE_WALK: the reference's own tree, box test and tie rule
+// -- the reference algorithm's image ray for ray, about a tenth of the speed) and RTCUDA_DETERMINISTIC=1
+// (RT_FLAG_DETERMINISTIC: order-independent fixed-point accumulation, bit-reproducible image).
+inline uint32_t flags_from_env() {
+    uint32_t f = 0;
+    if (const char *e = std::getenv("RTCUDA_REFERENCE_WALK")) f |= std::atoi(e) != 0 ? RT_FLAG_REFERENCE_WALK : 0u;
+    if (const char *e = std::getenv("RTCUDA_DETERMINISTIC")) f |= std::atoi(e) != 0 ? RT_FLAG_DETERMINISTIC : 0u;
+    return f;
+}
+
 // render.cuh:366-367.  `seed` is the reference's hard-coded RAND_SEED = 1 (render.cuh:417).
 inline void render(int width, int height, int num_samples, int max_bounces, Camera camera, Scene scene,
                    std::vector<Vec3> &framebuffer, uint64_t seed = 1, rt_stats *stats = nullptr) {
@@ -332,12 +342,13 @@ inline void render(int width, int height, int num_samples, int max_bounces, Came
     framebuffer.resize((size_t)width * height);
     static_assert(sizeof(Vec3) == 12, "Vec3 must be three packed floats");
     const std::vector<int> devices = devices_from_env();
+    const uint32_t flags = flags_from_env();
     if (!devices.empty()) {
-        rtcuda_detail::check(rt_render_multi(h, &camera.pod, width, height, num_samples, max_bounces, seed, 0, devices.data(),
+        rtcuda_detail::check(rt_render_multi(h, &camera.pod, width, height, num_samples, max_bounces, seed, flags, devices.data(),
                                              (int)devices.size(), reinterpret_cast<float *>(framebuffer.data()), stats), "render");
         return;
     }
-    rtcuda_detail::check(rt_render(h, &camera.pod, width, height, num_samples, max_bounces, seed, 0,
+    rtcuda_detail::check(rt_render(h, &camera.pod, width, height, num_samples, max_bounces, seed, flags,
                                    reinterpret_cast<float *>(framebuffer.data()), stats), "render");
 }
 

@@ -106,3 +106,12 @@ def test_cpp_driver_reaches_several_devices_through_render(api, tmp_path):
     four, _ = run("four.ppm", env=env)
     for got in (two, four):  # identical contributions; the order of the float adds may flip a quantisation boundary
         assert (got != one).mean() < 1e-3 and np.abs(got - one).max() <= 1
+    # the library's modes behind the unchanged call: RTCUDA_DETERMINISTIC=1 is bit-reproducible (the same PPM twice, and from
+    # two device shards), RTCUDA_REFERENCE_WALK=1 renders the same scene through the reference's own tree
+    det_env = dict(os.environ, RTCUDA_DETERMINISTIC="1")
+    d1, _ = run("det1.ppm", env=det_env)
+    d2, _ = run("det2.ppm", env=dict(det_env, RTCUDA_DEVICES="0,0"))
+    assert np.array_equal(d1, d2)
+    assert (d1 != one).mean() < 1e-3 and np.abs(d1 - one).max() <= 1
+    ref, _ = run("ref.ppm", env=dict(os.environ, RTCUDA_REFERENCE_WALK="1"))
+    assert (ref != one).mean() < 1e-2 and ref.any()
