@@ -592,11 +592,24 @@ def main():
                 if roof["achieved"] is not None:
                     roof["frac_of_measured_peak"] = round(roof["achieved"] * 1e12 / rate, 4)
                 roof["copy_bandwidth_measured_GBs"] = round(api.measure_copy_bandwidth(1 << 30, 5) / 1e9, 1)
+                # what the SIMDs can ISSUE for scalar code, measured in this run: independent v_mul_f32 chains at the kernel's
+                # occupancy (rt_probe_issue; DESIGN 5.2: 2.9 cycles per wave64 instruction, and no scalar stream does better
+                # except dependent sequences at 2.25) -- next to the kernel's own vector-instruction rate from the PMC pass
+                sec, n_instr = api.probe_issue(2, 4, 20000)
+                simple_ipc = 4.0 * n_instr / (sec * 2.4e9)  # wave-instructions per cycle per SIMD (nominal 2.4 GHz)
+                roof["simple_stream_valu_per_cycle_per_simd_measured"] = round(simple_ipc, 3)
+                if roof.get("valu_wave_instructions_per_launch"):
+                    k_ipc = roof["valu_wave_instructions_per_launch"] / (1024.0 * avg_s * 2.4e9)
+                    roof["kernel_valu_per_cycle_per_simd"] = round(k_ipc, 3)
+                    roof["frac_of_simple_stream_issue"] = round(k_ipc / simple_ipc, 3)
             except Exception as e:  # noqa: BLE001 -- reported, never fatal for the bench line
                 roof["calibration_error"] = str(e)
             roof["frac_note"] = ("frac = active lane-operations/s over the fp32 vector peak in lane-operations/s; "
                                  "valu_issue_frac counts every issued wave-instruction as 64 lanes (what the SIMDs spend "
-                                 "issue slots on); the gap between the two is lane utilisation.  HBM is not the bound: see hbm.frac")
+                                 "issue slots on); the gap between the two is lane utilisation.  frac_of_simple_stream_issue = the "
+                                 "kernel's vector instructions per cycle per SIMD over what a stream of independent v_mul_f32 "
+                                 "issues at the same occupancy in this run (the spec-sheet 0.5 per cycle is not reached by any "
+                                 "scalar stream on this chip: DESIGN 5.2).  HBM is not the bound: see hbm.frac")
             out["roofline"] = roof
         else:
             out["roofline"] = None
