@@ -110,6 +110,11 @@ typedef struct rt_stats {
                                     algorithm's image ray for ray, including the hits its box test loses.  Several times
                                     slower than the default kernels.  Not combinable with RT_FLAG_RNG_PER_SAMPLE. */
 
+#define RT_FLAG_WATERTIGHT 16u /* the triangle-list definition of the two results above instead of the reference's: an accepted
+                                    hit is never lost to a box test, ties go to the larger caller index.  This is what
+                                    exhaustive search over all triangles returns (about 1 path in 4 * 10^6 differs from the
+                                    reference's image).  Saves the default's check of every hit (a few per cent). */
+
 /* ---- scene -------------------------------------------------------------------------------
  * Replaces: Triangle(p0,p1,p2) x n (triangle.cuh:6-7), cudaMalloc/Memcpy of triangles,
  * materials and lights (main.cu:50-51,119-122,136-137), Primitive(tri*,mat*,light*)

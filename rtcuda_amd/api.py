@@ -24,7 +24,8 @@ W = 1 << 20  # RT_NUM_WORKING_PATHS
 FLAG_TIME_KERNELS = 1
 FLAG_DETERMINISTIC = 2
 FLAG_RNG_PER_SAMPLE = 4  # NOT the reference's random numbers (see include/rtcuda_amd.h): partition-invariant streams
-FLAG_REFERENCE_WALK = 8  # opt-in parity mode: the reference's own tree, box test, order and tie rule (never benchmarked)
+FLAG_REFERENCE_WALK = 8  # cross-check mode: every ray walks the reference's own tree literally (slow; the default kernels give the same image)
+FLAG_WATERTIGHT = 16     # the triangle-list definition (no hit lost to a box test, ties by caller index) instead of the reference's
 
 EXPORTS = [
     "rt_scene_create", "rt_scene_destroy", "rt_scene_info", "rt_scene_build_info", "rt_camera_make", "rt_render", "rt_render_multi",
@@ -51,6 +52,9 @@ class RtStats(ctypes.Structure):
     def as_dict(self) -> dict:
         d = {n: getattr(self, n) for n, _ in self._fields_ if n != "reserved"}
         d["lds_top_records"] = int(self.reserved[2])  # BVH records the persistent kernel staged in LDS
+        # default kernels (no RT_FLAG_WATERTIGHT): closest hits re-traced through the reference's own tree, accepted hits the
+        # reference's box test loses, exact ties at the final distance
+        d["literal_retraces"], d["reference_lost_hits"], d["exact_ties"] = (int(self.reserved[k]) for k in (4, 5, 6))
         return d
 
 

@@ -48,6 +48,22 @@ RT_DEV V3 unit(V3 a) {
     return mk(a.x * inv_len, a.y * inv_len, a.z * inv_len);
 }
 RT_DEV float max3(V3 a) { return fmaxf(fmaxf(a.x, a.y), a.z); }
+// 1 / x, CORRECTLY ROUNDED for every x with 2^-24 <= |x| < 2^126: v_rcp_f32 (1 ulp) and STEPS Newton steps in FMA arithmetic
+// -- 1 + 2 * STEPS instructions instead of the 11 of the compiler's IEEE division, which must also serve denormals,
+// infinities and results that underflow.  tests/cpp/rcp_exact_check.hip compares the one-step and the two-step form with
+// `1.f / x` for EVERY fp32 bit pattern of that range on the GPU (v_rcp_f32 is this chip's, not a formula): none differs,
+// for either form; the GPU suite repeats the scan.  Only for call sites that can PROVE the range: the slab setup
+// of ref_visible, whose operand is clamped to FLT_EPSILON <= |x| <= 1.
+template <int STEPS = 1>
+RT_DEV float rcp_exact_normal(float x) {
+    float r = __builtin_amdgcn_rcpf(x);
+#pragma unroll
+    for (int k = 0; k < STEPS; k++) {
+        const float e = fmaf(-x, r, 1.f);
+        r = fmaf(e, r, r);
+    }
+    return r;
+}
 RT_DEV V3 reflect(V3 v, V3 n) { return sub(v, scale(n, 2.f * dot(v, n))); }  // vec3.cuh:71-73
 RT_DEV V3 refract4(V3 unit_v, V3 unit_n, float eta_ratio, float cos_theta) {  // vec3.cuh:82-86
     V3 v_parallel = scale(add(unit_v, scale(unit_n, cos_theta)), eta_ratio);

@@ -69,13 +69,81 @@ struct WalkResult {
     long long nodes = 0, tris = 0, leaves = 0;
     int max_sp = 0;
     bool failed = false;
+    float tie_t = -1.f;     // closest: the distance of the last EXACT tie between two accepted hits (a tie at the final t
+                            // is what the reference's tree order decides: triangle.cuh:49)
+    long long own_fail = 0, leaf_fail = 0;  // verified walks: hits whose own box / whose reference leaf box fails the reference's slab test
 };
+
+// ---- the reference's slab test (aabb_intersector.cuh:14-36), as reference_walk / ref_visible in rtcuda_amd.hip
+struct RefSlab {
+    bool nx, ny, nz;
+    V3 inv, so;
+    bool neg_zero;  // a direction component is -0.0: the octant (d < 0: false) and the sign of 1 / d disagree
+};
+inline bool is_neg_zero(float x) { uint32_t b; memcpy(&b, &x, 4); return b == 0x80000000u; }
+inline RefSlab ref_slab(V3 o, V3 d) {
+    RefSlab s;
+    s.nx = d.x < 0; s.ny = d.y < 0; s.nz = d.z < 0;
+    s.inv = inv_dir(d);
+    s.so = V3{(-o.x) * s.inv.x, (-o.y) * s.inv.y, (-o.z) * s.inv.z};
+    s.neg_zero = is_neg_zero(d.x) || is_neg_zero(d.y) || is_neg_zero(d.z);
+    return s;
+}
+// b = [xmin, xmax, ymin, ymax, zmin, zmax] (bounding_box.cuh:15)
+inline bool ref_box(const RefSlab &s, const float *b, float &entry) {
+    const float ex = s.inv.x * b[s.nx ? 1 : 0] + s.so.x;
+    const float ey = s.inv.y * b[s.ny ? 3 : 2] + s.so.y;
+    const float ez = s.inv.z * b[s.nz ? 5 : 4] + s.so.z;
+    entry = fmaxf(ex, fmaxf(ey, ez));
+    const float xx = s.inv.x * b[s.nx ? 0 : 1] + s.so.x;
+    const float xy = s.inv.y * b[s.ny ? 2 : 3] + s.so.y;
+    const float xz = s.inv.z * b[s.nz ? 4 : 5] + s.so.z;
+    return entry <= fminf(xx, fminf(xy, xz));
+}
+// What the reference's walk can SEE.  Its box test does not look at tmax (aabb_intersector.cuh:35), so whether it ever
+// reaches a triangle depends on the ray alone: every box on the way down to the triangle's leaf must pass.  Those
+// boxes are nested exactly (a node's box is the min / max of its triangles' boxes, bvh.cuh:57-61,150-160), rounding is
+// monotone, and a slab term inv * bound + so is a monotone function of the bound -- so (octants consistent with the
+// signs of 1 / d, i.e. no -0.0 component) a parent's entry distance is <= its child's and its exit distance >= its
+// child's: IF THE LEAF'S BOX PASSES, EVERY ANCESTOR'S PASSES.  The triangle's own box (triangle.cuh:22-37) lies inside
+// the leaf's, so a pass on it is a pass on the leaf: the common case needs no memory access at all.
+// The one case in which octant and sign of 1 / d disagree is a direction component of exactly -0.0: the nesting argument
+// does not hold then, and the ancestors are tested one by one through the parent links.
+struct RefView {
+    rtref::Tree tree;
+    std::vector<int> leaf_of;  // caller's triangle index -> node index of its leaf in the reference's tree
+    std::vector<int> parent;   // node -> parent node (root: -1)
+    bool root_leaf = true;
+};
+inline void own_box(const Tri &tr, float *b) {  // triangle.cuh:9-10,22-37 on the stored record
+    const V3 p1 = sub(tr.p0, tr.e1), p2{tr.p0.x + tr.e2.x, tr.p0.y + tr.e2.y, tr.p0.z + tr.e2.z};
+    b[0] = fminf(tr.p0.x, fminf(p1.x, p2.x)); b[1] = fmaxf(tr.p0.x, fmaxf(p1.x, p2.x));
+    b[2] = fminf(tr.p0.y, fminf(p1.y, p2.y)); b[3] = fmaxf(tr.p0.y, fmaxf(p1.y, p2.y));
+    b[4] = fminf(tr.p0.z, fminf(p1.z, p2.z)); b[5] = fmaxf(tr.p0.z, fmaxf(p1.z, p2.z));
+}
+inline bool ref_visible(const RefView &rv, const RefSlab &s, const Tri &tr, int caller_index, WalkResult &w) {
+    float b[6], e;
+    own_box(tr, b);
+    if (ref_box(s, b, e) && !s.neg_zero) return true;
+    w.own_fail++;
+    if (rv.root_leaf) return true;  // bvh.cuh:252 / :307: a root that is a leaf is intersected without a box test
+    int node = rv.leaf_of[(size_t)caller_index];
+    bool vis = ref_box(s, rv.tree.nodes[(size_t)node].box.b, e);
+    if (vis && s.neg_zero)
+        for (node = rv.parent[(size_t)node]; vis && node > 0; node = rv.parent[(size_t)node])  // (the root's own box is never tested)
+            vis = ref_box(s, rv.tree.nodes[(size_t)node].box.b, e);
+    if (!vis) w.leaf_fail++;
+    return vis;
+}
 // One ray through one of the two record formats.  wide: node = records cur, cur + 1 (children 0, 1 | 2, 3): the nearest
 // child the ray may enter becomes the cursor, the others are pushed in record order; 2-wide: near child, far child
 // pushed.  mode 0: closest hit (ties: the larger caller index, closest_hit_wins); mode 1: any hit but `excl`.
+// `rv` (verified walks, mode 1): an accepted hit only occludes if the reference's walk can see its triangle.
 WalkResult walk_ray(const std::vector<rtbvh::Pair> &rec, bool wide, const std::vector<Tri> &tris, const std::vector<int32_t> &order,
-                    int stack_entries, int mode, V3 o, V3 d, float tmax, int excl) {
+                    int stack_entries, int mode, V3 o, V3 d, float tmax, int excl, const RefView *rv = nullptr) {
     WalkResult w;
+    RefSlab slab{};
+    if (rv) slab = ref_slab(o, d);
     std::vector<int> stack(stack_entries + 8);
     const V3 inv = inv_dir(d);
     int sp = 0, cur = tris.empty() ? rtbvh::kNoChild : 0;
@@ -118,10 +186,13 @@ WalkResult walk_ray(const std::vector<rtbvh::Pair> &rec, bool wide, const std::v
                 w.tris++;
                 if (tri_hit(tris[k], o, d, tmax, t)) {
                     if (mode == 1) {
-                        if (k != excl) { w.occluded = true; break; }
-                    } else if (!(t == tmax && w.best >= 0) || order[k] > order[w.best]) {  // closest_hit_wins()
-                        tmax = t;
-                        w.best = k;
+                        if (k != excl && (!rv || ref_visible(*rv, slab, tris[k], order[k], w))) { w.occluded = true; break; }
+                    } else {
+                        if (t == tmax && w.best >= 0) w.tie_t = t;
+                        if (!(t == tmax && w.best >= 0) || order[k] > order[w.best]) {  // closest_hit_wins()
+                            tmax = t;
+                            w.best = k;
+                        }
                     }
                 }
             }
@@ -232,7 +303,54 @@ struct HostWalk {
     std::vector<int> inverse;  // original index -> leaf-order index
     bool wide = true;
     int n = 0;
+    RefView ref;               // the reference's own tree (rt_ref_tree.h), for the verified walks
 };
+// Bvh::traverse (bvh.cuh:251-303 / :306-357) over the reference's tree, as reference_walk in rtcuda_amd.hip: left child
+// before right child, a leaf child intersected on the spot, near inner child first by fp32 entry distance, the later
+// tested triangle wins t <= tmax.  best / excl: leaf-order indices of the product (as everywhere in this file).
+void literal_walk(const HostWalk &hw, int mode, V3 o, V3 d, float tmax, int excl, WalkResult &w) {
+    const rtref::Tree &t = hw.ref.tree;
+    w.best = -1;
+    w.occluded = false;
+    if (hw.n == 0) return;
+    auto leaf = [&](const rtref::Node &nd) -> bool {
+        for (int i = nd.link; i < nd.link + nd.count; i++) {
+            const int k = hw.inverse[(size_t)t.prims[(size_t)i]];
+            float tt;
+            if (tri_hit(hw.tris[(size_t)k], o, d, tmax, tt)) {
+                if (mode == 1) {
+                    if (k != excl) { w.occluded = true; return true; }
+                } else {
+                    tmax = tt;
+                    w.best = k;
+                }
+            }
+        }
+        return false;
+    };
+    if (t.nodes[0].count > 0) {
+        leaf(t.nodes[0]);
+    } else {
+        const RefSlab s = ref_slab(o, d);
+        int stk[64], sp = 0, left = t.nodes[0].link;
+        while (true) {
+            const rtref::Node &a = t.nodes[(size_t)left], &b = t.nodes[(size_t)left + 1];
+            float el, er;
+            bool gl = ref_box(s, a.box.b, el);
+            if (gl && a.count > 0) { if (leaf(a)) break; gl = false; }
+            bool gr = ref_box(s, b.box.b, er);
+            if (gr && b.count > 0) { if (leaf(b)) break; gr = false; }
+            if (gl && gr) {
+                const bool right_first = el > er;
+                stk[sp++] = right_first ? a.link : b.link;
+                left = right_first ? b.link : a.link;
+            } else if (gl) left = a.link;
+            else if (gr) left = b.link;
+            else { if (sp == 0) break; left = stk[--sp]; }
+        }
+    }
+    w.t = w.best >= 0 ? tmax : 0.f;
+}
 void *rt_hostwalk_create(const float *verts, int n) {
     HostWalk *w = new HostWalk();
     w->n = n;
@@ -242,6 +360,15 @@ void *rt_hostwalk_create(const float *verts, int n) {
     w->tris = leaf_order_triangles(verts, w->r, n);
     w->inverse.assign(n, 0);
     for (int k = 0; k < n; k++) w->inverse[w->r.order[k]] = k;
+    w->ref.tree = rtref::build(verts, n);
+    w->ref.root_leaf = w->ref.tree.nodes[0].count > 0 || n == 0;
+    w->ref.leaf_of.assign((size_t)std::max(n, 1), 0);
+    w->ref.parent.assign(w->ref.tree.nodes.size(), -1);
+    for (size_t k = 0; k < w->ref.tree.nodes.size(); k++) {
+        const rtref::Node &nd = w->ref.tree.nodes[k];
+        for (int i = nd.link; nd.count > 0 && i < nd.link + nd.count; i++) w->ref.leaf_of[(size_t)w->ref.tree.prims[(size_t)i]] = (int)k;
+        if (nd.count == 0 && n > 0) w->ref.parent[(size_t)nd.link] = w->ref.parent[(size_t)nd.link + 1] = (int)k;
+    }
     return w;
 }
 void rt_hostwalk_destroy(void *h) { delete (HostWalk *)h; }
@@ -281,6 +408,58 @@ int rt_hostwalk_trace(void *h, int mode, int n_rays, const float *o3, const floa
     g_walk_stats[1] += st_nodes;
     g_walk_stats[2] += st_tris;
     g_walk_stats[3] += st_leaves;
+    return failures;
+}
+// The DEFAULT kernels' decision procedure on the CPU (k_paths / k_trace with VERIFY): the product's own walk, then
+//   closest hit: the hit stands if the reference's walk can see its triangle (ref_visible) and no exact tie occurred at
+//                the final distance; otherwise -- about one ray in 10^7 -- the ray is re-traced by the literal walk;
+//   any hit:     an accepted hit occludes only if the reference's walk can see its triangle (no re-trace needed: "is
+//                there a visible accepted triangle" does not depend on the order of the search);
+//   (a ray with a -0.0 direction component: ref_visible tests every ancestor, see RefView).
+// The result must equal the reference's literal walk on EVERY ray (tests/test_traversal_audit.py).
+// stats6 += [rays, hits whose own box failed, hits whose leaf box failed (= hits the reference loses), exact ties at the
+// final distance, -0.0 rays, literal re-traces]
+int rt_hostwalk_trace_verified(void *h, int mode, int n_rays, const float *o3, const float *d3, const float *tmax_in,
+                               const int *excluded, int *out_i, float *out_t, long long *stats6) {
+    const HostWalk &w = *(const HostWalk *)h;
+    const rtbvh::Result &r = w.r;
+    const std::vector<rtbvh::Pair> &rec = w.wide ? r.quads : r.pairs;
+    const int stack_entries = w.wide ? r.stack_bound : r.pair_depth + 1;
+    int failures = 0;
+    long long own = 0, leafb = 0, ties = 0, negz = 0, lit = 0;
+#pragma omp parallel for schedule(dynamic, 1024) reduction(+ : failures, own, leafb, ties, negz, lit)
+    for (int i = 0; i < n_rays; i++) {
+        V3 o{o3[3 * i], o3[3 * i + 1], o3[3 * i + 2]}, d{d3[3 * i], d3[3 * i + 1], d3[3 * i + 2]};
+        const int excl = (mode == 1 && excluded[i] >= 0 && excluded[i] < w.n) ? w.inverse[excluded[i]] : -1;
+        const RefSlab s = ref_slab(o, d);
+        WalkResult res;
+        negz += s.neg_zero ? 1 : 0;
+        if (mode == 1) {
+            res = walk_ray(rec, w.wide, w.tris, r.order, stack_entries, 1, o, d, tmax_in[i], excl, &w.ref);
+        } else {
+            res = walk_ray(rec, w.wide, w.tris, r.order, stack_entries, 0, o, d, tmax_in[i], -1);
+            if (res.best >= 0) {
+                const bool tie = res.tie_t == res.t;
+                const bool seen = ref_visible(w.ref, s, w.tris[(size_t)res.best], r.order[(size_t)res.best], res);
+                ties += tie ? 1 : 0;
+                if (tie || !seen) {
+                    lit++;
+                    const bool failed = res.failed;
+                    literal_walk(w, 0, o, d, tmax_in[i], -1, res);
+                    res.failed = failed;
+                }
+            }
+        }
+        failures += res.failed ? 1 : 0;
+        own += res.own_fail; leafb += res.leaf_fail;
+        if (mode == 1) {
+            out_i[i] = res.occluded ? 1 : 0;
+        } else {
+            out_i[i] = res.best >= 0 ? r.order[res.best] : -1;
+            out_t[i] = res.t;
+        }
+    }
+    if (stats6) { stats6[0] += n_rays; stats6[1] += own; stats6[2] += leafb; stats6[3] += ties; stats6[4] += negz; stats6[5] += lit; }
     return failures;
 }
 // The reference's own tree as the product builds it for RT_FLAG_REFERENCE_WALK (rt_ref_tree.h), for a node-by-node

@@ -109,6 +109,11 @@ struct DScene {
     const float4 *ref_nodes;
     const int *ref_prims;
     int ref_n_prims;
+    // default kernels (VERIFY; null with RT_FLAG_WATERTIGHT): leaf-order triangle index -> the node of its leaf in the
+    // reference's tree, node -> parent node (root: -1), and whether that tree's root is a leaf (ref_visible)
+    const int *ref_leaf_of;
+    const int *ref_parent;
+    int ref_root_leaf;
 };
 __device__ __host__ inline int tab_off_lights(int n_mats) { return 5 * n_mats; }
 __device__ __host__ inline int tab_off_ltri(int n_mats, int n_lights) { return 5 * n_mats + 8 * n_lights; }
@@ -180,7 +185,12 @@ struct DCounters {
     int last_live_round;         // highest batch-closing round in which some slot still traced a ray
     unsigned int unused0;        // (round 3: the lockstep rounds' shade count, now per round in Context::d_lock)
     unsigned int pad2[2];
+    // VERIFY builds (rare events, global atomics): [0] accepted hits whose OWN box fails the reference's slab test,
+    // [1] ... whose reference leaf box (or, for a ray with a -0.0 direction component, some ancestor box) fails it too =
+    // hits the reference's walk loses, [2] closest hits with an exact tie at the final distance, [3] literal re-traces
+    unsigned long long vstat[4];
 };
+enum { V_OWN_FAIL = 0, V_LOST = 1, V_TIE = 2, V_LITERAL = 3 };
 enum { C_CAMERA = 0, C_SHADE, C_CLOSEST, C_ANY, C_EMIT, C_SHADOW_ADD, C_RR, C_UNUSED, C_COUNT };
 struct DWaveRow {
     unsigned long long c[C_COUNT];  // one 64-byte line per wave
@@ -1045,12 +1055,18 @@ __device__ inline bool ref_box(const RefSlab &s, float4 n0, float4 n1, float &en
     const float exit = fminf(xx, fminf(xy, xz));
     return entry <= exit;
 }
+// `stack` / `over` / `cap`: the lane's own traversal stack (LDS column + global overflow column, stack_push / stack_pop) --
+// free whenever this runs, since the lane's ray through the product's tree has ended or never started.  (Round 4 kept 32
+// entries in a private array: the compiler promoted it to 32 VGPRs indexed through select chains -- 227 VGPRs unconstrained,
+// 53 spilled at the 4-wave budget.)
 template <bool ANY>
-__device__ inline void reference_walk(const DScene &sc, V3 o, V3 d, float &tmax, int &tri, float &hu, float &hv) {
+__device__ inline void reference_walk(const DScene &sc, V3 o, V3 d, float &tmax, int &tri, float &hu, float &hv, int *stack,
+                                      int *over, int cap) {
     if (sc.ref_n_prims <= 0) return;
     const float4 *__restrict__ nodes = sc.ref_nodes;
     // true: the ray is finished (an occluder was found)
     auto leaf = [&](int first, int count) -> bool {
+#pragma nounroll
         for (int i = first; i < first + count; i++) {
             const int k = sc.ref_prims[i];
             const Tri tr = load_tri(sc.tris, k);
@@ -1079,10 +1095,10 @@ __device__ inline void reference_walk(const DScene &sc, V3 o, V3 d, float &tmax,
         }
     }
     const RefSlab s = ref_slab(o, d);
-    int stk[32];
     int sp = 0;
     int left = __float_as_int(nodes[1].w);
     // (a walk over a validated tree of n nodes ends after at most n / 2 pairs; the bound is a guard, not a schedule)
+#pragma nounroll
     for (int guard = 0; guard < (1 << 24); guard++) {
         const float4 a0 = nodes[2 * left], a1 = nodes[2 * left + 1], b0 = nodes[2 * left + 2], b1 = nodes[2 * left + 3];
         const int lcount = __float_as_int(a1.z), llink = __float_as_int(a1.w);
@@ -1100,8 +1116,7 @@ __device__ inline void reference_walk(const DScene &sc, V3 o, V3 d, float &tmax,
         }
         if (go_l && go_r) {
             const bool right_first = el > er;
-            stk[min(sp, 31)] = right_first ? llink : rlink;
-            sp++;
+            stack_push(stack, over, sp, cap, right_first ? llink : rlink);
             left = right_first ? rlink : llink;
         } else if (go_l) {
             left = llink;
@@ -1109,10 +1124,86 @@ __device__ inline void reference_walk(const DScene &sc, V3 o, V3 d, float &tmax,
             left = rlink;
         } else {
             if (sp == 0) break;
-            sp--;
-            left = stk[min(sp, 31)];
+            left = stack_pop(stack, over, sp, cap);
         }
     }
+}
+
+// ============================================================================ VERIFY: the reference's decisions on the product's walk
+// What the reference's walk can SEE is a function of the ray alone: its box test does not look at tmax
+// (aabb_intersector.cuh:35), so a leaf is reached iff every box on the way down to it passes `entry <= exit`, whatever has
+// been hit before.  Its closest hit is therefore the nearest accepted triangle AMONG THE VISIBLE ONES (ties: the one its
+// walk tests last, triangle.cuh:49), and a shadow ray is occluded iff a VISIBLE accepted triangle other than the target
+// exists -- definitions that any search order over any acceleration structure can evaluate.  And visibility is cheap:
+//   * the boxes along a root-to-leaf path are nested exactly (a node's box is the min / max of its triangles' boxes:
+//     bvh.cuh:57-61,150-160); fp32 rounding is monotone, so each slab term inv * bound + scaled_origin is a monotone
+//     function of the bound, non-decreasing for inv > 0 and non-increasing for inv < 0; with the octant chosen by the
+//     sign of d (aabb_intersector.cuh:14-16) the near bound of a parent gives an entry distance <= its child's and the
+//     far bound an exit distance >= its child's.  Hence: IF THE LEAF'S BOX PASSES, EVERY ANCESTOR'S PASSES -- a triangle
+//     is visible iff its LEAF's box passes the reference's test (nothing is assumed about the size of any rounding error);
+//   * the triangle's own box (triangle.cuh:22-37) lies inside its leaf's, so a pass on the own box -- computed from the
+//     record that is in registers anyway -- is a pass on the leaf's: the common case costs no memory access.  Only when
+//     the own box fails (flat boxes of axis-aligned triangles hit on their rim: ~1 hit in 10^7) is the leaf's box fetched;
+//   * the one case in which octant and sign of 1 / d disagree is a direction component of exactly -0.0 (d < 0 is false,
+//     1 / copysign(eps, -0.0) is negative): the nesting argument does not hold then and the ancestors are tested one by
+//     one through the parent links.
+// So the default kernels keep their own tree, node format, speculation and scheduling and still return the reference's
+// answers: a shadow ray's accepted hit only counts if its triangle is visible (k_paths / k_trace: `ref_visible` where
+// `occluded` is about to be set), and a finished path ray's closest hit T is checked once, in the block that shades it
+// anyway: T visible and no exact tie at the final distance  =>  T is the reference's closest hit (T is the nearest
+// accepted triangle of ALL, so also of the visible ones).  The rest -- T invisible (the nearest VISIBLE hit is needed)
+// or a tie (the reference's test order decides) -- is ~2 rays in 10^7 and is re-traced by reference_walk behind a
+// rare branch.  tests/test_traversal_audit.py replays > 4 * 10^7 rays of literal oracle renders through the CPU twin of
+// exactly this procedure (rt_host_check.cpp): equal on every ray; the GPU suite holds whole frames to the LITERAL
+// oracle's fixed-point image bit for bit.
+__device__ __forceinline__ bool neg_zero3(V3 d) {
+    return __float_as_uint(d.x) == 0x80000000u || __float_as_uint(d.y) == 0x80000000u || __float_as_uint(d.z) == 0x80000000u;
+}
+__device__ __forceinline__ bool ref_visible(const DScene &sc, V3 o, V3 d, const Tri &tr, int k,
+                                            unsigned long long *__restrict__ vstat) {
+    // the reference's slab setup (aabb_intersector.cuh:17-21): 1 / d with |d| clamped away from 0 -- the operand is a
+    // unit vector's component, FLT_EPSILON <= |x| <= 1, where rcp_exact_normal IS the IEEE quotient (rt_device.h) -- and
+    // the scaled origin (-o) * (1 / d)
+    const V3 inv = mk(rcp_exact_normal((fabsf(d.x) < kFltEps) ? copysignf(kFltEps, d.x) : d.x),
+                      rcp_exact_normal((fabsf(d.y) < kFltEps) ? copysignf(kFltEps, d.y) : d.y),
+                      rcp_exact_normal((fabsf(d.z) < kFltEps) ? copysignf(kFltEps, d.z) : d.z));
+    const V3 so = mul(neg(o), inv);
+    // the triangle's own box (triangle.cuh:9-10,22-37)
+    const V3 p1 = sub(tr.p0, tr.e1), p2 = add(tr.p0, tr.e2);
+    const float lox = fminf(tr.p0.x, fminf(p1.x, p2.x)), hix = fmaxf(tr.p0.x, fmaxf(p1.x, p2.x));
+    const float loy = fminf(tr.p0.y, fminf(p1.y, p2.y)), hiy = fmaxf(tr.p0.y, fmaxf(p1.y, p2.y));
+    const float loz = fminf(tr.p0.z, fminf(p1.z, p2.z)), hiz = fmaxf(tr.p0.z, fmaxf(p1.z, p2.z));
+    // aabb_intersector.cuh:24-35: inv * bound + scaled_origin, a multiplication and an addition rounded one by one.  The
+    // reference picks the near / far bound by the octant; with the octant consistent with the sign of 1 / d (no -0.0
+    // component) the near bound's term is the smaller of the two (monotone rounding again), so min / max pick the same
+    // values without the three compares and six selects
+    const float tlx = inv.x * lox + so.x, thx = inv.x * hix + so.x;
+    const float tly = inv.y * loy + so.y, thy = inv.y * hiy + so.y;
+    const float tlz = inv.z * loz + so.z, thz = inv.z * hiz + so.z;
+    const float entry = fmaxf(fminf(tlx, thx), fmaxf(fminf(tly, thy), fminf(tlz, thz)));
+    const float exit = fminf(fmaxf(tlx, thx), fminf(fmaxf(tly, thy), fmaxf(tlz, thz)));
+    bool vis = entry <= exit && !neg_zero3(d);
+    if (!vis) {  // rare (~1 hit in 10^7): the literal forms from here on
+        atomicAdd(&vstat[V_OWN_FAIL], 1ull);
+        vis = sc.ref_root_leaf != 0;  // bvh.cuh:252 / :307: a root that is a leaf is intersected without any box test
+        if (!vis) {
+            const RefSlab s = ref_slab(o, d);
+            float e;
+            int node = sc.ref_leaf_of[(unsigned)k];
+            vis = ref_box(s, sc.ref_nodes[2 * node], sc.ref_nodes[2 * node + 1], e);
+            if (vis && neg_zero3(d)) {  // no nesting argument for this ray: every ancestor below the root (the root's box is never tested)
+#pragma nounroll
+                for (int guard = 0; guard < 64 && vis; guard++) {
+                    node = sc.ref_parent[(unsigned)node];
+                    if (node <= 0) break;
+                    vis = ref_box(s, sc.ref_nodes[2 * node], sc.ref_nodes[2 * node + 1], e);
+                }
+            }
+            if (!vis) atomicAdd(&vstat[V_LOST], 1ull);
+        }
+        __asm__ volatile("" ::: "memory");
+    }
+    return vis;
 }
 
 enum { MODE_POOL = 0, MODE_TEST_CLOSEST = 2, MODE_TEST_ANY = 3 };
@@ -1132,6 +1223,7 @@ struct TraceParams {
     const int *order, *excluded;
     int *out_i;
     float *out_t, *out_u, *out_v;
+    unsigned long long *vstat;  // VERIFY builds: DCounters::vstat
 };
 
 // MODE_POOL traces BOTH ray kinds of a round in one launch: the path ray of every live slot
@@ -1143,7 +1235,8 @@ struct TraceParams {
 // also times the builds with 80 / 96 / 128 VGPRs).
 // LITERAL (RT_FLAG_REFERENCE_WALK): a lane traverses its whole ray with reference_walk -- the scheduling around it
 // (chunks, refill, finalisation) is unchanged, WIDE is not looked at.
-template <int MODE, bool WIDE, int MINW = 8, bool LITERAL = false>
+// VERIFY (the default; off with RT_FLAG_WATERTIGHT): the product's walk with the reference's decisions -- see ref_visible.
+template <int MODE, bool WIDE, int MINW = 8, bool LITERAL = false, bool VERIFY = false>
 __global__ void __launch_bounds__(kBlock, MINW) k_trace(DScene sc, DPools p, TraceParams tp, int stack_cap, int *overflow) {
     if (MODE == MODE_POOL && tp.lock_shades != nullptr && tp.lock_round >= 1 && tp.lock_shades[tp.lock_round] == 0u) return;
     extern __shared__ int s_lds[];
@@ -1192,6 +1285,24 @@ __global__ void __launch_bounds__(kBlock, MINW) k_trace(DScene sc, DPools p, Tra
             pf_fin_lanes += wave_count((fin));
 #endif
             const bool is_any = MODE == MODE_POOL ? (id & kAnyBit) != 0 : MODE == MODE_TEST_ANY;
+            if (VERIFY && !LITERAL && fin && !is_any && tri >= 0) {
+                // the closest hit stands if the reference's walk can see its triangle and nothing tied with it at the final
+                // distance (the sign of hv: see the leaf phase); otherwise (~2 rays in 10^7) the ray is re-traced literally
+                bool bad = (__float_as_uint(hv) >> 31) != 0u;
+                if (bad) {
+                    atomicAdd(&tp.vstat[V_TIE], 1ull);
+                } else {
+                    const Tri tr = load_tri(sc.tris, tri);
+                    bad = !ref_visible(sc, o, d, tr, tri, tp.vstat);
+                }
+                if (bad) {
+                    atomicAdd(&tp.vstat[V_LITERAL], 1ull);
+                    tmax = MODE == MODE_POOL ? kFltMax : tp.tmax[id & (kAnyBit - 1)];
+                    tri = -1;
+                    hu = hv = 0.f;
+                    reference_walk<false>(sc, o, d, tmax, tri, hu, hv, stack, over, stack_cap);
+                }
+            }
             if (MODE == MODE_POOL) deposits += wave_count((fin && is_any && hu == 0.f));
             if (fin) {
                 const int slot = id & (kAnyBit - 1);
@@ -1293,8 +1404,8 @@ __global__ void __launch_bounds__(kBlock, MINW) k_trace(DScene sc, DPools p, Tra
         if (LITERAL) {
             if (cur >= 0) {
                 const bool is_any = MODE == MODE_POOL ? (id & kAnyBit) != 0 : MODE == MODE_TEST_ANY;
-                if (is_any) reference_walk<true>(sc, o, d, tmax, tri, hu, hv);
-                else reference_walk<false>(sc, o, d, tmax, tri, hu, hv);
+                if (is_any) reference_walk<true>(sc, o, d, tmax, tri, hu, hv, stack, over, stack_cap);
+                else reference_walk<false>(sc, o, d, tmax, tri, hu, hv, stack, over, stack_cap);
                 cur = kEntryDone;
             }
             continue;
@@ -1332,16 +1443,24 @@ __global__ void __launch_bounds__(kBlock, MINW) k_trace(DScene sc, DPools p, Tra
                 float t, u, v;
                 if (tri_intersect(tr, o, d, tmax, t, u, v)) {
                     if (is_any) {
-                        if (k != tri) {  // bvh.cuh:243: first accepted hit that is not the excluded triangle
+                        // bvh.cuh:243: first accepted hit that is not the excluded triangle (VERIFY: and that the reference's
+                        // walk can see at all)
+                        if (k != tri && (!VERIFY || ref_visible(sc, o, d, tr, k, tp.vstat))) {
                             hu = 1.f;    // occluded
                             stop = true;
                             break;
                         }
-                    } else if (closest_hit_wins(sc, t, tmax, k, tri)) {  // bvh.cuh:227-231 (t <= tmax)
-                        tmax = t;
-                        hu = u;
-                        hv = v;
-                        tri = k;
+                    } else {
+                        const bool tie = t == tmax && tri >= 0;
+                        if (closest_hit_wins(sc, t, tmax, k, tri)) {  // bvh.cuh:227-231 (t <= tmax)
+                            tmax = t;
+                            hu = u;
+                            hv = v;
+                            tri = k;
+                        }
+                        // VERIFY: an exact tie is the reference's tree order to decide (triangle.cuh:49): marked in the
+                        // sign of hv (v >= 0 for an accepted hit; a closer hit later overwrites the mark with its own v)
+                        if (VERIFY && tie) hv = __uint_as_float(__float_as_uint(hv) | 0x80000000u);
                     }
                 }
             }
@@ -1426,12 +1545,16 @@ constexpr bool kSpeculate = RT_SPECULATE != 0;  // k_paths: postpone a leaf reac
 // LITERAL (RT_FLAG_REFERENCE_WALK): the node block is a lane's WHOLE ray through reference_walk -- the reference's tree,
 // box test, order and tie rule; no triangle blocks, no speculation.  Everything around it (phases, ADV / GEN blocks, the
 // sample accumulator) is the same code.  Opt-in and never timed.
-template <bool LDS_TABLES, bool WIDE, bool MAJORITY, int MIN_WAVES, bool DRAW_CIDS = false, bool LITERAL = false>
+// VERIFY (the default build; off with RT_FLAG_WATERTIGHT): the reference's decisions on this kernel's own walk (see
+// ref_visible): a shadow ray's accepted hit counts only if the reference's walk can see its triangle (triangle block); a
+// path ray's closest hit is checked once, at the top of the ADV block that shades it -- visible, and no exact tie at the
+// final distance -- and the ~2 rays in 10^7 that fail are re-traced there by reference_walk.
+template <bool LDS_TABLES, bool WIDE, bool MAJORITY, int MIN_WAVES, bool DRAW_CIDS = false, bool LITERAL = false, bool VERIFY = false>
 __global__ void __launch_bounds__(kBlock, MIN_WAVES)
 k_paths(DScene sc, DPools p, Camera cam_arg, AdvanceParams ap_arg, float *__restrict__ fb, DWaveRow *__restrict__ rows,
         int stack_cap, int *overflow, int adv_batch, int debug_no_deposit, unsigned long long *prof, int top_n,
         int prio_period, int rot_wave, int rot_set, int gen_batch, int tri_follow, unsigned int *__restrict__ next_cid,
-        int half_fill) {
+        int half_fill, unsigned long long *__restrict__ vstat) {
     // The GEN block exists where the chip is short of issue slots (4 waves per SIMD): there it takes a third of the
     // lanes out of the long ADV block (+3 %, and the ADV block no longer spills).  On small shards (2 waves per
     // SIMD) a slot-round is a latency chain and one more block in it costs 5 %: gen() stays inside ADV there.
@@ -1759,23 +1882,45 @@ k_paths(DScene sc, DPools p, Camera cam_arg, AdvanceParams ap_arg, float *__rest
             out.did_gen = out.did_shade = out.has_shadow = out.did_emit = out.new_ray = false;
             out.rr_draws = 0;
             if (phase == PH_ADV) {
-                cold_load();  // the slot state is only live between here and cold_save() below
+                // the slot state is only live between cold_load() and cold_save() below
+                cold_load();
                 SlotState st;
-                st.bounces = bounces;
-                st.pixel = pixel;
-                st.gen = gen;
-                st.rs = rs;
-                st.beta = beta;
                 st.wo = d;
                 st.hit_info = -1;
                 st.isect_p = st.isect_n = mk(0, 0, 0);
                 if (tri >= 0) {  // hit record in the form mat() consumes (render.cuh:152-153, 311-316)
                     Tri tr = load_tri(sc.tris, tri);
                     float4 sh = sc.tri_shade[(unsigned)tri];
-                    st.isect_p = tri_point(tr, hu, hv);
-                    st.isect_n = mk(sh.x, sh.y, sh.z);
-                    st.hit_info = __float_as_int(sh.w);
+                    if (VERIFY) {
+                        // (o, d) are still the path ray that ended on `tri`.  A set sign bit of hv: an exact tie at the final
+                        // distance (triangle block) -- or a v of -0.0, which costs a needless, equally exact re-trace
+                        bool bad = (__float_as_uint(hv) >> 31) != 0u;
+                        if (bad) atomicAdd(&vstat[V_TIE], 1ull);
+                        else bad = !ref_visible(sc, o, d, tr, tri, vstat);
+                        if (bad) {
+                            atomicAdd(&vstat[V_LITERAL], 1ull);
+                            float tm = kFltMax;
+                            tri = -1;
+                            hu = hv = 0.f;
+                            reference_walk<false>(sc, o, d, tm, tri, hu, hv, stack, over, stack_cap);
+                            cold_load();  // (again: what was loaded above need not stay in registers across the walk)
+                            if (tri >= 0) {
+                                tr = load_tri(sc.tris, tri);
+                                sh = sc.tri_shade[(unsigned)tri];
+                            }
+                        }
+                    }
+                    if (!VERIFY || tri >= 0) {
+                        st.isect_p = tri_point(tr, hu, hv);
+                        st.isect_n = mk(sh.x, sh.y, sh.z);
+                        st.hit_info = __float_as_int(sh.w);
+                    }
                 }
+                st.bounces = bounces;
+                st.pixel = pixel;
+                st.gen = gen;
+                st.rs = rs;
+                st.beta = beta;
                 advance_core<SPLIT_GEN, true, true>(sc, tab, cam, ap, ap.slot_lo + i, st, out, fb, acc);
                 bounces = st.bounces;
                 pixel = st.pixel;
@@ -1848,8 +1993,8 @@ k_paths(DScene sc, DPools p, Camera cam_arg, AdvanceParams ap_arg, float *__rest
 #endif
             if (LITERAL) {
                 if (want) {
-                    if (is_any) reference_walk<true>(sc, o, d, tmax, tri, hu, hv);
-                    else reference_walk<false>(sc, o, d, tmax, tri, hu, hv);
+                    if (is_any) reference_walk<true>(sc, o, d, tmax, tri, hu, hv, stack, over, stack_cap);
+                    else reference_walk<false>(sc, o, d, tmax, tri, hu, hv, stack, over, stack_cap);
                     cur = kEntryDone;
                 }
             } else if (want) {
@@ -1924,8 +2069,16 @@ k_paths(DScene sc, DPools p, Camera cam_arg, AdvanceParams ap_arg, float *__rest
                         float t, u, v;
                         const bool hit = tri_intersect(tr[j], o, d, tmax, t, u, v);
                         occluded = hit && is_any && ks[j] != tri;
+                        // VERIFY: ... and only if the reference's walk can see that triangle (2 % of the shadow rays get here)
+                        if (VERIFY && occluded) occluded = ref_visible(sc, o, d, tr[j], ks[j], vstat);
                         bool better = hit && !is_any;
-                        if (better && t == tmax && tri >= 0) better = sc.order[(unsigned)ks[j]] > sc.order[(unsigned)tri];
+                        if (better && t == tmax && tri >= 0) {
+                            better = sc.order[(unsigned)ks[j]] > sc.order[(unsigned)tri];
+                            if (VERIFY) {  // an exact tie: whichever of the two stays, its hv carries the mark (see the ADV block)
+                                v = __uint_as_float(__float_as_uint(v) | 0x80000000u);
+                                hv = __uint_as_float(__float_as_uint(hv) | 0x80000000u);
+                            }
+                        }
                         tmax = better ? t : tmax;
                         hu = occluded ? 1.f : (better ? u : hu);
                         hv = better ? v : hv;
@@ -2503,7 +2656,11 @@ struct rt_scene {
     mutable bool ref_ready = false;
     mutable float4 *d_ref_nodes = nullptr;
     mutable int *d_ref_prims = nullptr;
+    mutable int *d_ref_leaf_of = nullptr;  // leaf-order triangle index -> node of its leaf in the reference's tree (ref_visible)
+    mutable int *d_ref_parent = nullptr;   // node -> parent node (root: -1)
     mutable int ref_nodes_count = 0, ref_depth = 0;
+    mutable bool ref_root_leaf = true;
+    mutable double build_seconds_ref = 0.0;  // host time of the reference-tree build + upload (one-off, first render that needs it)
     rt_scene() = default;
     rt_scene(const rt_scene &) = delete;
     rt_scene &operator=(const rt_scene &) = delete;
@@ -2519,6 +2676,8 @@ struct rt_scene {
         (void)hipFree(d_tables);
         (void)hipFree(d_ref_nodes);
         (void)hipFree(d_ref_prims);
+        (void)hipFree(d_ref_leaf_of);
+        (void)hipFree(d_ref_parent);
     }
     DScene dev() const {
         DScene s;
@@ -2536,6 +2695,9 @@ struct rt_scene {
         s.ref_nodes = d_ref_nodes;
         s.ref_prims = d_ref_prims;
         s.ref_n_prims = ref_ready ? n_tris : 0;
+        s.ref_leaf_of = d_ref_leaf_of;
+        s.ref_parent = d_ref_parent;
+        s.ref_root_leaf = ref_root_leaf ? 1 : 0;
         return s;
     }
 };
@@ -2685,6 +2847,7 @@ bool validate_quads(const std::vector<rtbvh::Pair> &quads, int n_tris) {
 int ensure_ref_tree(const rt_scene *scene) {
     std::lock_guard<std::mutex> lock(scene->ref_mutex);
     if (scene->ref_ready) return 0;
+    const auto t_begin = std::chrono::steady_clock::now();
     const int n = scene->n_tris;
     if ((int)scene->h_tri9.size() != 9 * n) return fail("RT_FLAG_REFERENCE_WALK: the scene holds no triangle copy");
     const rtref::Tree t = rtref::build(scene->h_tri9.data(), n);
@@ -2720,23 +2883,40 @@ int ensure_ref_tree(const rt_scene *scene) {
     }
     std::vector<int> prim_leaf((size_t)std::max(n, 1), 0);  // reference primitive position -> this scene's leaf-order index
     for (int i = 0; i < n; i++) prim_leaf[i] = scene->h_inverse[t.prims[i]];
-    float4 *dn = nullptr;
-    int *dp = nullptr;
-    HIP_TRY(hipMalloc((void **)&dn, sizeof(rtref::Node) * (size_t)std::max(nn, 1)));
-    if (hipMalloc((void **)&dp, sizeof(int) * prim_leaf.size()) != hipSuccess) {
-        (void)hipFree(dn);
-        return fail("RT_FLAG_REFERENCE_WALK: out of device memory");
+    // what ref_visible reads: the leaf of every triangle (leaf-order index -> node) and the way up from there
+    std::vector<int> leaf_of((size_t)std::max(n, 1), 0), parent((size_t)std::max(nn, 1), -1);
+    for (int k = 0; k < nn; k++) {
+        const rtref::Node &nd = t.nodes[(size_t)k];
+        if (nd.count > 0) {
+            for (int i = nd.link; i < nd.link + nd.count; i++) leaf_of[(size_t)prim_leaf[(size_t)i]] = k;
+        } else if (n > 0) {
+            parent[(size_t)nd.link] = parent[(size_t)nd.link + 1] = k;
+        }
     }
-    if (hipMemcpy(dn, t.nodes.data(), sizeof(rtref::Node) * (size_t)nn, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(dp, prim_leaf.data(), sizeof(int) * prim_leaf.size(), hipMemcpyHostToDevice) != hipSuccess) {
+    float4 *dn = nullptr;
+    int *dp = nullptr, *dl = nullptr, *dpar = nullptr;
+    if (hipMalloc((void **)&dn, sizeof(rtref::Node) * (size_t)std::max(nn, 1)) != hipSuccess ||
+        hipMalloc((void **)&dp, sizeof(int) * prim_leaf.size()) != hipSuccess ||
+        hipMalloc((void **)&dl, sizeof(int) * leaf_of.size()) != hipSuccess ||
+        hipMalloc((void **)&dpar, sizeof(int) * parent.size()) != hipSuccess ||
+        hipMemcpy(dn, t.nodes.data(), sizeof(rtref::Node) * (size_t)nn, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(dp, prim_leaf.data(), sizeof(int) * prim_leaf.size(), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(dl, leaf_of.data(), sizeof(int) * leaf_of.size(), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(dpar, parent.data(), sizeof(int) * parent.size(), hipMemcpyHostToDevice) != hipSuccess) {
         (void)hipFree(dn);
         (void)hipFree(dp);
-        return fail("RT_FLAG_REFERENCE_WALK: upload failed");
+        (void)hipFree(dl);
+        (void)hipFree(dpar);
+        return fail("reference tree: device allocation or upload failed");
     }
     scene->d_ref_nodes = dn;
     scene->d_ref_prims = dp;
+    scene->d_ref_leaf_of = dl;
+    scene->d_ref_parent = dpar;
+    scene->ref_root_leaf = n == 0 || t.nodes[0].count > 0;
     scene->ref_nodes_count = nn;
     scene->ref_depth = t.depth;
+    scene->build_seconds_ref = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
     scene->ref_ready = true;
     return 0;
 }
@@ -2912,10 +3092,13 @@ static bool sort_shade() {
         if (wide) hipLaunchKernelGGL((k_trace<MODE, true>), grid, dim3(kBlock), lds, stream, __VA_ARGS__);   \
         else hipLaunchKernelGGL((k_trace<MODE, false>), grid, dim3(kBlock), lds, stream, __VA_ARGS__);       \
     } while (0)
-// ... or, with RT_FLAG_REFERENCE_WALK, the build that walks the reference's tree (the node format does not matter then)
-#define RT_LAUNCH_TRACE_REF(MODE, literal, wide, grid, lds, stream, ...)                                                  \
+// ... or, with RT_FLAG_REFERENCE_WALK, the build that walks the reference's tree (the node format does not matter then);
+// `verify`: the default build -- the product's walk with the reference's decisions (ref_visible); neither: RT_FLAG_WATERTIGHT
+#define RT_LAUNCH_TRACE_REF(MODE, literal, verify, wide, grid, lds, stream, ...)                                          \
     do {                                                                                                                  \
         if (literal) hipLaunchKernelGGL((k_trace<MODE, false, 8, true>), grid, dim3(kBlock), lds, stream, __VA_ARGS__);     \
+        else if ((verify) && (wide)) hipLaunchKernelGGL((k_trace<MODE, true, 8, false, true>), grid, dim3(kBlock), lds, stream, __VA_ARGS__); \
+        else if (verify) hipLaunchKernelGGL((k_trace<MODE, false, 8, false, true>), grid, dim3(kBlock), lds, stream, __VA_ARGS__); \
         else RT_LAUNCH_TRACE(MODE, wide, grid, lds, stream, __VA_ARGS__);                                                 \
     } while (0)
 
@@ -2981,6 +3164,10 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
     const bool per_sample = (flags & RT_FLAG_RNG_PER_SAMPLE) != 0;
     const bool literal = (flags & RT_FLAG_REFERENCE_WALK) != 0;
     if (literal && per_sample) return fail("rt_render_shard: RT_FLAG_REFERENCE_WALK is a parity mode and RT_FLAG_RNG_PER_SAMPLE is not: pick one");
+    if (literal && (flags & RT_FLAG_WATERTIGHT)) return fail("rt_render_shard: RT_FLAG_REFERENCE_WALK and RT_FLAG_WATERTIGHT exclude each other");
+    // the default: the reference's decisions (which hits its walk can see, who wins a tie) on the product's own walk.  The
+    // per-sample mode is not the reference's image anyway and keeps the triangle-list definition.
+    const bool verify = !literal && !per_sample && (flags & RT_FLAG_WATERTIGHT) == 0;
     if (per_sample) {
         if (spp % shard_count != 0) return fail("rt_render_shard: RT_FLAG_RNG_PER_SAMPLE needs num_samples divisible by shard_count");
         spp /= shard_count;
@@ -2991,7 +3178,7 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
     if (dev != scene->device) return fail("rt_render_shard: scene was created on another device");
-    if (literal && ensure_ref_tree(scene)) return 1;
+    if ((literal || verify) && ensure_ref_tree(scene)) return 1;
     const int n = per_sample ? kW : kW / shard_count;
     const int slot_lo = per_sample ? 0 : shard_index * n;
     Context *cp = nullptr;
@@ -3006,10 +3193,8 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
     Camera cam;
     memcpy(&cam, camera, sizeof(Camera));
     {
-        DCounters zero;
+        DCounters zero{};
         zero.last_live_round = -1;
-        zero.unused0 = 0;
-        zero.pad2[0] = zero.pad2[1] = 0;
         c.h_ctr[0] = zero;  // pinned staging
         HIP_TRY(hipMemcpyAsync(c.d_ctr, &c.h_ctr[0], sizeof(DCounters), hipMemcpyHostToDevice, st));
         HIP_TRY(hipMemsetAsync(c.d_rows, 0, sizeof(DWaveRow) * (size_t)c.n_rows, st));
@@ -3019,7 +3204,9 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
     const size_t lds_bytes = sizeof(int) * (size_t)kBlock * (size_t)(stack_cap + 2);  // stack (+ 1 row: push_if) + pending
     // one buffer serves the context's k_trace and k_paths grids (never in flight together); k_paths keeps fewer
     // entries in LDS, so it needs the deeper overflow
-    if (ensure_overflow(c.d_over, c.over_levels, scene->stack_bound - std::min(stack_cap, lds_stack_cap(scene, 8)))) return 1;
+    // (the literal walk of the reference's tree -- depth <= 30 -- borrows the lane's stack: reference_walk)
+    const int stack_need = std::max(scene->stack_bound, (literal || verify) ? 32 : 0);
+    if (ensure_overflow(c.d_over, c.over_levels, stack_need - std::min(stack_cap, lds_stack_cap(scene, 8)))) return 1;
     int *const d_over = c.d_over;
     // Slots of this shard that ever get a camera ray: slot s serves the camera rays s, s + W, ..., so in a frame of fewer than
     // W camera rays the slots from cam_end on never do anything -- the kernels of such a frame (it is nothing but the
@@ -3092,6 +3279,7 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
     tpp.rows = c.d_rows;
     tpp.debug_no_deposit = (flags & 0x100u) ? 1 : 0;
     tpp.fb_fixed = (flags & kFlagFixedFb) ? 1 : 0;
+    tpp.vstat = &c.d_ctr->vstat[0];
 #ifdef RT_TRACE_PROFILE
     unsigned long long *d_prof = nullptr;
     HIP_TRY(hipMalloc((void **)&d_prof, sizeof(unsigned long long) * 16));
@@ -3197,14 +3385,19 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
         HIP_TRY(hipEventRecord(c.ev_a, st));
 // MIN_WAVES: 4 waves per SIMD (at most 128 VGPRs) when the grid fills the chip, 2 (up to 256 VGPRs) when the
         // shard is so small that only 2 workgroups per CU exist anyway (8-GPU runs)
-#define RT_LAUNCH_PATHS(T, WD, MJ)                                                                                     \
+#define RT_LAUNCH_PATHS_V(T, WD, MJ, VER)                                                                              \
     do {                                                                                                               \
         if (few_blocks)                                                                                                \
-            hipLaunchKernelGGL((k_paths<T, WD, MJ, 2>), grid_paths, block, lds_paths, st, sc, c.pools, cam, ap, d_sum,   \
-                               c.d_rows, paths_cap, d_over2, adv_batch, dbg, paths_prof, top_n, prio_rotate, rot_wave, rot_set, gen_batch, tri_follow, &c.d_ctr->pad2[0], half_fill); \
+            hipLaunchKernelGGL((k_paths<T, WD, MJ, 2, false, false, VER>), grid_paths, block, lds_paths, st, sc, c.pools, cam, ap, d_sum,   \
+                               c.d_rows, paths_cap, d_over2, adv_batch, dbg, paths_prof, top_n, prio_rotate, rot_wave, rot_set, gen_batch, tri_follow, &c.d_ctr->pad2[0], half_fill, &c.d_ctr->vstat[0]); \
         else                                                                                                           \
-            hipLaunchKernelGGL((k_paths<T, WD, MJ, 4>), grid_paths, block, lds_paths, st, sc, c.pools, cam, ap, d_sum,   \
-                               c.d_rows, paths_cap, d_over2, adv_batch, dbg, paths_prof, 0, prio_rotate, rot_wave, rot_set, gen_batch, tri_follow, &c.d_ctr->pad2[0], half_fill);     \
+            hipLaunchKernelGGL((k_paths<T, WD, MJ, 4, false, false, VER>), grid_paths, block, lds_paths, st, sc, c.pools, cam, ap, d_sum,   \
+                               c.d_rows, paths_cap, d_over2, adv_batch, dbg, paths_prof, 0, prio_rotate, rot_wave, rot_set, gen_batch, tri_follow, &c.d_ctr->pad2[0], half_fill, &c.d_ctr->vstat[0]);     \
+    } while (0)
+#define RT_LAUNCH_PATHS(T, WD, MJ)                 \
+    do {                                           \
+        if (verify) RT_LAUNCH_PATHS_V(T, WD, MJ, true); \
+        else RT_LAUNCH_PATHS_V(T, WD, MJ, false);  \
     } while (0)
         if (literal) {
             // RT_FLAG_REFERENCE_WALK: the build whose node block is the reference's own walk
@@ -3214,10 +3407,10 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
     do {                                                                                                               \
         if (few_blocks)                                                                                                \
             hipLaunchKernelGGL((k_paths<T, false, true, 2, false, true>), grid_paths, block, lds_paths, st, sc, c.pools, cam, ap, d_sum, \
-                               c.d_rows, paths_cap, d_over2, adv_batch, dbg, paths_prof, 0, prio_rotate, rot_wave, rot_set, gen_batch, tri_follow, &c.d_ctr->pad2[0], half_fill); \
+                               c.d_rows, paths_cap, d_over2, adv_batch, dbg, paths_prof, 0, prio_rotate, rot_wave, rot_set, gen_batch, tri_follow, &c.d_ctr->pad2[0], half_fill, &c.d_ctr->vstat[0]); \
         else                                                                                                           \
             hipLaunchKernelGGL((k_paths<T, false, true, 4, false, true>), grid_paths, block, lds_paths, st, sc, c.pools, cam, ap, d_sum, \
-                               c.d_rows, paths_cap, d_over2, adv_batch, dbg, paths_prof, 0, prio_rotate, rot_wave, rot_set, gen_batch, tri_follow, &c.d_ctr->pad2[0], half_fill); \
+                               c.d_rows, paths_cap, d_over2, adv_batch, dbg, paths_prof, 0, prio_rotate, rot_wave, rot_set, gen_batch, tri_follow, &c.d_ctr->pad2[0], half_fill, &c.d_ctr->vstat[0]); \
     } while (0)
             if (lds_tables) RT_LAUNCH_REF(true);
             else RT_LAUNCH_REF(false);
@@ -3226,7 +3419,7 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
             // per-sample streams: the build in which the waves draw their camera rays from the frame's counter
 #define RT_LAUNCH_DRAW(T, WD)                                                                                          \
     hipLaunchKernelGGL((k_paths<T, WD, true, 4, true>), grid_paths, block, lds_paths, st, sc, c.pools, cam, ap, d_sum,  \
-                       c.d_rows, paths_cap, d_over2, adv_batch, dbg, paths_prof, 0, prio_rotate, rot_wave, rot_set, gen_batch, tri_follow, &c.d_ctr->pad2[0], half_fill)
+                       c.d_rows, paths_cap, d_over2, adv_batch, dbg, paths_prof, 0, prio_rotate, rot_wave, rot_set, gen_batch, tri_follow, &c.d_ctr->pad2[0], half_fill, &c.d_ctr->vstat[0])
             if (lds_tables && scene->wide) RT_LAUNCH_DRAW(true, true);
             else if (lds_tables) RT_LAUNCH_DRAW(true, false);
             else if (scene->wide) RT_LAUNCH_DRAW(false, true);
@@ -3244,6 +3437,7 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
             else RT_LAUNCH_PATHS(false, false, false);
         }
 #undef RT_LAUNCH_PATHS
+#undef RT_LAUNCH_PATHS_V
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(c.ev_b, st));
         HIP_TRY(hipEventSynchronize(c.ev_b));
@@ -3287,12 +3481,12 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
                 HIP_TRY(hipEventRecord(e0, st));
                 RT_LAUNCH_ADVANCE(st, d_sum);
                 HIP_TRY(hipEventRecord(e1, st));
-                RT_LAUNCH_TRACE_REF(MODE_POOL, literal, scene->wide, grid_trace, lds_bytes, st, sc, c.pools, tpp, stack_cap, d_over);
+                RT_LAUNCH_TRACE_REF(MODE_POOL, literal, verify, scene->wide, grid_trace, lds_bytes, st, sc, c.pools, tpp, stack_cap, d_over);
                 HIP_TRY(hipEventRecord(e2, st));
                 HIP_TRY(hipEventRecord(e3, st));
             } else {
                 RT_LAUNCH_ADVANCE(st, d_sum);
-                RT_LAUNCH_TRACE_REF(MODE_POOL, literal, scene->wide, grid_trace, lds_bytes, st, sc, c.pools, tpp, stack_cap, d_over);
+                RT_LAUNCH_TRACE_REF(MODE_POOL, literal, verify, scene->wide, grid_trace, lds_bytes, st, sc, c.pools, tpp, stack_cap, d_over);
             }
             rounds++;
         }
@@ -3322,7 +3516,7 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
             RT_LAUNCH_ADVANCE(st, d_sum);
             tpp.lock_shades = c.d_lock;
             tpp.lock_round = j;
-            RT_LAUNCH_TRACE_REF(MODE_POOL, literal, scene->wide, grid_trace, lds_bytes, st, sc, c.pools, tpp, stack_cap, d_over);
+            RT_LAUNCH_TRACE_REF(MODE_POOL, literal, verify, scene->wide, grid_trace, lds_bytes, st, sc, c.pools, tpp, stack_cap, d_over);
         }
         HIP_TRY(hipGetLastError());
     }
@@ -3352,6 +3546,8 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
 #endif
     float ms_total = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms_total, ev_start, ev_stop));
+    DCounters h_final{};
+    HIP_TRY(hipMemcpy(&h_final, c.d_ctr, sizeof(DCounters), hipMemcpyDeviceToHost));
     std::vector<DWaveRow> h_rows((size_t)c.n_rows);
     HIP_TRY(hipMemcpy(h_rows.data(), c.d_rows, sizeof(DWaveRow) * (size_t)c.n_rows, hipMemcpyDeviceToHost));
     unsigned long long fin[C_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -3399,6 +3595,9 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
             stats->reserved[1] = 1;
             stats->reserved[2] = top_records_in_lds;
         }
+        stats->reserved[4] = (int64_t)h_final.vstat[V_LITERAL];
+        stats->reserved[5] = (int64_t)h_final.vstat[V_LOST];
+        stats->reserved[6] = (int64_t)h_final.vstat[V_TIE];
     }
     return 0;
 }
@@ -3454,6 +3653,7 @@ int render_overlapped(const rt_scene *scene, const rt_camera *camera, int width,
             tot.seconds_rng_init = std::max(tot.seconds_rng_init, sub[k].seconds_rng_init);
             tot.reserved[0] += sub[k].reserved[0];
             tot.reserved[2] = std::max(tot.reserved[2], sub[k].reserved[2]);
+            for (int q = 4; q < 7; q++) tot.reserved[q] += sub[k].reserved[q];
         }
         *stats = tot;
     }
@@ -3932,6 +4132,7 @@ int rt_render_multi(const rt_scene *scene, const rt_camera *camera, int width, i
             tot.seconds_advance = std::max(tot.seconds_advance, sub[k].seconds_advance);
             tot.seconds_render = std::max(tot.seconds_render, sub[k].seconds_render);  // the devices render side by side
             tot.seconds_rng_init = std::max(tot.seconds_rng_init, sub[k].seconds_rng_init);
+            for (int q = 4; q < 7; q++) tot.reserved[q] += sub[k].reserved[q];
         }
         tot.reserved[3] = n_devices;
         *stats = tot;
@@ -3950,10 +4151,14 @@ int rt_trace_closest_flags(const rt_scene *scene, uint32_t flags, int n, const f
         return fail("rt_trace_closest: bad argument");
     if (n == 0) return 0;
     const bool literal = (flags & RT_FLAG_REFERENCE_WALK) != 0;
-    if (literal && ensure_ref_tree(scene)) return 1;
+    const bool verify = !literal && (flags & RT_FLAG_WATERTIGHT) == 0;
+    if ((literal || verify) && ensure_ref_tree(scene)) return 1;
     float *d_o, *d_d, *d_tm, *d_t, *d_u, *d_v;
     int *d_h;
+    unsigned long long *d_vstat;
     DevScope tmp;
+    if (tmp.alloc(d_vstat, 4)) return 1;
+    HIP_TRY(hipMemset(d_vstat, 0, 4 * sizeof(unsigned long long)));
     if (tmp.alloc(d_o, 3 * (size_t)n) || tmp.alloc(d_d, 3 * (size_t)n) || tmp.alloc(d_tm, (size_t)n) || tmp.alloc(d_t, (size_t)n) ||
         tmp.alloc(d_u, (size_t)n) || tmp.alloc(d_v, (size_t)n) || tmp.alloc(d_h, (size_t)n))
         return 1;
@@ -3964,7 +4169,7 @@ int rt_trace_closest_flags(const rt_scene *scene, uint32_t flags, int n, const f
     const int stack_cap = lds_stack_cap(scene, kLdsStack);
     int *d_over = nullptr;
     int over_levels = 0;
-    if (ensure_overflow(d_over, over_levels, scene->stack_bound - stack_cap)) return 1;
+    if (ensure_overflow(d_over, over_levels, std::max(scene->stack_bound, 32) - stack_cap)) return 1;
     tmp.ptrs.push_back(d_over);
     {
         TraceParams tp{};
@@ -3977,8 +4182,9 @@ int rt_trace_closest_flags(const rt_scene *scene, uint32_t flags, int n, const f
         tp.out_t = d_t;
         tp.out_u = d_u;
         tp.out_v = d_v;
+        tp.vstat = d_vstat;
         DPools none{};
-        RT_LAUNCH_TRACE_REF(MODE_TEST_CLOSEST, literal, scene->wide, dim3(test_grid), sizeof(int) * kBlock * (size_t)(stack_cap + 2), nullptr,
+        RT_LAUNCH_TRACE_REF(MODE_TEST_CLOSEST, literal, verify, scene->wide, dim3(test_grid), sizeof(int) * kBlock * (size_t)(stack_cap + 2), nullptr,
                         scene->dev(), none, tp, stack_cap, d_over);
     }
     HIP_TRY(hipGetLastError());
@@ -4000,7 +4206,8 @@ int rt_trace_any_flags(const rt_scene *scene, uint32_t flags, int n, const float
         return fail("rt_trace_any: bad argument");
     if (n == 0) return 0;
     const bool literal = (flags & RT_FLAG_REFERENCE_WALK) != 0;
-    if (literal && ensure_ref_tree(scene)) return 1;
+    const bool verify = !literal && (flags & RT_FLAG_WATERTIGHT) == 0;
+    if ((literal || verify) && ensure_ref_tree(scene)) return 1;
     std::vector<int> excl(n);
     for (int i = 0; i < n; i++) {
         int e = excluded_tri[i];
@@ -4008,7 +4215,10 @@ int rt_trace_any_flags(const rt_scene *scene, uint32_t flags, int n, const float
     }
     float *d_o, *d_d, *d_tm;
     int *d_e, *d_occ;
+    unsigned long long *d_vstat;
     DevScope tmp;
+    if (tmp.alloc(d_vstat, 4)) return 1;
+    HIP_TRY(hipMemset(d_vstat, 0, 4 * sizeof(unsigned long long)));
     if (tmp.alloc(d_o, 3 * (size_t)n) || tmp.alloc(d_d, 3 * (size_t)n) || tmp.alloc(d_tm, (size_t)n) || tmp.alloc(d_e, (size_t)n) ||
         tmp.alloc(d_occ, (size_t)n))
         return 1;
@@ -4020,7 +4230,7 @@ int rt_trace_any_flags(const rt_scene *scene, uint32_t flags, int n, const float
     const int stack_cap = lds_stack_cap(scene, kLdsStack);
     int *d_over = nullptr;
     int over_levels = 0;
-    if (ensure_overflow(d_over, over_levels, scene->stack_bound - stack_cap)) return 1;
+    if (ensure_overflow(d_over, over_levels, std::max(scene->stack_bound, 32) - stack_cap)) return 1;
     tmp.ptrs.push_back(d_over);
     {
         TraceParams tp{};
@@ -4030,8 +4240,9 @@ int rt_trace_any_flags(const rt_scene *scene, uint32_t flags, int n, const float
         tp.tmax = d_tm;
         tp.excluded = d_e;
         tp.out_i = d_occ;
+        tp.vstat = d_vstat;
         DPools none{};
-        RT_LAUNCH_TRACE_REF(MODE_TEST_ANY, literal, scene->wide, dim3(test_grid), sizeof(int) * kBlock * (size_t)(stack_cap + 2), nullptr,
+        RT_LAUNCH_TRACE_REF(MODE_TEST_ANY, literal, verify, scene->wide, dim3(test_grid), sizeof(int) * kBlock * (size_t)(stack_cap + 2), nullptr,
                         scene->dev(), none, tp, stack_cap, d_over);
     }
     HIP_TRY(hipGetLastError());

@@ -63,7 +63,7 @@ def oracle_scene(oracle, variant, watertight):
     return _oracle_scene_cache[key]
 
 
-def oracle_render(oracle, variant, w, h, spp, max_bounces=10, seed=1, watertight=True, slot_lo=0, slot_hi=1 << 20):
+def oracle_render(oracle, variant, w, h, spp, max_bounces=10, seed=1, watertight=False, slot_lo=0, slot_hi=1 << 20):
     """(image, raw sums, stats) of an oracle render, computed once per session for each distinct argument tuple."""
     key = (oracle.flavour, variant, w, h, spp, max_bounces, seed, bool(watertight), slot_lo, slot_hi)
     if key not in _oracle_render_cache:

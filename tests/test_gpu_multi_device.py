@@ -64,7 +64,7 @@ def test_multi_device_render_in_the_other_modes(api, gpu_full):
     (every shard renders ALL slots at spp / n) through the same entry point, each bit-equal to its single-device render."""
     w, h, spp = 300, 200, 48
     cam = api.make_camera(aspect=w / h)
-    for extra in (api.FLAG_REFERENCE_WALK, api.FLAG_RNG_PER_SAMPLE):
+    for extra in (api.FLAG_REFERENCE_WALK, api.FLAG_RNG_PER_SAMPLE, api.FLAG_WATERTIGHT):
         F = api.FLAG_DETERMINISTIC | extra
         ref, st_ref = gpu_full.render(cam, w, h, spp, flags=F)
         img, st = gpu_full.render_multi(cam, w, h, spp, [0, 0, 0, 0], flags=F)

@@ -9,11 +9,13 @@ re-roll chain, the idle skip, the GEN / ADV routing at max_bounces, and the smal
 (MIN_WAVES = 2) that every rank of an 8-GPU run launches.  Reference lines being matched:
 render.cuh:84-137 (init), :139-248 (mat), :250-275 (gen), :278-328 (ah / ch), :428-449 (host loop).
 
-The oracle runs in its watertight mode here (see _scenes); test_literal_reference_walk_differs_only_by_audited_rays
-holds the literal mode next to it.
+The oracle runs in its LITERAL mode here -- the reference's own tree, its fp32 slab test on exact boxes and its tree-order
+tie rule (bvh.cuh:221-357, aabb_intersector.cuh:14-36, triangle.cuh:49) -- against the DEFAULT kernels, which make the
+reference's decisions on their own walk (ref_visible in rtcuda_amd.hip).  RT_FLAG_WATERTIGHT (the triangle-list definition)
+is held against the oracle's watertight mode by the tests that name it.
 
 Bar: integer event totals EQUAL to the oracle's, image RMS < 2e-6 per channel (only the order of
-the float atomics differs; north-star tolerance 1e-4), fixed-point sums bit-equal between shardings.
+the float atomics differs; north-star tolerance 1e-4), fixed-point sums bit-equal to the oracle's and between shardings.
 """
 import os
 
@@ -42,11 +44,11 @@ def _scenes(api, oracle, variant):
     if variant not in _scene_cache:
         from rtcuda_amd import scenes
         _scene_cache[variant] = api.Scene(scenes.cornell_bunny(variant))
-    # Oracle in its WATERTIGHT mode: about one path ray in 10^7 is decided differently by the reference's own BVH
-    # walk than by exhaustive search over all triangles (its fp32 slab test on exact boxes drops a triangle the
-    # triangle test accepts); the product's walk agrees with exhaustive search.  tests/test_traversal_audit.py
-    # (CPU) replays every ray of a literal render to prove both statements; here the comparison is strict.
-    return _scene_cache[variant], oracle_scene(oracle, variant, True)
+    # Oracle in its LITERAL mode: about one path ray in 10^7 is decided differently by the reference's own BVH walk than by
+    # exhaustive search over all triangles (its fp32 slab test on exact boxes drops a triangle the triangle test accepts),
+    # and exact ties go to the triangle its walk tests last.  The default kernels reproduce both (tests/test_traversal_audit.py
+    # replays every ray of literal renders through their CPU twin); the comparison here is strict.
+    return _scene_cache[variant], oracle_scene(oracle, variant, False)
 
 
 def _rms(a, b):
@@ -62,8 +64,8 @@ def _rms(a, b):
 
 def _max_abs(a, b):
     """Largest per-channel difference over ALL pixels (NaN pixels, equal on both sides by _rms, count as 0).  Both sides
-    give a hit at exactly equal t to the larger caller index (closest_hit_wins / the oracle's watertight mode), so no
-    pixel is exempt."""
+    decide ties the same way (the reference's: the default kernels re-trace such a ray through the reference's own tree), so
+    no pixel is exempt."""
     return np.nan_to_num(np.abs(a.astype(np.float64) - b.astype(np.float64))).max()
 
 
@@ -111,13 +113,32 @@ def test_persistent_kernel_matches_oracle(api, oracle, variant, w, h, spp, max_b
     assert _max_abs(img_g, img_c) < 1e-4
 
 
-def test_literal_reference_walk_differs_only_by_audited_rays(api, oracle):
-    """The same frame against the LITERAL oracle (the reference's own slab test): the event totals may differ by the
-    few rays its BVH walk loses (1 of 11.5 M path rays on this frame: tests/test_traversal_audit.py), nothing more."""
+WATERTIGHT_CASES = [("full_bsdf", 480, 270, 32, 10, 1), ("matte", 256, 256, 40, 10, 1), ("sixteen_lights", 480, 270, 20, 10, 1)]
+
+
+@pytest.mark.parametrize("variant,w,h,spp,max_bounces,seed", WATERTIGHT_CASES)
+def test_watertight_flag_matches_the_watertight_oracle(api, oracle, variant, w, h, spp, max_bounces, seed):
+    """RT_FLAG_WATERTIGHT: no accepted hit is lost to a box test and ties go to the larger caller index -- what exhaustive
+    search over the triangle list returns, and what the oracle's watertight mode restates.  Equal events, same image."""
+    gpu, _ = _scenes(api, oracle, variant)
+    img_c, _, st_c = oracle_render(oracle, variant, w, h, spp, max_bounces=max_bounces, seed=seed, watertight=True)
+    img_g, st_g = gpu.render(api.make_camera(aspect=w / h), w, h, spp, max_bounces=max_bounces, seed=seed, flags=api.FLAG_WATERTIGHT)
+    _assert_same_events(st_g, st_c, w * h * spp)
+    assert st_g["literal_retraces"] == 0 and st_g["reference_lost_hits"] == 0  # (that machinery is not in this build)
+    assert _rms(img_g, img_c).max() < 2e-6 and _max_abs(img_g, img_c) < 1e-4
+
+
+def test_watertight_flag_differs_from_the_reference_only_by_audited_rays(api, oracle):
+    """RT_FLAG_WATERTIGHT against the LITERAL oracle (the reference's own slab test): the event totals may differ by the
+    few rays the reference's BVH walk loses (1 of 11.5 M path rays on this frame: tests/test_traversal_audit.py), nothing
+    more -- and the default kernels' counters say which rays those were."""
     w, h, spp = 256, 256, 40
     gpu, _ = _scenes(api, oracle, "matte")
     img_c, _, st_c = oracle_render(oracle, "matte", w, h, spp, watertight=False)
-    img_g, st_g = gpu.render(api.make_camera(aspect=1.0), w, h, spp)
+    _, st_d = gpu.render(api.make_camera(aspect=1.0), w, h, spp)
+    _assert_same_events(st_d, st_c, w * h * spp)
+    assert 1 <= st_d["reference_lost_hits"] <= 4 and 1 <= st_d["literal_retraces"] <= 16, st_d
+    img_g, st_g = gpu.render(api.make_camera(aspect=1.0), w, h, spp, flags=api.FLAG_WATERTIGHT)
     for kg, kc in (("shade_events", "sum_mat"), ("any_rays", "sum_ah"), ("emission_adds", "emission_adds"),
                    ("shadow_adds", "ah_adds"), ("rr_draws", "rr_draws")):
         assert abs(st_g[kg] - st_c[kc]) <= 4, (kg, st_g[kg], st_c[kc])
@@ -371,7 +392,7 @@ def test_multi_generation_render_matches_committed_golden(api, variant, w, h, sp
     from rtcuda_amd import scenes
     key = f"{variant}_{w}x{h}x{spp}"
     sc = api.Scene(scenes.cornell_bunny(variant))
-    img, st = sc.render(api.make_camera(aspect=w / h), w, h, spp)
+    img, st = sc.render(api.make_camera(aspect=w / h), w, h, spp, flags=api.FLAG_WATERTIGHT)  # (fixtures of the watertight oracle)
     assert [st["shade_events"], st["any_rays"], st["emission_adds"], st["shadow_adds"], st["rr_draws"],
             st["camera_rays"]] == GOLDEN[key + "_counts"].tolist()
     ref = GOLDEN[key + "_img"].astype(np.float32)
@@ -381,21 +402,25 @@ def test_multi_generation_render_matches_committed_golden(api, variant, w, h, sp
 
 @pytest.mark.parametrize("variant,w,h,spp", [("matte", 160, 100, 160), ("full_bsdf", 128, 72, 256)])
 def test_multi_generation_render_against_the_literal_reference_fixture(api, variant, w, h, spp):
-    """The committed LITERAL-oracle fixtures (the reference's own fp32 slab test and tree-order tie rule): the product's
-    walk is conservative, so it may differ by the rays the reference's walk loses -- at most 4 events and 2 pixels on
-    frames of this size (audited bound, tests/test_traversal_audit.py) -- and stays inside the north-star tolerance."""
+    """The committed LITERAL-oracle fixtures (the reference's own fp32 slab test and tree-order tie rule).  Round 5: the
+    default kernels make the reference's decisions, so the counts are EQUAL and no pixel moves (until round 4 the bound was
+    the audited one: 4 events, 2 pixels over 1e-4); RT_FLAG_WATERTIGHT stays inside that bound."""
     from rtcuda_amd import scenes
     key = f"literal_{variant}_{w}x{h}x{spp}"
     sc = api.Scene(scenes.cornell_bunny(variant))
     img, st = sc.render(api.make_camera(aspect=w / h), w, h, spp)
+    img_w, st_w = sc.render(api.make_camera(aspect=w / h), w, h, spp, flags=api.FLAG_WATERTIGHT)
     sc.close()
-    got = [st["shade_events"], st["any_rays"], st["emission_adds"], st["shadow_adds"], st["rr_draws"], st["camera_rays"]]
     want = GOLDEN[key + "_counts"].tolist()
+    ref = GOLDEN[key + "_img"]
+    got = [st["shade_events"], st["any_rays"], st["emission_adds"], st["shadow_adds"], st["rr_draws"], st["camera_rays"]]
+    assert got == want
+    assert _rms(img, ref).max() < 2e-6 and _max_abs(img, ref) < 1e-4
+    got = [st_w["shade_events"], st_w["any_rays"], st_w["emission_adds"], st_w["shadow_adds"], st_w["rr_draws"], st_w["camera_rays"]]
     assert got[5] == want[5]
     assert all(abs(g - c) <= 4 for g, c in zip(got, want)), (got, want)
-    ref = GOLDEN[key + "_img"]
-    assert np.array_equal(np.isnan(img), np.isnan(ref))
-    d = np.nan_to_num(np.abs(img.astype(np.float64) - ref))
+    assert np.array_equal(np.isnan(img_w), np.isnan(ref))
+    d = np.nan_to_num(np.abs(img_w.astype(np.float64) - ref))
     assert (d.max(axis=2) > 1e-4).sum() <= 2
     assert np.sqrt(np.mean(d ** 2)) < 1e-4
 
@@ -450,36 +475,43 @@ def test_per_sample_rng_mode_is_partition_invariant_and_statistically_equivalent
 
 
 FIXED_CASES = [
-    # variant, w, h, spp, reference walk?
-    ("full_bsdf", 300, 200, 48, False),      # 2.7 generations, spp does not divide W, one NaN contribution (dropped)
-    ("full_bsdf", 160, 90, 16, False),       # one generation: every camera ray is of the FINAL generation (lockstep pipeline)
-    ("matte", 256, 256, 40, False),
-    ("sixteen_lights", 480, 270, 20, False),
-    ("matte", 256, 256, 40, True),           # RT_FLAG_REFERENCE_WALK against the LITERAL oracle
-    ("sixteen_lights", 480, 270, 20, True),
-    ("four_bunnies", 480, 270, 20, False),   # the deep tree (global overflow stack in k_paths) ...
-    ("four_bunnies", 480, 270, 20, True),    # ... and the reference's depth-22 tree
+    # variant, w, h, spp, mode: "default" (the reference's decisions on the product's walk) and "reference_walk"
+    # (RT_FLAG_REFERENCE_WALK: every ray through the reference's own tree) against the LITERAL oracle, "watertight"
+    # (RT_FLAG_WATERTIGHT) against the watertight oracle
+    ("full_bsdf", 300, 200, 48, "default"),      # 2.7 generations, spp does not divide W, one NaN contribution (dropped)
+    ("full_bsdf", 160, 90, 16, "default"),       # one generation: every camera ray is of the FINAL generation (lockstep pipeline)
+    ("matte", 256, 256, 40, "default"),          # (a frame on which the reference loses a hit)
+    ("sixteen_lights", 480, 270, 20, "default"),
+    ("sixteen_lights", 480, 270, 48, "default"),  # 7 shadow rays whose occluder the reference's walk cannot see
+    ("four_bunnies", 480, 270, 20, "default"),   # the deep tree (global overflow stack in k_paths) and the reference's depth-22 tree
+    ("matte", 256, 256, 40, "reference_walk"),
+    ("sixteen_lights", 480, 270, 20, "reference_walk"),
+    ("four_bunnies", 480, 270, 20, "reference_walk"),
+    ("full_bsdf", 300, 200, 48, "watertight"),
+    ("matte", 256, 256, 40, "watertight"),
+    ("sixteen_lights", 480, 270, 20, "watertight"),
 ]
 
 
-@pytest.mark.parametrize("variant,w,h,spp,ref_walk", FIXED_CASES)
-def test_deterministic_sums_equal_the_oracles_fixed_point_sums_bit_for_bit(api, oracle, variant, w, h, spp, ref_walk):
+@pytest.mark.parametrize("variant,w,h,spp,mode", FIXED_CASES)
+def test_deterministic_sums_equal_the_oracles_fixed_point_sums_bit_for_bit(api, oracle, variant, w, h, spp, mode):
     """The IMAGE, bit for bit: RT_FLAG_DETERMINISTIC's int64 sums (2^-30 fixed point; a camera ray's contributions summed in
     float in path order, then converted -- contribution by contribution in the final generation) against the oracle's
     restatement of that accumulation over ITS paths (oracle.cpp render_literal, `fb_fixed`).  Integer adds commute, so there
     is exactly one right answer per frame, and every one of the w * h * 3 sums must equal it: every path, every contribution,
-    every rounding.  Default kernels vs the watertight oracle; RT_FLAG_REFERENCE_WALK vs the literal oracle.  The six full
-    BASELINE frames are held to committed hashes of the same arrays (test_every_full_baseline_frame_image_hash)."""
+    every rounding.  Default kernels and RT_FLAG_REFERENCE_WALK vs the literal oracle; RT_FLAG_WATERTIGHT vs the watertight
+    oracle.  The six full BASELINE frames are held to committed hashes of the same arrays
+    (test_every_full_baseline_frame_image_hash)."""
     import torch
     from conftest import usable_cpus
     from oracle.oracle import sums_hash
     gpu, _ = _scenes(api, oracle, variant)
-    osc = oracle_scene(oracle, variant, not ref_walk)
+    osc = oracle_scene(oracle, variant, mode == "watertight")
+    flags = {"default": 0, "reference_walk": api.FLAG_REFERENCE_WALK, "watertight": api.FLAG_WATERTIGHT}[mode]
     want = np.zeros((h, w, 3), np.int64)
     _, _, st_c = osc.render(default_camera(oracle, w / h), w, h, spp, threads=usable_cpus(), fixed_out=want)
     got = torch.zeros(h * w * 3, dtype=torch.int64, device="cuda")
-    st_g = gpu.render_shard_fixed(api.make_camera(aspect=w / h), w, h, spp, 0, 1, got.data_ptr(),
-                                  flags=api.FLAG_REFERENCE_WALK if ref_walk else 0)
+    st_g = gpu.render_shard_fixed(api.make_camera(aspect=w / h), w, h, spp, 0, 1, got.data_ptr(), flags=flags)
     torch.cuda.synchronize()
     _assert_same_events(st_g, st_c, w * h * spp)
     g = got.cpu().numpy().reshape(h, w, 3)
@@ -488,8 +520,7 @@ def test_deterministic_sums_equal_the_oracles_fixed_point_sums_bit_for_bit(api, 
     # ... and the same array from 8 slot-range shards (what 8 ranks would reduce)
     acc = torch.zeros_like(got)
     for r in range(8):
-        gpu.render_shard_fixed(api.make_camera(aspect=w / h), w, h, spp, r, 8, acc.data_ptr(),
-                               flags=api.FLAG_REFERENCE_WALK if ref_walk else 0)
+        gpu.render_shard_fixed(api.make_camera(aspect=w / h), w, h, spp, r, 8, acc.data_ptr(), flags=flags)
     torch.cuda.synchronize()
     assert torch.equal(acc, got)
 
@@ -501,13 +532,23 @@ def _full_size_hashes():
     return json.load(open(path))["frames"] if os.path.exists(path) else []
 
 
-@pytest.mark.parametrize("frame", _full_size_hashes(),
-                         ids=lambda f: f"{f['scene']}_{f['width']}x{f['height']}x{f['spp']}_{f['mode']}")
-def test_every_full_baseline_frame_image_hash(api, frame):
+def _full_size_hash_cases():
+    out = []
+    for f in _full_size_hashes():
+        out.append((f, "default" if f["mode"] == "literal" else "watertight"))
+        if f["mode"] == "literal":
+            out.append((f, "reference_walk"))
+    return out
+
+
+@pytest.mark.parametrize("frame,how", _full_size_hash_cases(),
+                         ids=lambda x: x if isinstance(x, str) else f"{x['scene']}_{x['width']}x{x['height']}x{x['spp']}_{x['mode']}")
+def test_every_full_baseline_frame_image_hash(api, frame, how):
     """Full-size image parity inside the GPU suite: the int64 fixed-point sums of a whole BASELINE frame (6 220 800 values)
     hashed to 64 bits and compared with the committed hash of the ORACLE's array for that frame (tests/golden/make_full_size_hashes.py:
-    minutes of CPU per frame; tests/golden/full_size_image_hashes.json).  `mode` watertight: the default kernels; `mode`
-    literal: RT_FLAG_REFERENCE_WALK.  Equal hashes = every pixel of the frame bit-equal to the oracle's."""
+    minutes of CPU per frame; tests/golden/full_size_image_hashes.json).  `mode` literal: the DEFAULT kernels -- the ones
+    bench.py times -- and RT_FLAG_REFERENCE_WALK; `mode` watertight: RT_FLAG_WATERTIGHT.  Equal hashes = every pixel of the
+    frame bit-equal to the oracle's."""
     import torch
     from oracle.oracle import sums_hash
     from rtcuda_amd import scenes
@@ -516,8 +557,8 @@ def test_every_full_baseline_frame_image_hash(api, frame):
         _scene_cache[frame["scene"]] = api.Scene(scenes.cornell_bunny(frame["scene"]))
     gpu = _scene_cache[frame["scene"]]
     got = torch.zeros(h * w * 3, dtype=torch.int64, device="cuda")
-    st = gpu.render_shard_fixed(api.make_camera(aspect=w / h), w, h, spp, 0, 1, got.data_ptr(),
-                                flags=api.FLAG_REFERENCE_WALK if frame["mode"] == "literal" else 0)
+    flags = {"default": 0, "reference_walk": api.FLAG_REFERENCE_WALK, "watertight": api.FLAG_WATERTIGHT}[how]
+    st = gpu.render_shard_fixed(api.make_camera(aspect=w / h), w, h, spp, 0, 1, got.data_ptr(), flags=flags)
     torch.cuda.synchronize()
     for k, v in frame["events"].items():
         assert st[k] == v, (k, st[k], v)
@@ -530,10 +571,12 @@ def _full_size_frames():
     return json.load(open(os.path.join(here, "golden", "full_size_event_totals.json")))["frames"]
 
 
+@pytest.mark.parametrize("column", ["oracle_literal", "oracle_watertight"])
 @pytest.mark.parametrize("frame", _full_size_frames(), ids=lambda f: f"{f['scene']}_{f['width']}x{f['height']}x{f['spp']}")
-def test_every_full_baseline_frame_has_the_oracles_event_totals(api, frame):
+def test_every_full_baseline_frame_has_the_oracles_event_totals(api, frame, column):
     """The six FULL BASELINE frames (1920x1080 at 256 / 512 / 1024 spp: 506 - 2 025 generations, 2 - 8 * 10^9 rays), each
-    rendered once by k_paths: the five integer event totals EQUAL the oracle's watertight totals.  The oracle's totals are committed answers (tests/golden/full_size_event_totals.json, made
+    rendered once by k_paths: the five integer event totals EQUAL the oracle's -- the default kernels the LITERAL oracle's,
+    RT_FLAG_WATERTIGHT the watertight oracle's.  The oracle's totals are committed answers (tests/golden/full_size_event_totals.json, made
     by tools/full_size_parity.py + tests/golden/make_full_size_totals.py: 100 - 400 s of 16 cores per frame and mode).  The
     image of a frame of this size is held against the oracle in profiles/r03_full_size_parity*.json; here: the oracle's
     number of NaN pixels, nothing negative, and the totals -- a checksum over every scheduling decision, every
@@ -545,17 +588,22 @@ def test_every_full_baseline_frame_has_the_oracles_event_totals(api, frame):
         _scene_cache[frame["scene"]] = api.Scene(scenes.cornell_bunny(frame["scene"]))
     gpu = _scene_cache[frame["scene"]]
     fb = torch.zeros(h * w * 3, dtype=torch.float32, device="cuda")
-    st = gpu.render_shard(api.make_camera(aspect=w / h), w, h, spp, 0, 1, fb.data_ptr())
+    st = gpu.render_shard(api.make_camera(aspect=w / h), w, h, spp, 0, 1, fb.data_ptr(),
+                          flags=0 if column == "oracle_literal" else api.FLAG_WATERTIGHT)
     torch.cuda.synchronize()
     assert st["camera_rays"] == frame["samples"] == w * h * spp
-    for k, v in frame["oracle_watertight"].items():
+    for k, v in frame[column].items():
         assert st[k] == v, (k, st[k], v)
-    # (the `oracle_literal` column of the same file is held -- exactly -- by the mode that makes the reference's own
-    # decisions: tests/test_gpu_reference_walk.py::test_every_full_baseline_frame_equals_the_literal_oracle_under_the_reference_walk)
+    # (RT_FLAG_REFERENCE_WALK holds the literal column too:
+    # tests/test_gpu_reference_walk.py::test_every_full_baseline_frame_equals_the_literal_oracle_under_the_reference_walk)
+    if column == "oracle_literal":
+        assert st["literal_retraces"] < 1e-6 * (st["closest_rays"] + st["any_rays"])  # the rare path is rare
     # the reference's estimator yields a NaN contribution about once in 10^7 samples (render.cuh has no guard; SURVEY Appendix
     # A.4 names one source): as many NaN pixels as the oracle's frame has, and nothing negative
     nan_pixels = int(torch.isnan(fb).view(-1, 3).any(dim=1).sum().item())
-    assert nan_pixels == frame["oracle_nan_pixels"], (nan_pixels, frame["oracle_nan_pixels"])
+    want_nan = {(f["scene"], f["spp"], f["mode"]): f["nan_pixels_float_image"] for f in _full_size_hashes()}
+    want_nan = want_nan.get((frame["scene"], spp, "literal" if column == "oracle_literal" else "watertight"), frame["oracle_nan_pixels"])
+    assert nan_pixels == want_nan, (nan_pixels, want_nan)
     assert bool((torch.nan_to_num(fb) >= 0).all().item())
 
 
@@ -613,7 +661,8 @@ def test_eight_rank_shards_of_the_other_baseline_configs_add_up_to_the_oracles_t
             tot[k] += st[k]
     torch.cuda.synchronize()
     assert tot["camera_rays"] == w * h * spp
-    for k, v in want["oracle_watertight"].items():
+    for k, v in want["oracle_literal"].items():  # (the default kernels: the LITERAL oracle's totals)
         assert tot[k] == v, (k, tot[k], v)
     nan_pixels = int(torch.isnan(fb).view(-1, 3).any(dim=1).sum().item())
-    assert nan_pixels == want["oracle_nan_pixels"]
+    want_nan = {(f["scene"], f["spp"], f["mode"]): f["nan_pixels_float_image"] for f in _full_size_hashes()}
+    assert nan_pixels == want_nan.get((scene, spp, "literal"), want["oracle_nan_pixels"])

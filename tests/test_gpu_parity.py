@@ -58,17 +58,16 @@ def test_xorwow_states_and_draws_bit_exact(api, oracle):
     assert np.array_equal(st, oracle.xorwow_init_range(0xDEADBEEF12345, 5, 16))
 
 
-def _closest_compare(gpu, cpu, o, d, tmax, max_mismatch_frac):
+def _closest_compare(gpu, cpu, o, d, tmax, max_mismatch_frac=0.0):
+    """Default kernels against the LITERAL oracle.  Round 5: the default kernels make the reference's decisions (which hits
+    its walk can see, who wins an exact tie), so EVERY ray must agree on the triangle; until round 4 a fraction of ties and
+    lost hits was allowed here."""
     g = gpu.trace_closest(o, d, tmax)
     c = cpu.trace_closest(o, d, tmax)
     same_tri = g[0] == c[0]
     n = len(o)
     bad = np.where(~same_tri)[0]
-    # every disagreement must be an exact tie (equal t on two triangles) or a 1-ulp grazing case
-    for i in bad[:50]:
-        if g[0][i] >= 0 and c[0][i] >= 0:
-            assert abs(float(g[1][i]) - float(c[1][i])) <= 4e-7 * max(1.0, abs(float(c[1][i]))), (i, g[1][i], c[1][i])
-    assert len(bad) <= max_mismatch_frac * n, f"{len(bad)} of {n} rays disagree on the hit triangle"
+    assert len(bad) <= max_mismatch_frac * n, f"{len(bad)} of {n} rays disagree on the hit triangle: {bad[:8]}"
     hit = same_tri & (c[0] >= 0)
     for k in (1, 2, 3):  # t, u, v bit for bit
         assert np.array_equal(g[k][hit].view(np.uint32), c[k][hit].view(np.uint32))
@@ -79,15 +78,15 @@ def test_trace_closest_matches_oracle(api, oracle, gpu_matte, cpu_matte):
     cam = default_camera(oracle, 16 / 9)
     o, d = raygen.camera_rays(cam, 1920, 1080, 400_000, seed=11)
     tmax = np.full(len(o), FLT_MAX, np.float32)
-    g, c, nbad = _closest_compare(gpu_matte, cpu_matte, o, d, tmax, 2e-5)
+    g, c, nbad = _closest_compare(gpu_matte, cpu_matte, o, d, tmax)
     assert 0.4 < (c[0] >= 0).mean() < 0.7  # 53 % of 16:9 primary rays hit the box (SURVEY Appx C)
     o2, d2 = raygen.bounce_rays(o, d, c[1], c[0] >= 0, seed=12)
-    _closest_compare(gpu_matte, cpu_matte, o2, d2, np.full(len(o2), FLT_MAX, np.float32), 2e-5)
+    _closest_compare(gpu_matte, cpu_matte, o2, d2, np.full(len(o2), FLT_MAX, np.float32))
     # finite tmax (shadow-ray style) and degenerate directions
     tm = np.random.default_rng(5).uniform(0.05, 1.5, len(o2)).astype(np.float32)
-    _closest_compare(gpu_matte, cpu_matte, o2, d2, tm, 2e-5)
+    _closest_compare(gpu_matte, cpu_matte, o2, d2, tm)
     o3, d3 = raygen.axis_aligned_rays(50_000, seed=13)
-    _closest_compare(gpu_matte, cpu_matte, o3, d3, np.full(len(o3), FLT_MAX, np.float32), 1e-3)
+    _closest_compare(gpu_matte, cpu_matte, o3, d3, np.full(len(o3), FLT_MAX, np.float32))
 
 
 def test_trace_any_matches_oracle(api, oracle, gpu_matte, cpu_matte, bunny_matte):
@@ -101,7 +100,7 @@ def test_trace_any_matches_oracle(api, oracle, gpu_matte, cpu_matte, bunny_matte
     excl = rng.choice(np.concatenate([light_tris, [-1]]), len(o2)).astype(np.int32)
     g_occ = gpu_matte.trace_any(o2, d2, tm, excl)
     c_occ = cpu_matte.trace_any(o2, d2, tm, excl)
-    assert (g_occ != c_occ).sum() <= 2e-5 * len(o2)
+    assert np.array_equal(g_occ, c_occ)
     assert 0.05 < c_occ.mean() < 0.95
     # empty batch is legal
     assert len(gpu_matte.trace_any(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32),
@@ -115,41 +114,47 @@ KNOWN_MISS_D = np.array([1048527110, 1054521025, 1063157561], np.uint32).view(np
 _raylog = {}
 
 
-def _watertight_ray_log(oracle, bunny_matte):
-    """Every ray of a 160 x 160 x 8 watertight-oracle render of the matte scene (~0.8 M rays), with the oracle's results."""
-    if not _raylog:
-        sc = oracle.scene(bunny_matte).set_watertight(True)
+def _oracle_ray_log(oracle, bunny_matte, watertight):
+    """Every ray of a 160 x 160 x 8 oracle render of the matte scene (~0.8 M rays) in the given mode, with the oracle's
+    results; `miss_*`: what that mode answers on the ray the reference's walk gets wrong."""
+    if watertight not in _raylog:
+        sc = oracle.scene(bunny_matte).set_watertight(watertight)
         oracle.raylog_enable(True)
         sc.render(default_camera(oracle, 1.0), 160, 160, 8, threads=usable_cpus())
-        _raylog.update(oracle.raylog_fetch())
+        log = oracle.raylog_fetch()
         oracle.raylog_enable(False)
-        brute = sc.trace_closest_brute(KNOWN_MISS_O, KNOWN_MISS_D, np.full(1, FLT_MAX, np.float32))
-        _raylog["miss_tri"], _raylog["miss_t"] = int(brute[0][0]), brute[1][0]
-    return _raylog
+        one = (sc.trace_closest_brute if watertight else sc.trace_closest)(KNOWN_MISS_O, KNOWN_MISS_D, np.full(1, FLT_MAX, np.float32))
+        log["miss_tri"], log["miss_t"] = int(one[0][0]), one[1][0]
+        _raylog[watertight] = log
+    return _raylog[watertight]
 
 
+@pytest.mark.parametrize("watertight", [False, True], ids=["default-vs-literal", "watertight-flag-vs-watertight"])
 @pytest.mark.parametrize("env", [{}, {"RT_BVH_WIDE": "0"}, {"RT_STACK_CAP": "2"}, {"RT_BVH_WIDE": "0", "RT_STACK_CAP": "2"}],
                          ids=["wide", "pairs", "wide-overflow", "pairs-overflow"])
-def test_oracle_ray_log_replayed_ray_by_ray(api, oracle, bunny_matte, monkeypatch, env):
-    """The GPU arithmetic itself (v_rcp_f32 for 1/d, the one-comparison packed box test, the overflow stack), ray by
-    ray: every path and shadow ray of an oracle render goes through rt_trace_closest / rt_trace_any and must come back
-    with the watertight oracle's answer -- triangle index and t bit for bit, ties included, occlusion flag -- for both
-    node formats and with the traversal stack forced through its global overflow part.  The ray the reference's own
-    walk gets wrong (KNOWN_MISS) is one of them."""
-    log = _watertight_ray_log(oracle, bunny_matte)
+def test_oracle_ray_log_replayed_ray_by_ray(api, oracle, bunny_matte, monkeypatch, env, watertight):
+    """The GPU arithmetic itself (v_rcp_f32 for 1/d, the one-comparison packed box test, the overflow stack; in the default
+    build also ref_visible and the rare literal re-trace), ray by ray: every path and shadow ray of an oracle render goes
+    through rt_trace_closest / rt_trace_any and must come back with the oracle's answer -- triangle index and t bit for bit,
+    ties included, occlusion flag -- for both node formats and with the traversal stack forced through its global overflow
+    part: the DEFAULT kernels against the LITERAL oracle, RT_FLAG_WATERTIGHT against the watertight oracle.  The ray the
+    reference's own walk gets wrong (KNOWN_MISS) is one of them: wall 69458 behind the light by default, as in the
+    reference; light 69462 with RT_FLAG_WATERTIGHT, as exhaustive search has it."""
+    log = _oracle_ray_log(oracle, bunny_matte, watertight)
+    flags = api.FLAG_WATERTIGHT if watertight else 0
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     gpu = api.Scene(bunny_matte)  # (RT_BVH_WIDE is read at scene creation)
     o = np.concatenate([log["closest_o"], KNOWN_MISS_O])
     d = np.concatenate([log["closest_d"], KNOWN_MISS_D])
-    tri, t, _, _ = gpu.trace_closest(o, d, np.full(len(o), FLT_MAX, np.float32))
+    tri, t, _, _ = gpu.trace_closest(o, d, np.full(len(o), FLT_MAX, np.float32), flags=flags)
     want_tri = np.concatenate([log["closest_tri"], [log["miss_tri"]]])
     want_t = np.concatenate([log["closest_t"], [log["miss_t"]]])
-    assert log["miss_tri"] == 69462
+    assert log["miss_tri"] == (69462 if watertight else 69458)
     assert np.array_equal(tri, want_tri)
     hit = want_tri >= 0
     assert np.array_equal(t[hit].view(np.uint32), want_t[hit].astype(np.float32).view(np.uint32))
-    occ = gpu.trace_any(log["any_o"], log["any_d"], log["any_tmax"], log["any_excluded"])
+    occ = gpu.trace_any(log["any_o"], log["any_d"], log["any_tmax"], log["any_excluded"], flags=flags)
     assert np.array_equal(occ, log["any_occluded"])
     gpu.close()
     assert len(o) > 500_000 and len(occ) > 200_000
@@ -271,7 +276,7 @@ def test_render_matches_committed_goldens(api, variant, w, h, spp):
     from rtcuda_amd import scenes
     key = f"{variant}_{w}x{h}x{spp}"
     sc = api.Scene(scenes.cornell_bunny(variant))
-    img, st = sc.render(api.make_camera(aspect=w / h), w, h, spp)
+    img, st = sc.render(api.make_camera(aspect=w / h), w, h, spp, flags=api.FLAG_WATERTIGHT)  # (fixtures of the watertight oracle)
     counts = GOLDEN[key + "_counts"]
     assert [st["shade_events"], st["any_rays"], st["emission_adds"], st["shadow_adds"], st["rr_draws"],
             st["camera_rays"]] == counts.tolist()
@@ -346,8 +351,8 @@ def test_both_node_formats_match_oracle(api, oracle, cpu_matte, bunny_matte, mon
         monkeypatch.setenv("RT_BVH_WIDE", wide)
         sc = api.Scene(bunny_matte)
         assert sc.info()["pairs"] > 1000
-        _closest_compare(sc, cpu_matte, o, d, tmax, 2e-5)
-        _closest_compare(sc, cpu_matte, o2, d2, np.full(len(o2), FLT_MAX, np.float32), 2e-5)
+        _closest_compare(sc, cpu_matte, o, d, tmax)
+        _closest_compare(sc, cpu_matte, o2, d2, np.full(len(o2), FLT_MAX, np.float32))
         sc.close()
 
 
@@ -358,9 +363,9 @@ def test_deep_bvh_four_bunnies(api, oracle):
     gpu, cpu = api.Scene(arrays), oracle.scene(arrays)
     cam = default_camera(oracle, 16 / 9)
     o, d = raygen.camera_rays(cam, 1920, 1080, 200_000, seed=41)
-    g, c, _ = _closest_compare(gpu, cpu, o, d, np.full(len(o), FLT_MAX, np.float32), 2e-5)
+    g, c, _ = _closest_compare(gpu, cpu, o, d, np.full(len(o), FLT_MAX, np.float32))
     o2, d2 = raygen.bounce_rays(o, d, c[1], c[0] >= 0, seed=42)
-    _closest_compare(gpu, cpu, o2, d2, np.full(len(o2), FLT_MAX, np.float32), 2e-5)
+    _closest_compare(gpu, cpu, o2, d2, np.full(len(o2), FLT_MAX, np.float32))
     w, h, spp = 64, 36, 8
     img_c, _, st_c = cpu.render(cam, w, h, spp, threads=8)
     img_g, st_g = gpu.render(api.make_camera(aspect=w / h), w, h, spp)
@@ -470,9 +475,9 @@ def test_device_lbvh_builder_gives_the_same_image(api, oracle, cpu_matte, bunny_
         else:  # two records per 4-wide node, fewer nodes than the binary tree has
             assert info["pairs"] % 2 == 0 and info["pairs"] // 2 < bunny_matte.n_tris - 1
         assert 0 < info["build_seconds"] < 0.5
-        g, c, _ = _closest_compare(sc, cpu_matte, o, d, np.full(len(o), FLT_MAX, np.float32), 2e-5)
+        g, c, _ = _closest_compare(sc, cpu_matte, o, d, np.full(len(o), FLT_MAX, np.float32))
         o2, d2 = raygen.bounce_rays(o, d, c[1], c[0] >= 0, seed=62)
-        _closest_compare(sc, cpu_matte, o2, d2, np.full(len(o2), FLT_MAX, np.float32), 2e-5)
+        _closest_compare(sc, cpu_matte, o2, d2, np.full(len(o2), FLT_MAX, np.float32))
         w, h, spp = 64, 36, 8
         img_c, _, st_c = cpu_matte.render(default_camera(oracle, w / h), w, h, spp, threads=8)
         img_g, st_g = sc.render(api.make_camera(aspect=w / h), w, h, spp)
@@ -504,3 +509,21 @@ def test_split_probe_counts_what_the_frame_traces(api, gpu_full):
     # the frame itself is untouched by the probe (its own context, its own buffers)
     img, st = gpu_full.render(api.make_camera(aspect=w / h), w, h, spp)
     assert st["camera_rays"] == w * h * spp
+
+
+def test_rcp_exact_normal_is_the_ieee_quotient_on_this_chip(tmp_path):
+    """ref_visible (rtcuda_amd.hip) needs 1 / d exactly as the reference's IEEE division gives it and computes it as
+    v_rcp_f32 + one FMA Newton step (rt_device.h: rcp_exact_normal).  v_rcp_f32 is a hardware approximation, so the proof is
+    exhaustive and runs here: every fp32 bit pattern with 2^-24 <= |x| < 2^126 (2.5 * 10^9 operands), compiled with the
+    product's flags, against the compiler's `1.f / x`."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    exe = str(tmp_path / "rcp_exact_check")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", "-ffp-contract=off",
+                           "-fno-fast-math", os.path.join(ROOT, "tests", "cpp", "rcp_exact_check.hip"), "-o", exe],
+                          stderr=subprocess.DEVNULL)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    one_step, two_steps, patterns = (int(x) for x in out.stdout.split()[:3])
+    assert out.returncode == 0 and one_step == 0 and two_steps == 0, out.stdout
+    assert patterns > 2_000_000_000

@@ -1,12 +1,15 @@
-"""RT_FLAG_REFERENCE_WALK on the GPU against the LITERAL oracle.  Run with -m gpu.
+"""The reference's own decisions on the GPU against the LITERAL oracle.  Run with -m gpu.
 
-The default kernels define two things by the triangle list alone that the reference defines by its own tree: which
-accepted hits its fp32 slab test loses (aabb_intersector.cuh:14-36, about 1 ray in 10^7) and which of two hits at
-exactly equal t wins (triangle.cuh:49: the later tested one).  With the flag the library builds the reference's tree
-(rt_ref_tree.h after bvh.cuh:30-219; held node for node against the oracle's on the CPU: tests/test_host_logic.py) and
-walks it as Bvh::traverse does (bvh.cuh:221-357).  Bar here: EXACT equality with the oracle's literal mode -- every ray's
-triangle, t, u, v and occlusion flag bit for bit, every integer event total of every frame up to the six full BASELINE
-frames, images within the float-atomics noise (RMS < 2e-6), fixed-point sums equal between shardings.
+Two results of lashhw/rtcuda are properties of its own tree, not of the scene: which accepted hits its fp32 slab test loses
+(aabb_intersector.cuh:14-36, about 1 ray in 10^7) and which of two hits at exactly equal t wins (triangle.cuh:49: the later
+tested one).  Two ways to the same answers are held here, side by side:
+  * RT_FLAG_REFERENCE_WALK: the library builds the reference's tree (rt_ref_tree.h after bvh.cuh:30-219; held node for node
+    against the oracle's on the CPU: tests/test_host_logic.py) and every ray walks it as Bvh::traverse does (bvh.cuh:221-357);
+  * the DEFAULT kernels: the product's own walk, with every hit checked against what the reference's walk can see
+    (ref_visible) and the rare rest re-traced literally.
+Bar: EXACT equality with the oracle's literal mode -- every ray's triangle, t, u, v and occlusion flag bit for bit, every
+integer event total of every frame up to the six full BASELINE frames, images within the float-atomics noise (RMS < 2e-6),
+fixed-point sums equal to the oracle's and between shardings.
 """
 import json
 import os
@@ -50,13 +53,17 @@ def _rms(a, b):
     return float(np.sqrt(np.mean(d ** 2)))
 
 
-def test_every_ray_of_a_literal_oracle_render_comes_back_with_the_references_answer(api, oracle, bunny_matte):
+@pytest.mark.parametrize("how", ["reference_walk", "default"])
+def test_every_ray_of_a_literal_oracle_render_comes_back_with_the_references_answer(api, oracle, bunny_matte, how):
     """Ray by ray: all path rays and shadow rays of a literal-oracle render of the matte scene, the ray the reference's walk
-    is known to get wrong, rays along the axes (zero direction components: the FLT_EPSILON clamp of the slab set-up) and
-    rays that start on the walls (entry = exit on flat boxes) through rt_trace_closest_flags / rt_trace_any_flags with
-    RT_FLAG_REFERENCE_WALK: triangle index, t, u, v and the occlusion flag equal the literal oracle's bit for bit --
+    is known to get wrong, rays along the axes (zero direction components: the FLT_EPSILON clamp of the slab set-up; also
+    NEGATIVE zeros, for which the reference's octant and the sign of its 1 / d disagree and nearly every box fails) and
+    rays that start on the walls (entry = exit on flat boxes) through rt_trace_closest_flags / rt_trace_any_flags --
+    with RT_FLAG_REFERENCE_WALK (every ray through the reference's own tree) and with the DEFAULT kernels (the product's walk,
+    ref_visible, the rare re-trace): triangle index, t, u, v and the occlusion flag equal the literal oracle's bit for bit --
     ties (the later tested triangle wins) and lost hits included."""
     import raygen
+    F = api.FLAG_REFERENCE_WALK if how == "reference_walk" else 0
     sc = oracle.scene(bunny_matte)  # literal mode (default)
     oracle.raylog_enable(True)
     sc.render(default_camera(oracle, 1.0), 160, 160, 8, threads=usable_cpus())
@@ -67,6 +74,10 @@ def test_every_ray_of_a_literal_oracle_render_comes_back_with_the_references_ans
     miss_d = np.array([1048527110, 1054521025, 1063157561], np.uint32).view(np.float32).reshape(1, 3)
     ao, ad = raygen.axis_aligned_rays(4000, seed=11)
     rng = np.random.default_rng(5)
+    nz_o, nz_d = raygen.axis_aligned_rays(3000, seed=12)
+    nz_d = np.where(nz_d == 0, np.float32(-0.0), nz_d)  # -0.0 components (np.where keeps the sign bit)
+    assert np.signbit(nz_d[nz_d == 0]).all() and (nz_d == 0).any()
+    ao, ad = np.concatenate([ao, nz_o]), np.concatenate([ad, nz_d])
     wall_o = rng.uniform(0, 1, (4000, 3)).astype(np.float32)
     wall_o[np.arange(4000), rng.integers(0, 3, 4000)] = rng.choice(np.array([0.0, 1.0, -1.0], np.float32), 4000)
     wall_d = rng.normal(size=(4000, 3))
@@ -75,7 +86,7 @@ def test_every_ray_of_a_literal_oracle_render_comes_back_with_the_references_ans
     d = np.concatenate([log["closest_d"], miss_d, ad, wall_d])
     tmax = np.full(len(o), FLT_MAX, np.float32)
     gpu = _gpu_scene(api, "matte")
-    tri, t, u, v = gpu.trace_closest(o, d, tmax, flags=api.FLAG_REFERENCE_WALK)
+    tri, t, u, v = gpu.trace_closest(o, d, tmax, flags=F)
     wt, tt, uu, vv = sc.trace_closest(o, d, tmax, threads=usable_cpus())
     n_log = len(log["closest_tri"])
     assert np.array_equal(wt[:n_log], log["closest_tri"])          # (the log and the stage entry point agree)
@@ -84,16 +95,15 @@ def test_every_ray_of_a_literal_oracle_render_comes_back_with_the_references_ans
     hit = wt >= 0
     for got, want in ((t, tt), (u, uu), (v, vv)):
         assert np.array_equal(got[hit].view(np.uint32), want[hit].view(np.uint32))
-    # ... and the default walk finds the light the reference loses on that ray
-    tri_d, _, _, _ = gpu.trace_closest(miss_o, miss_d, np.full(1, FLT_MAX, np.float32))
+    # ... and RT_FLAG_WATERTIGHT finds the light the reference loses on that ray
+    tri_d, _, _, _ = gpu.trace_closest(miss_o, miss_d, np.full(1, FLT_MAX, np.float32), flags=api.FLAG_WATERTIGHT)
     assert int(tri_d[0]) == 69462
-    occ = gpu.trace_any(log["any_o"], log["any_d"], log["any_tmax"], log["any_excluded"], flags=api.FLAG_REFERENCE_WALK)
+    occ = gpu.trace_any(log["any_o"], log["any_d"], log["any_tmax"], log["any_excluded"], flags=F)
     assert np.array_equal(occ, log["any_occluded"])
     tm2 = rng.uniform(0.05, 2.0, len(ao) + len(wall_o)).astype(np.float32)
     excl = rng.integers(-1, bunny_matte.n_tris, len(tm2)).astype(np.int32)
     o2, d2 = np.concatenate([ao, wall_o]), np.concatenate([ad, wall_d])
-    assert np.array_equal(gpu.trace_any(o2, d2, tm2, excl, flags=api.FLAG_REFERENCE_WALK),
-                          sc.trace_any(o2, d2, tm2, excl, threads=usable_cpus()))
+    assert np.array_equal(gpu.trace_any(o2, d2, tm2, excl, flags=F), sc.trace_any(o2, d2, tm2, excl, threads=usable_cpus()))
     assert n_log > 500_000 and len(occ) > 200_000
 
 
@@ -109,12 +119,14 @@ CASES = [
 ]
 
 
+@pytest.mark.parametrize("how", ["reference_walk", "default"])
 @pytest.mark.parametrize("variant,w,h,spp,max_bounces,seed", CASES)
-def test_reference_walk_frame_equals_the_literal_oracle(api, oracle, variant, w, h, spp, max_bounces, seed):
+def test_reference_walk_frame_equals_the_literal_oracle(api, oracle, variant, w, h, spp, max_bounces, seed, how):
+    """Whole frames against the LITERAL oracle: with RT_FLAG_REFERENCE_WALK and with the default kernels."""
     img_c, _, st_c = oracle_render(oracle, variant, w, h, spp, max_bounces=max_bounces, seed=seed, watertight=False)
     gpu = _gpu_scene(api, variant)
     img_g, st_g = gpu.render(api.make_camera(aspect=w / h), w, h, spp, max_bounces=max_bounces, seed=seed,
-                             flags=api.FLAG_REFERENCE_WALK)
+                             flags=api.FLAG_REFERENCE_WALK if how == "reference_walk" else 0)
     assert st_g["camera_rays"] == w * h * spp
     for kg, kc in EVENTS:
         assert st_g[kg] == st_c[kc], (kg, st_g[kg], st_c[kc])
@@ -122,25 +134,29 @@ def test_reference_walk_frame_equals_the_literal_oracle(api, oracle, variant, w,
     assert np.nan_to_num(np.abs(img_g.astype(np.float64) - img_c)).max() < 1e-4
 
 
-def test_reference_walk_differs_from_the_default_walk_where_the_audit_says(api, oracle):
-    """The sixteen-light 480 x 270 x 48 frame: the literal walk leaves 7 shadow rays unoccluded that exhaustive search --
-    and the default kernels -- find occluded.  Both modes on the GPU, each equal to its oracle mode."""
+def test_reference_walk_differs_from_the_watertight_walk_where_the_audit_says(api, oracle):
+    """The sixteen-light 480 x 270 x 48 frame: the reference's walk leaves 7 shadow rays unoccluded that exhaustive search --
+    and RT_FLAG_WATERTIGHT -- find occluded (DESIGN section 3).  All three modes on the GPU, each equal to its oracle mode;
+    the default kernels' counter of lost hits says 7."""
     w, h, spp = 480, 270, 48
     gpu = _gpu_scene(api, "sixteen_lights")
     cam = api.make_camera(aspect=w / h)
     _, st_ref = gpu.render(cam, w, h, spp, flags=api.FLAG_REFERENCE_WALK)
     _, st_def = gpu.render(cam, w, h, spp)
+    _, st_wat = gpu.render(cam, w, h, spp, flags=api.FLAG_WATERTIGHT)
     _, _, lit = oracle_render(oracle, "sixteen_lights", w, h, spp, watertight=False)
     _, _, wat = oracle_render(oracle, "sixteen_lights", w, h, spp, watertight=True)
     assert [st_ref[g] for g, _ in EVENTS] == [lit[c] for _, c in EVENTS]
-    assert [st_def[g] for g, _ in EVENTS] == [wat[c] for _, c in EVENTS]
+    assert [st_def[g] for g, _ in EVENTS] == [lit[c] for _, c in EVENTS]
+    assert [st_wat[g] for g, _ in EVENTS] == [wat[c] for _, c in EVENTS]
+    assert st_def["reference_lost_hits"] == 7, st_def
     assert [lit[c] for _, c in EVENTS] != [wat[c] for _, c in EVENTS]  # (the two definitions do differ on this frame)
 
 
 @pytest.mark.parametrize("variant,w,h,spp", [("matte", 160, 100, 160), ("full_bsdf", 128, 72, 256)])
 def test_reference_walk_reproduces_the_committed_literal_fixtures(api, variant, w, h, spp):
-    """tests/golden/render_goldens.npz `literal_*`: outputs of the literal oracle (tests/golden/make_golden.py).  The default
-    kernels are held to these within the audited bound; the reference walk must reproduce the counts EXACTLY."""
+    """tests/golden/render_goldens.npz `literal_*`: outputs of the literal oracle (tests/golden/make_golden.py).  The reference
+    walk must reproduce the counts EXACTLY (and so must the default kernels: tests/test_gpu_multigen.py)."""
     key = f"literal_{variant}_{w}x{h}x{spp}"
     gpu = _gpu_scene(api, variant)
     img, st = gpu.render(api.make_camera(aspect=w / h), w, h, spp, flags=api.FLAG_REFERENCE_WALK)
@@ -182,8 +198,7 @@ def _full_size_frames():
 @pytest.mark.parametrize("frame", _full_size_frames(), ids=lambda f: f"{f['scene']}_{f['width']}x{f['height']}x{f['spp']}")
 def test_every_full_baseline_frame_equals_the_literal_oracle_under_the_reference_walk(api, frame):
     """The six full BASELINE frames under RT_FLAG_REFERENCE_WALK: the five integer event totals EQUAL the committed
-    `oracle_literal` column (tests/golden/full_size_event_totals.json) -- where the default kernels equal the
-    `oracle_watertight` column and stay within the audited bound of this one."""
+    `oracle_literal` column (tests/golden/full_size_event_totals.json) -- as the default kernels do (tests/test_gpu_multigen.py)."""
     import torch
     w, h, spp = frame["width"], frame["height"], frame["spp"]
     gpu = _gpu_scene(api, frame["scene"])
@@ -240,11 +255,14 @@ def test_reference_walk_on_tiny_and_degenerate_scenes(api, oracle, name, arrays)
     cam = api.make_camera(aspect=1.0)
     got = torch.zeros(h * w * 3, dtype=torch.int64, device="cuda")
     st = gpu.render_shard_fixed(cam, w, h, spp, 0, 1, got.data_ptr(), flags=api.FLAG_REFERENCE_WALK)
+    got_d = torch.zeros_like(got)
+    st_d = gpu.render_shard_fixed(cam, w, h, spp, 0, 1, got_d.data_ptr())  # the default kernels on the same edge cases
     torch.cuda.synchronize()
     assert st["camera_rays"] == w * h * spp
     for kg, kc in EVENTS:
-        assert st[kg] == st_c[kc], (name, kg, st[kg], st_c[kc])
+        assert st[kg] == st_c[kc] == st_d[kg], (name, kg, st[kg], st_c[kc], st_d[kg])
     assert np.array_equal(got.cpu().numpy().reshape(h, w, 3), want)
+    assert torch.equal(got_d, got)
     img_m, st_m = gpu.render_multi(cam, w, h, spp, [0, 0], flags=api.FLAG_REFERENCE_WALK | api.FLAG_DETERMINISTIC)
     img_1, _ = gpu.render(cam, w, h, spp, flags=api.FLAG_REFERENCE_WALK | api.FLAG_DETERMINISTIC)
     assert all(st_m[kg] == st_c[kc] for kg, kc in EVENTS)
