@@ -26,8 +26,12 @@ Rank 0 prints ONE JSON line with the contract fields plus
                 spec / 2), next to the rate a pure v_fma_f32 kernel sustains in the same run.  SURVEY 8d's
                 algorithmic bytes at the REFERENCE's record sizes are kept as `reference_equivalent_GBs`.
   parity        (N = 1) the same scene at the CPU sample's spp rendered on the GPU and compared with the
-                oracle: integer event totals and image RMS -- the default kernels against the oracle's
-                watertight mode (equal), and RT_FLAG_REFERENCE_WALK against its literal mode (equal)
+                oracle: integer event totals and image RMS -- the default (timed) kernels AND RT_FLAG_REFERENCE_WALK
+                against the oracle's LITERAL mode (the reference's own tree, slab test and tie rule), RT_FLAG_WATERTIGHT
+                against its watertight mode; all three pairs equal
+  reference_decisions  how often the default kernels' rare paths ran in the timed frame: hits the reference's walk loses,
+                exact ties, literal re-traces (~2 rays in 10^7), and the frame time of the same frame under
+                RT_FLAG_WATERTIGHT (what making the reference's decisions costs)
   cpu_baseline  the CPU oracle (a port of the reference's algorithm; the reference itself needs
                 nvcc + cuRAND + CUB and cannot be built here) timed on a bounded sample
   multi_gpu     (N > 1) ranks the collective backend saw, every rank's camera rays and kernel time, the reduce timed
@@ -35,8 +39,9 @@ Rank 0 prints ONE JSON line with the contract fields plus
   per_sample    the same frame in the per-sample RNG mode (NOT the reference's random numbers; labelled so)
   extra_configs BASELINE configs 3, 4 and 5 (matte x 1024 spp, four bunnies x 256, sixteen lights x 512), a few frames
                 each, event totals against the committed oracle totals
-  reference_walk_mode  the headline frame once under RT_FLAG_REFERENCE_WALK (opt-in parity mode, not the timed kernels):
-                its rate, and its event totals against the committed totals of the oracle's LITERAL mode
+  reference_walk_mode  the headline frame once under RT_FLAG_REFERENCE_WALK (every ray through the reference's own tree: the
+                slow cross-check of the default kernels): its rate, and its event totals against the committed totals of
+                the oracle's LITERAL mode
 """
 import argparse
 import json
@@ -59,7 +64,8 @@ APPX_C = {  # scene: (NPc, TTc, NPa, TTa)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32 at 2.4 GHz; peak fp32 vector 157.3 TFLOP/s = 2 flop x 78.6 T lane-op/s
 VALU_PEAK_LANE_OPS = 256 * 4 * 32 * 2.4e9
-TOTAL_KEYS = ("camera_rays", "shade_events", "any_rays", "emission_adds", "shadow_adds", "rr_draws", "closest_rays")
+TOTAL_KEYS = ("camera_rays", "shade_events", "any_rays", "emission_adds", "shadow_adds", "rr_draws", "closest_rays",
+              "literal_retraces", "reference_lost_hits", "exact_ties")
 # BASELINE.json configs 3, 5 and 4 (the headline is config 2 = configs[1]); scene definitions in SURVEY.md section 8d
 EXTRA_CONFIGS = (("matte", 1024, "BASELINE configs[2]: bun_zipper.ply 1920x1080 1024 spp (the reference's all-matte scene)"),
                  ("sixteen_lights", 512, "BASELINE configs[4]: bun_zipper.ply + 16 area lights, 1920x1080 512 spp"),
@@ -74,8 +80,9 @@ def any_ray_bytes(np_a: float, tt_a: float) -> float:
     return 68.0 + 64.0 * np_a + 72.0 * tt_a
 
 
-def golden_totals(scene: str, w: int, h: int, spp: int, column: str = "oracle_watertight"):
-    """The committed oracle event totals of a full BASELINE frame (tests/golden/full_size_event_totals.json) or None."""
+def golden_totals(scene: str, w: int, h: int, spp: int, column: str = "oracle_literal"):
+    """The committed oracle event totals of a full BASELINE frame (tests/golden/full_size_event_totals.json) or None.
+    `oracle_literal`: the reference's own decisions -- what the default kernels reproduce; `oracle_watertight`: RT_FLAG_WATERTIGHT."""
     path = os.path.join(ROOT, "tests", "golden", "full_size_event_totals.json")
     if not os.path.exists(path):
         return None
@@ -282,9 +289,37 @@ def main():
     want = golden_totals(args.scene, w, h, spp) if (not per_sample_headline and args.max_bounces == 10) else None
     totals_rec = {"summed_over_ranks": head_totals, "golden": want,
                   "equal": (all(head_totals[k] == v for k, v in want.items()) and head_totals["camera_rays"] == w * h * spp) if want else None,
-                  "golden_source": "tests/golden/full_size_event_totals.json (oracle, watertight mode; the default kernels equal it exactly)"}
+                  "golden_source": "tests/golden/full_size_event_totals.json, column oracle_literal: the oracle in its LITERAL mode (the "
+                                   "reference's own tree, fp32 slab test and tie rule); the default kernels equal it exactly"}
     if totals_rec["equal"] is False and args.debug_flags == 0:
         invalid = "the frame's event totals differ from the committed oracle totals"
+
+    # ---- what making the reference's decisions costs: the same frame under RT_FLAG_WATERTIGHT (the triangle-list definition:
+    # no check of the hits), and how often the default kernels' rare paths ran in the timed frame
+    decisions = None
+    if not per_sample_headline and args.debug_flags == 0:
+        n_rays = float(head_totals["closest_rays"] + head_totals["any_rays"])
+        decisions = {"literal_retraces": head_totals["literal_retraces"], "reference_lost_hits": head_totals["reference_lost_hits"],
+                     "exact_ties": head_totals["exact_ties"],
+                     "literal_retrace_fraction_of_rays": head_totals["literal_retraces"] / max(n_rays, 1.0),
+                     "what": "default kernels = the product's walk + a check of every hit against what the reference's walk can see "
+                             "(ref_visible); a closest hit that is invisible to it, or tied at the final distance, is re-traced through "
+                             "the reference's own tree"}
+        if not args.no_extras:
+            wt = Config(env, arrays, w, h, spp, args.max_bounces, base_flags | api.FLAG_WATERTIGHT, args.deterministic)
+            wt_elapsed, wt_agg, wt_fail = wt.timed(2, 1, False)
+            wt_totals = wt.frame_totals()
+            wt_failed = rtdist.agree_on_failure(bool(wt_fail))
+            wt_want = golden_totals(args.scene, w, h, spp, "oracle_watertight") if args.max_bounces == 10 else None
+            wt_equal = (all(wt_totals[k] == v for k, v in wt_want.items()) and wt_totals["camera_rays"] == w * h * spp) if wt_want else None
+            decisions["watertight_flag"] = {
+                "what": "RT_FLAG_WATERTIGHT, 2 timed frames: the triangle-list definition (no hit lost to a box test, ties by caller "
+                        "index) -- NOT the reference's image on ~1 path in 4e6",
+                "ms_per_frame": None if wt_failed else round(1e3 * wt_elapsed / 2, 3),
+                "event_totals_equal_committed_WATERTIGHT_oracle_totals": wt_equal}
+            wt.close()
+            if wt_equal is False:
+                invalid = "RT_FLAG_WATERTIGHT: the frame's event totals differ from the committed watertight-oracle totals"
 
     # ---- the same frame in the OTHER RNG mode (per-sample streams: NOT the reference's random numbers), same steps
     sub_per_sample = None
@@ -332,11 +367,14 @@ def main():
                            "value": None if (e_failed or e_equal is False) else round(float(w) * h * e_spp * e_steps / e_elapsed / 1e6, 3),
                            "unit": "Msamples/s", "ms_per_frame": round(1e3 * e_elapsed / e_steps, 3),
                            "k_paths_ms_rank0": round(1e3 * e_agg["seconds_trace"] / max(e_agg["launches_trace"], 1), 3),
-                           "event_totals_equal_committed_oracle_totals": e_equal, "totals_summed_over_ranks": e_totals})
+                           "event_totals_equal_committed_LITERAL_oracle_totals": e_equal,
+                           "literal_retrace_fraction_of_rays": e_totals["literal_retraces"] / max(float(e_totals["closest_rays"] + e_totals["any_rays"]), 1.0),
+                           "totals_summed_over_ranks": e_totals})
             cfg.close()
             if scene_name == "sixteen_lights":
-                # the one BASELINE scene on which the timed kernels are NOT within 1e-4 RMS of the reference's literal walk (its
-                # slab test drops hits on the flat light boxes: DESIGN section 3): the same frame once in the mode that is
+                # the one BASELINE scene on which the triangle-list definition (RT_FLAG_WATERTIGHT; the timed kernels until round 4)
+                # is NOT within 1e-4 RMS of the reference's literal walk (its slab test drops hits on the flat light boxes: DESIGN
+                # section 3): the same frame once through the reference's own tree, as a cross-check of the timed frames above
                 cfg = Config(env, scenes.cornell_bunny(scene_name), w, h, e_spp, 10, base_flags | api.FLAG_REFERENCE_WALK, args.deterministic)
                 l_elapsed, _, l_fail = cfg.timed(1, 0, False)
                 l_totals = cfg.frame_totals()
@@ -344,18 +382,19 @@ def main():
                 l_want = golden_totals(scene_name, w, h, e_spp, "oracle_literal")
                 l_equal = (all(l_totals[k] == v for k, v in l_want.items()) and l_totals["camera_rays"] == w * h * e_spp) if l_want else None
                 extras[-1]["reference_walk_mode"] = {
-                    "what": "RT_FLAG_REFERENCE_WALK, one frame (incl. the reference-tree build): the reference algorithm's image ray for ray, "
-                            "also on the shadow rays its slab test leaves unoccluded; opt-in, not the timed kernels",
+                    "what": "RT_FLAG_REFERENCE_WALK, one frame: every ray through the reference's own tree -- the slow way to the totals the "
+                            "timed (default) kernels produced above",
                     "value": None if (l_failed or l_equal is False) else round(float(w) * h * e_spp / l_elapsed / 1e6, 3),
                     "unit": "Msamples/s", "ms_per_frame": round(1e3 * l_elapsed, 3),
                     "event_totals_equal_committed_LITERAL_oracle_totals": l_equal,
-                    "default_kernels_vs_literal_walk": "RMS 3.2e-4, 7 678 pixels over 1e-4, -1 519 NEE deposits of 1.95e9 shadow rays "
-                                                       "(profiles/r03_full_size_parity_sixteen_lights_512spp.json); equal to exhaustive search"}
+                    "watertight_flag_vs_literal_walk": "RMS 3.2e-4, 7 678 pixels over 1e-4, -1 519 NEE deposits of 1.95e9 shadow rays "
+                                                       "(profiles/r03_full_size_parity_sixteen_lights_512spp.json: what the timed kernels were "
+                                                       "until round 4); the default kernels now lose those 1 285 occluders as the reference does"}
                 cfg.close()
 
-    # ---- the headline frame ONCE in the opt-in parity mode RT_FLAG_REFERENCE_WALK (the reference's own tree, box test, order
-    # and tie rule): its event totals against the committed totals of the oracle's LITERAL mode -- the one mode in which the
-    # image is the reference algorithm's ray for ray, also on the rays its slab test loses.  Never the timed kernels.
+    # ---- the headline frame ONCE under RT_FLAG_REFERENCE_WALK (every ray through the reference's own tree, box test, order
+    # and tie rule): its event totals against the committed totals of the oracle's LITERAL mode -- the slow cross-check of what
+    # the timed kernels produce.  Never the timed kernels.
     ref_walk = None
     if not args.no_extras and not per_sample_headline and args.debug_flags == 0:
         cfg = Config(env, arrays, w, h, spp, args.max_bounces, base_flags | api.FLAG_REFERENCE_WALK, args.deterministic)
@@ -364,8 +403,8 @@ def main():
         r_failed = rtdist.agree_on_failure(bool(r_fail))
         r_want = golden_totals(args.scene, w, h, spp, "oracle_literal") if args.max_bounces == 10 else None
         r_equal = (all(r_totals[k] == v for k, v in r_want.items()) and r_totals["camera_rays"] == w * h * spp) if r_want else None
-        ref_walk = {"what": "RT_FLAG_REFERENCE_WALK, one frame (first use: includes building and uploading the reference's tree), "
-                            "opt-in parity mode: NOT the timed kernels",
+        ref_walk = {"what": "RT_FLAG_REFERENCE_WALK, one frame: the literal walk of the reference's own tree, cross-check mode: NOT the "
+                            "timed kernels (which reach the same totals on their own walk)",
                     "value": None if (r_failed or r_equal is False) else round(float(w) * h * spp / r_elapsed / 1e6, 3),
                     "unit": "Msamples/s", "ms_per_frame": round(1e3 * r_elapsed, 3),
                     "event_totals_equal_committed_LITERAL_oracle_totals": r_equal, "totals_summed_over_ranks": r_totals}
@@ -396,7 +435,7 @@ def main():
                 rec = json.loads(lines[-1])
                 ref_mean = float(torch.nanmean(frame_copy.double()).item())
                 in_process = dict(rec, what=what,
-                                  event_totals_equal_the_rank_sharded_frame=all(rec["totals"][k] == head_totals[k] for k in TOTAL_KEYS),
+                                  event_totals_equal_the_rank_sharded_frame=all(rec["totals"][k] == head_totals[k] for k in rec["totals"]),
                                   image_mean_of_the_rank_sharded_frame=ref_mean)
         except Exception as e:  # noqa: BLE001 -- reported in the line, never fatal for it (incl. the child's timeout)
             in_process = {"what": what, "devices": devices, "error": str(e)}
@@ -430,6 +469,7 @@ def main():
         out["event_totals"] = totals_rec
         if multi is not None:
             out["multi_gpu"] = multi
+        out["reference_decisions"] = decisions
         out["per_sample"] = sub_per_sample
         out["extra_configs"] = extras
         out["reference_walk_mode"] = ref_walk
@@ -479,12 +519,14 @@ def main():
                 np_a = ost["ah_node_pairs"] / ost["ah_rays"]
                 tt_a = ost["ah_tri_tests"] / ost["ah_rays"]
                 np_src = f"oracle statistics of the cpu_baseline sample ({args.cpu_spp} spp)"
-            # ---- parity of THIS binary on THIS box: the sample frame on the GPU against the oracle.  Two pairs, each held
-            # to equality: the default kernels against the oracle's watertight mode, and RT_FLAG_REFERENCE_WALK (the
-            # reference's own tree, box test and tie rule) against its literal mode -- the run just timed above.
+            # ---- parity of THIS binary on THIS box: the sample frame on the GPU against the oracle.  Three pairs, each held
+            # to equality: the default (timed) kernels and RT_FLAG_REFERENCE_WALK against the oracle's LITERAL mode -- the
+            # reference's own tree, box test and tie rule: the run just timed above -- and RT_FLAG_WATERTIGHT against its
+            # watertight mode.
             if not args.no_parity and args.debug_flags == 0 and not per_sample_headline:
                 sc0 = head.scene
                 gimg, gst = sc0.render(head.cam, w, h, args.cpu_spp, max_bounces=args.max_bounces, seed=1)
+                timg, tst = sc0.render(head.cam, w, h, args.cpu_spp, max_bounces=args.max_bounces, seed=1, flags=api.FLAG_WATERTIGHT)
                 wimg, _, wst = osc.set_watertight(True).render(ocam, w, h, args.cpu_spp, args.max_bounces, 1, threads=cores)
                 pairs = (("shade_events", "sum_mat"), ("any_rays", "sum_ah"), ("emission_adds", "emission_adds"),
                          ("shadow_adds", "ah_adds"), ("rr_draws", "rr_draws"))
@@ -495,31 +537,30 @@ def main():
                 out["parity"] = {
                     "frame": f"{w}x{h}x{args.cpu_spp} ({w * h * args.cpu_spp / (1 << 20):.1f} generations: all but the last "
                              f"run in the persistent kernel)",
-                    "events_equal": all(gst[g] == wst[o] for g, o in pairs) and gst["camera_rays"] == w * h * args.cpu_spp,
-                    "events": {g: [int(gst[g]), int(wst[o])] for g, o in pairs},
-                    "rms": rms_of(gimg, wimg), "max_abs": float(np.nanmax(np.abs(gimg - wimg))),
-                    "nan_pixels_gpu_oracle": [int(np.isnan(gimg).any(axis=2).sum()), int(np.isnan(wimg).any(axis=2).sum())],
-                    "vs_literal_reference_walk": {
-                        "what": "the TIMED (default) kernels against the literal oracle: they differ by the rays the reference's fp32 "
-                                "slab test loses (about 1 in 10^7; on the sixteen-light scene those rays carry whole light deposits)",
-                        "event_deltas": {g: int(gst[g]) - int(ost[o]) for g, o in pairs}, "rms": rms_of(gimg, oimg),
-                        "pixels_over_1e-4": int((np.nan_to_num(np.abs(gimg - oimg)).max(axis=2) > 1e-4).sum())},
-                    "tolerance": "north star: 1e-4 per-channel RMS; tests: equal event totals, RMS < 2e-6"}
-                if not out["parity"]["events_equal"] or out["parity"]["rms"] > 1e-4:
-                    invalid = "parity check failed: the GPU frame differs from the oracle"
-                # the default kernels may differ from the LITERAL walk only by the rays the reference's fp32 slab test loses:
-                # the audited rate is about 1 in 10^7 rays (tests/test_traversal_audit.py); 3 in 10^7 is the gate
-                lit = out["parity"]["vs_literal_reference_walk"]
-                n_rays = float(gst["closest_rays"] + gst["any_rays"])
-                ev_bound, px_bound = max(4, int(3e-7 * n_rays)), max(4, int(2e-7 * n_rays))
-                lit["audited_bounds"] = {"abs_event_delta": ev_bound, "pixels_over_1e-4": px_bound}
-                if max(abs(v) for v in lit["event_deltas"].values()) > ev_bound or lit["pixels_over_1e-4"] > px_bound:
-                    invalid = "the GPU frame differs from the LITERAL reference walk by more than the audited bound"
+                    "oracle_mode": "LITERAL: the reference's own tree (bvh.cuh:30-219), fp32 slab test on exact boxes "
+                                   "(aabb_intersector.cuh:14-36) and tie rule (triangle.cuh:49)",
+                    "events_equal": all(gst[g] == ost[o] for g, o in pairs) and gst["camera_rays"] == w * h * args.cpu_spp,
+                    "events": {g: [int(gst[g]), int(ost[o])] for g, o in pairs},
+                    "rms": rms_of(gimg, oimg), "max_abs": float(np.nanmax(np.abs(gimg - oimg))),
+                    "nan_pixels_gpu_oracle": [int(np.isnan(gimg).any(axis=2).sum()), int(np.isnan(oimg).any(axis=2).sum())],
+                    "rare_paths": {k: int(gst[k]) for k in ("literal_retraces", "reference_lost_hits", "exact_ties")},
+                    "watertight_flag": {
+                        "what": "RT_FLAG_WATERTIGHT against the oracle's watertight mode (no hit lost to a box test, ties by caller "
+                                "index): equal; against the literal oracle it differs by the rays the reference's fp32 slab test loses",
+                        "events_equal": all(tst[g] == wst[o] for g, o in pairs), "rms": rms_of(timg, wimg),
+                        "event_deltas_vs_literal": {g: int(tst[g]) - int(ost[o]) for g, o in pairs},
+                        "rms_vs_literal": rms_of(timg, oimg),
+                        "pixels_over_1e-4_vs_literal": int((np.nan_to_num(np.abs(timg - oimg)).max(axis=2) > 1e-4).sum())},
+                    "tolerance": "north star: 1e-4 per-channel RMS; here and in the tests: equal event totals, RMS < 2e-6 (float atomics)"}
+                if not out["parity"]["events_equal"] or out["parity"]["rms"] > 2e-6:
+                    invalid = "parity check failed: the GPU frame differs from the LITERAL oracle"
+                if not out["parity"]["watertight_flag"]["events_equal"] or out["parity"]["watertight_flag"]["rms"] > 2e-6:
+                    invalid = "parity check failed: the RT_FLAG_WATERTIGHT frame differs from the watertight oracle"
                 # ... and the mode that makes the reference's own decisions must reproduce the literal render exactly
                 rimg, rst = sc0.render(head.cam, w, h, args.cpu_spp, max_bounces=args.max_bounces, seed=1, flags=api.FLAG_REFERENCE_WALK)
                 out["parity"]["reference_walk_mode"] = {
-                    "what": "RT_FLAG_REFERENCE_WALK (opt-in, not the timed kernels) against the literal oracle: the reference's own "
-                            "tree, slab test, traversal order and tie rule on the GPU",
+                    "what": "RT_FLAG_REFERENCE_WALK (cross-check mode, not the timed kernels) against the literal oracle: every ray "
+                            "through the reference's own tree, slab test, traversal order and tie rule on the GPU",
                     "events_equal": all(rst[g] == ost[o] for g, o in pairs) and rst["camera_rays"] == w * h * args.cpu_spp,
                     "events": {g: [int(rst[g]), int(ost[o])] for g, o in pairs},
                     "rms": rms_of(rimg, oimg), "max_abs": float(np.nanmax(np.abs(rimg - oimg))),

@@ -14,7 +14,14 @@ What is checked here, without a GPU:
   * the oracle's `watertight` mode (conservative box decisions + a tree-independent rule for hits at exactly equal t:
     the larger caller index wins, where the reference lets its tree order decide -- SURVEY Appendix A.10) agrees with
     the product's walk on EVERY ray, triangle index included, which is why the GPU parity tests can demand equal
-    integer event totals against it at any frame size.
+    integer event totals against it at any frame size;
+  * round 5 -- the DEFAULT kernels' decision procedure (rtcuda_amd.hip: ref_visible + the rare literal re-trace), as its
+    CPU twin `rt_hostwalk_trace_verified`: the product's own walk, every hit checked against what the reference's walk can
+    SEE.  The reference's box test ignores tmax, so visibility is a function of the ray alone; the boxes on a root-to-leaf
+    path are nested exactly and fp32 rounding is monotone, so a triangle is visible iff its LEAF's box passes the
+    reference's slab test (and the triangle's own box passing implies that).  The verified walk must return the literal
+    walk's answer on EVERY ray -- lost hits and ties included -- and does, on > 4 * 10^7 rays of literal renders plus
+    axis-aligned, negative-zero and wall-hugging rays.
 """
 import ctypes
 import os
@@ -37,6 +44,7 @@ class HostWalk:
         self.lib.rt_hostwalk_create.argtypes = [ctypes.c_void_p, ctypes.c_int]
         self.lib.rt_hostwalk_destroy.argtypes = [ctypes.c_void_p]
         self.lib.rt_hostwalk_trace.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 6
+        self.lib.rt_hostwalk_trace_verified.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 7
         self.tris = np.ascontiguousarray(arrays.tris, np.float32)
         self.h = self.lib.rt_hostwalk_create(self.tris.ctypes.data, len(self.tris))
         assert self.h
@@ -57,6 +65,24 @@ class HostWalk:
         assert self.lib.rt_hostwalk_trace(self.h, 1, len(o), o.ctypes.data, d.ctypes.data, tm.ctypes.data,
                                           ex.ctypes.data, occ.ctypes.data, None) == 0
         return occ
+
+    def closest_verified(self, o, d, tmax=None):
+        """The default kernels' procedure for a path ray -> (triangle, t, stats6): see rt_hostwalk_trace_verified."""
+        o, d = np.ascontiguousarray(o, np.float32), np.ascontiguousarray(d, np.float32)
+        n = len(o)
+        tm = np.full(n, FLT_MAX, np.float32) if tmax is None else np.ascontiguousarray(tmax, np.float32)
+        tri, t, st = np.zeros(n, np.int32), np.zeros(n, np.float32), np.zeros(6, np.int64)
+        assert self.lib.rt_hostwalk_trace_verified(self.h, 0, n, o.ctypes.data, d.ctypes.data, tm.ctypes.data, None,
+                                                   tri.ctypes.data, t.ctypes.data, st.ctypes.data) == 0
+        return tri, t, dict(zip(("rays", "own_box_failed", "lost_hits", "ties", "neg_zero_rays", "literal_retraces"), st.tolist()))
+
+    def any_verified(self, o, d, tmax, excluded):
+        o, d = np.ascontiguousarray(o, np.float32), np.ascontiguousarray(d, np.float32)
+        tm, ex = np.ascontiguousarray(tmax, np.float32), np.ascontiguousarray(excluded, np.int32)
+        occ, st = np.zeros(len(o), np.int32), np.zeros(6, np.int64)
+        assert self.lib.rt_hostwalk_trace_verified(self.h, 1, len(o), o.ctypes.data, d.ctypes.data, tm.ctypes.data,
+                                                   ex.ctypes.data, occ.ctypes.data, None, st.ctypes.data) == 0
+        return occ, dict(zip(("rays", "own_box_failed", "lost_hits", "ties", "neg_zero_rays", "literal_retraces"), st.tolist()))
 
     def __del__(self):
         if getattr(self, "h", None):
@@ -137,3 +163,68 @@ def test_every_ray_of_a_render_replayed_through_the_product_walk(oracle, variant
     assert np.array_equal(tri, log["closest_tri"])  # ties included: both sides give them to the larger caller index
     for k in ("sum_mat", "sum_ah", "emission_adds", "ah_adds", "rr_draws"):
         assert abs(st_w[k] - st[k]) <= 8, k  # the two modes differ by a handful of rays at most
+
+
+@pytest.mark.parametrize("variant,w,h,spp,lost_any,lost_closest", [
+    ("matte", 256, 256, 40, 0, 1),            # the frame with the known lost hit (path ray 1 836 499)
+    ("sixteen_lights", 480, 270, 48, 7, 0),   # 7 shadow rays whose occluder the reference cannot see
+    ("full_bsdf", 200, 120, 24, None, None),
+])
+def test_verified_walk_returns_the_literal_walks_answer_on_every_ray(oracle, variant, w, h, spp, lost_any, lost_closest):
+    """The decision procedure of the DEFAULT kernels against the reference's literal walk, ray by ray: every path ray and
+    every shadow ray of a literal oracle render.  No tolerance: the hit triangle (ties included), t bit for bit, the
+    occlusion flag.  The plain product walk (RT_FLAG_WATERTIGHT) differs on exactly the rays the counters name."""
+    from rtcuda_amd import scenes
+    arrays = scenes.cornell_bunny(variant)
+    sc = oracle.scene(arrays)
+    walk = HostWalk(arrays)
+    oracle.raylog_enable(True)
+    sc.render(default_camera(oracle, w / h), w, h, spp, threads=os.cpu_count() or 8)
+    log = oracle.raylog_fetch()
+    oracle.raylog_enable(False)
+    occ, st_a = walk.any_verified(log["any_o"], log["any_d"], log["any_tmax"], log["any_excluded"])
+    assert np.array_equal(occ, log["any_occluded"])
+    plain = walk.any(log["any_o"], log["any_d"], log["any_tmax"], log["any_excluded"])
+    assert int((plain != log["any_occluded"]).sum()) == st_a["lost_hits"]  # each lost occluder flips one shadow ray
+    assert st_a["literal_retraces"] == 0                                    # shadow rays never need the literal walk
+    tri, t, st_c = walk.closest_verified(log["closest_o"], log["closest_d"])
+    hit = log["closest_tri"] >= 0
+    assert np.array_equal(tri, log["closest_tri"])
+    assert np.array_equal(t[hit].view(np.uint32), log["closest_t"][hit].view(np.uint32))
+    assert st_c["literal_retraces"] == st_c["lost_hits"] + st_c["ties"] <= 2e-6 * len(tri) + 4
+    if lost_any is not None:
+        assert (st_a["lost_hits"], st_c["lost_hits"]) == (lost_any, lost_closest)
+    # the own box is (nearly) as good a witness as the leaf's box: the common case never leaves the registers
+    assert st_a["own_box_failed"] + st_c["own_box_failed"] <= 1e-6 * (len(tri) + len(occ)) + 8
+
+
+def test_verified_walk_on_rays_chosen_to_break_it(oracle, bunny_matte, walk_matte):
+    """Rays along the axes (the FLT_EPSILON clamp of 1 / d), rays with NEGATIVE-zero components (the reference's octant says
+    "positive", its 1 / d is negative: nearly every box fails -- ref_visible then tests every ancestor), rays that start on
+    the walls and rays that graze the flat boxes of the axis-aligned triangles: closest hit and any hit, verified walk
+    against the oracle's literal walk, every ray."""
+    import raygen
+    sc = oracle.scene(bunny_matte)
+    rng = np.random.default_rng(77)
+    ao, ad = raygen.axis_aligned_rays(20000, seed=3)
+    nz_o, nz_d = raygen.axis_aligned_rays(20000, seed=4)
+    nz_d = np.where(nz_d == 0, np.float32(-0.0), nz_d)
+    wall_o = rng.uniform(0, 1, (40000, 3)).astype(np.float32)
+    wall_o[:, 2] = -wall_o[:, 2]
+    wall_o[np.arange(40000), rng.integers(0, 3, 40000)] = rng.choice(np.array([0.0, 1.0, -1.0, 0.999], np.float32), 40000)
+    wall_d = rng.normal(size=(40000, 3))
+    wall_d[:20000, 1] *= 1e-3  # grazing the floor / ceiling / light planes
+    wall_d = (wall_d / np.linalg.norm(wall_d, axis=1, keepdims=True)).astype(np.float32)
+    o, d = np.concatenate([ao, nz_o, wall_o]), np.concatenate([ad, nz_d, wall_d])
+    tmax = np.full(len(o), FLT_MAX, np.float32)
+    want = sc.trace_closest(o, d, tmax)
+    tri, t, st = walk_matte.closest_verified(o, d)
+    assert st["neg_zero_rays"] >= 20000
+    assert np.array_equal(tri, want[0])
+    hit = want[0] >= 0
+    assert np.array_equal(t[hit].view(np.uint32), want[1][hit].view(np.uint32))
+    assert hit.sum() > 10000
+    tm = rng.uniform(0.05, 2.0, len(o)).astype(np.float32)
+    excl = rng.integers(-1, bunny_matte.n_tris, len(o)).astype(np.int32)
+    occ, _ = walk_matte.any_verified(o, d, tm, excl)
+    assert np.array_equal(occ, sc.trace_any(o, d, tm, excl))

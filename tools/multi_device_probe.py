@@ -27,7 +27,8 @@ def main():
     t0 = time.perf_counter()
     img, st = sc.render_multi(cam, w, h, spp, devices, max_bounces=max_bounces, seed=1)
     t_second = time.perf_counter() - t0
-    keys = ("camera_rays", "shade_events", "any_rays", "emission_adds", "shadow_adds", "rr_draws", "closest_rays")
+    keys = ("camera_rays", "shade_events", "any_rays", "emission_adds", "shadow_adds", "rr_draws", "closest_rays", "literal_retraces",
+            "reference_lost_hits", "exact_ties")
     print(json.dumps({"devices": devices, "device_shards": st["device_shards"], "wall_ms_first_call": round(1e3 * t_first, 2),
                       "wall_ms": round(1e3 * t_second, 2), "device_ms_slowest_shard": round(1e3 * st["seconds_render"], 3),
                       "Msamples_per_s_wall": round(float(w) * h * spp / t_second / 1e6, 1),
