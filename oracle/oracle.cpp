@@ -4,9 +4,12 @@
 // cpu_baseline leg and __graft_entry__.smoke() may load it.  Nothing under rtcuda_amd/ links,
 // imports or calls it.
 //
-// PARITY UNPINNED.  The reference ships no test, fixture or golden image for this path and cannot be
-// built or run in this image (nvcc, cuRAND, CUB absent), so nothing the reference itself produced pins
-// this restatement: its pins are the known answers SURVEY.md Appendix C records
+// PARITY UNPINNED.  The reference ships no test, fixture or golden image for this path and its device code
+// cannot be built or run in this image (nvcc, cuRAND, CUB absent), so nothing the reference itself produced pins
+// this restatement of the RENDER path.  (Three of its files are pure host C++ and do build here -- happly.h,
+// matrix4x4.hpp, transform.hpp: oracle/Makefile target _ref_host -- and their output pins the scene
+// preparation, i.e. the geometry this oracle and the product render: tests/golden/ref_host_fixture.npz.)
+// Its pins are the known answers SURVEY.md Appendix C records
 // (tests/golden/appendix_c.json, tests/test_oracle_pins.py) and the committed outputs of its own two
 // modes (tests/golden/render_goldens.npz).  Of Appendix C's answers, the XORWOW states and draws, the
 // camera / triangle / offset / heuristic bit patterns, the BVH statistics, the per-iteration queue counts,

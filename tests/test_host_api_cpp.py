@@ -296,3 +296,79 @@ int run(const float *verts, int n, const int32_t *tri_mat, const int32_t *tri_li
 ''')
     subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"),
                            str(src)])
+
+
+# ----------------------------------------------------------------------------- the reference's OWN host code as the pin
+def _ref_host_tools():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_ref_host_fixture", os.path.join(ROOT, "tests", "golden", "make_ref_host_fixture.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod, np.load(os.path.join(ROOT, "tests", "golden", "ref_host_fixture.npz"))
+
+
+def _same_bits(a, b):
+    a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
+    return a.dtype == b.dtype and a.shape == b.shape and a.tobytes() == b.tobytes()
+
+
+def test_product_headers_write_what_the_references_own_host_code_wrote(tmp_path):
+    """tests/golden/ref_host_fixture.npz holds the OUTPUT OF THE REFERENCE'S OWN FILES: happly.h, matrix4x4.hpp and
+    transform.hpp are pure host C++, compile unmodified (oracle/Makefile, target _ref_host) and were run on bun_zipper.ply
+    through oracle/ref_host_driver.cpp (tests/golden/make_ref_host_fixture.py).  The SAME driver source compiled against the
+    product's own headers (include/rtcuda/ply.hpp, matrix4x4.hpp, transform.hpp) must write the same numbers, bit for bit:
+    35 947 parsed positions, 69 451 index triples, the composite bunny matrix (main.cu:68-70), every vertex after
+    Transform::apply and the Vec3 narrowing (main.cu:71,79-81), 12 Matrix4x4::Rotate matrices, 48 composite + apply results.
+    This is SURVEY section 8 rows f1 / f2 pinned by the reference itself, not by a restatement."""
+    mod, fx = _ref_host_tools()
+    exe = str(tmp_path / "ref_host_product")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-DREF_HOST_PRODUCT", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "oracle", "ref_host_driver.cpp"), "-o", exe])
+    out = str(tmp_path / "product.bin")
+    subprocess.check_call([exe, PLY, out])
+    got = mod.read_dump(out)
+    assert _same_bits(got["parsed_positions_f64"], fx["parsed_positions_f32"].astype(np.float64))
+    for k in ("faces", "bunny_matrix", "transformed_f32", "applied_every_997th_f64", "rotate_args", "rotate_matrices", "rotated_applies_f64"):
+        assert _same_bits(got[k], fx[k]), k
+    assert got["faces"].shape == (69451, 3) and got["transformed_f32"].shape == (35947, 3)  # bun_zipper.ply:4,10
+
+
+def test_python_scene_recipe_against_the_references_own_host_code():
+    """rtcuda_amd/scenes.py (the recipe every parity test and bench.py renders) against the same fixture: load_ply, the
+    composite bunny transform, apply_transform + narrowing -- bit for bit; rotate within an ulp of the reference's cosf /
+    sinf (numpy's fp32 cos / sin are not glibc's), composite + apply on the reference's own rotation matrices exactly."""
+    _, fx = _ref_host_tools()
+    pos, faces = scenes.load_ply(PLY)
+    assert _same_bits(pos.astype(np.float32), fx["parsed_positions_f32"])
+    assert np.array_equal(np.asarray(faces), fx["faces"])
+    m = scenes.bunny_transform()
+    assert _same_bits(m.astype(np.float32), fx["bunny_matrix"])
+    vt = scenes.apply_transform(m, pos.astype(np.float64))
+    assert _same_bits(vt, fx["transformed_f32"])
+    # the z a Transform::apply leaves is a double; x and y went through fp32 (transform.hpp:27-32)
+    kept = fx["applied_every_997th_f64"]
+    assert np.array_equal(kept[:, :2], vt[::997, :2].astype(np.float64)) and _same_bits(kept[:, 2].astype(np.float32), vt[::997, 2])
+    for args, want in zip(fx["rotate_args"], fx["rotate_matrices"]):
+        assert np.allclose(scenes.rotate(*args), want, rtol=0, atol=6e-8), args
+    pts = np.array([[-0.0378297, 0.12794, 0.00447467], [0.0, 0.0, 0.0], [1.0, -2.0, 3.0], [0.061, 0.1871, -0.0588]])
+    for k, rot in enumerate(fx["rotate_matrices"]):
+        got = scenes.apply_transform(scenes.composite(m, rot), pts)
+        want = fx["rotated_applies_f64"][4 * k:4 * k + 4]
+        assert _same_bits(got, want.astype(np.float32)), k
+        assert np.array_equal(want[:, :2], want[:, :2].astype(np.float32).astype(np.float64))  # x, y: fp32 values
+
+
+def test_reference_host_build_reproduces_the_committed_fixture(tmp_path):
+    """Where the reference is present (this container; never the GPU box): rebuild oracle/_ref/ref_host from the reference's
+    files where they lie, run it, and compare with the committed fixture -- the fixture is what the recipe says it is."""
+    ref = os.environ.get("REF", "/root/reference")
+    if not os.path.exists(os.path.join(ref, "happly.h")):
+        pytest.skip("the reference tree is not present here")
+    mod, fx = _ref_host_tools()
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "_ref_host", f"REF={ref}"], stdout=subprocess.DEVNULL)
+    out = str(tmp_path / "ref.bin")
+    subprocess.check_call([os.path.join(ROOT, "oracle", "_ref", "ref_host"), os.path.join(ref, "bun_zipper.ply"), out])
+    got = mod.read_dump(out)
+    assert _same_bits(got["parsed_positions_f64"], fx["parsed_positions_f32"].astype(np.float64))
+    for k in ("faces", "bunny_matrix", "transformed_f32", "applied_every_997th_f64", "rotate_args", "rotate_matrices", "rotated_applies_f64"):
+        assert _same_bits(got[k], fx[k]), k
