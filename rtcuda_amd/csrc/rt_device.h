@@ -14,6 +14,13 @@
 #include "rt_pinned_math.h"
 
 #define RT_DEV __device__ __forceinline__
+// tools/isa_census.py builds with -DRT_ISA_MARKS: assembler comments that say which source region an instruction belongs to
+// (profiles/r05_adv_census.md).  Nothing in a product build.
+#ifdef RT_ISA_MARKS
+#define RT_MARK(name) __asm__ volatile("; RT_MARK " name)
+#else
+#define RT_MARK(name)
+#endif
 
 namespace rt {
 

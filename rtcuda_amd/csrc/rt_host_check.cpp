@@ -69,6 +69,7 @@ struct WalkResult {
     long long nodes = 0, tris = 0, leaves = 0;
     int max_sp = 0;
     bool failed = false;
+    bool unseen_occluder = false;  // verified any-hit walks: the occluder found is invisible to the reference's walk
     float tie_t = -1.f;     // closest: the distance of the last EXACT tie between two accepted hits (a tie at the final t
                             // is what the reference's tree order decides: triangle.cuh:49)
     long long own_fail = 0, leaf_fail = 0;  // verified walks: hits whose own box / whose reference leaf box fails the reference's slab test
@@ -138,7 +139,8 @@ inline bool ref_visible(const RefView &rv, const RefSlab &s, const Tri &tr, int 
 // One ray through one of the two record formats.  wide: node = records cur, cur + 1 (children 0, 1 | 2, 3): the nearest
 // child the ray may enter becomes the cursor, the others are pushed in record order; 2-wide: near child, far child
 // pushed.  mode 0: closest hit (ties: the larger caller index, closest_hit_wins); mode 1: any hit but `excl`.
-// `rv` (verified walks, mode 1): an accepted hit only occludes if the reference's walk can see its triangle.
+// `rv` (verified walks, mode 1): the first accepted hit ends the walk, as always; if the reference's walk cannot see its
+// triangle, the result is flagged (`unseen_occluder`) and the caller asks the literal walk.
 WalkResult walk_ray(const std::vector<rtbvh::Pair> &rec, bool wide, const std::vector<Tri> &tris, const std::vector<int32_t> &order,
                     int stack_entries, int mode, V3 o, V3 d, float tmax, int excl, const RefView *rv = nullptr) {
     WalkResult w;
@@ -186,7 +188,11 @@ WalkResult walk_ray(const std::vector<rtbvh::Pair> &rec, bool wide, const std::v
                 w.tris++;
                 if (tri_hit(tris[k], o, d, tmax, t)) {
                     if (mode == 1) {
-                        if (k != excl && (!rv || ref_visible(*rv, slab, tris[k], order[k], w))) { w.occluded = true; break; }
+                        if (k != excl) {
+                            w.occluded = true;
+                            w.unseen_occluder = rv && !ref_visible(*rv, slab, tris[k], order[k], w);
+                            break;
+                        }
                     } else {
                         if (t == tmax && w.best >= 0) w.tie_t = t;
                         if (!(t == tmax && w.best >= 0) || order[k] > order[w.best]) {  // closest_hit_wins()
@@ -413,8 +419,8 @@ int rt_hostwalk_trace(void *h, int mode, int n_rays, const float *o3, const floa
 // The DEFAULT kernels' decision procedure on the CPU (k_paths / k_trace with VERIFY): the product's own walk, then
 //   closest hit: the hit stands if the reference's walk can see its triangle (ref_visible) and no exact tie occurred at
 //                the final distance; otherwise -- about one ray in 10^7 -- the ray is re-traced by the literal walk;
-//   any hit:     an accepted hit occludes only if the reference's walk can see its triangle (no re-trace needed: "is
-//                there a visible accepted triangle" does not depend on the order of the search);
+//   any hit:     the first accepted hit occludes if the reference's walk can see its triangle; if it cannot (~1 in 10^7),
+//                that hit says nothing about the rest of the ray, and the literal walk decides;
 //   (a ray with a -0.0 direction component: ref_visible tests every ancestor, see RefView).
 // The result must equal the reference's literal walk on EVERY ray (tests/test_traversal_audit.py).
 // stats6 += [rays, hits whose own box failed, hits whose leaf box failed (= hits the reference loses), exact ties at the
@@ -436,6 +442,13 @@ int rt_hostwalk_trace_verified(void *h, int mode, int n_rays, const float *o3, c
         negz += s.neg_zero ? 1 : 0;
         if (mode == 1) {
             res = walk_ray(rec, w.wide, w.tris, r.order, stack_entries, 1, o, d, tmax_in[i], excl, &w.ref);
+            if (res.unseen_occluder) {
+                lit++;
+                const bool failed = res.failed;
+                const long long of = res.own_fail, lf = res.leaf_fail;
+                literal_walk(w, 1, o, d, tmax_in[i], excl, res);
+                res.failed = failed; res.own_fail = of; res.leaf_fail = lf;
+            }
         } else {
             res = walk_ray(rec, w.wide, w.tris, r.order, stack_entries, 0, o, d, tmax_in[i], -1);
             if (res.best >= 0) {

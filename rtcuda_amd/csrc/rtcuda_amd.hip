@@ -499,6 +499,7 @@ __device__ __forceinline__ void advance_core(const DScene &sc, const float *tab,
     // path missed idles (no RNG use) until bounces reaches max_bounces; a slot that Russian roulette "killed" is
     // re-rolled by every following init() (Appendix A.1) -- beta, and with it the kill probability, does not change
     // along such a chain, so the chain is a tight loop of draws.  `lockstep`: exactly one init() per call.
+    RT_MARK("adv.init");
     if (st.bounces == 0 && hit && light_of_hit >= 0) {  // :98-103 emission only at bounce 0
         Light l = tab_light(tab, sc.num_mats, light_of_hit);
         if (USE_ACC) acc_add(acc, l.lx, l.ly, l.lz);  // (k_paths; a compile-time choice: `if (acc)` is a per-lane pointer test)
@@ -544,6 +545,7 @@ __device__ __forceinline__ void advance_core(const DScene &sc, const float *tab,
         return;
     }
     // ---- mat() :139-248
+    RT_MARK("adv.mat.sample_f");
     Material m = tab_material(tab, st.hit_info & 0xffff);
     V3 multiplier = scale(st.beta, (float)sc.num_lights);  // taken BEFORE the beta update (:150)
     {
@@ -555,6 +557,7 @@ __device__ __forceinline__ void advance_core(const DScene &sc, const float *tab,
         out.new_ray = true;
         st.beta = mul(st.beta, divf(scale(f, dot(wi, n)), pdf));  // :166
     }
+    RT_MARK("adv.mat.light_sample");
     if (sc.num_lights > 0) {
         int light_idx = min((int)(rng_uniform(st.rs) * sc.num_lights), sc.num_lights - 1);  // :178
         Light light = tab_light(tab, sc.num_mats, light_idx);
@@ -586,6 +589,7 @@ __device__ __forceinline__ void advance_core(const DScene &sc, const float *tab,
             Li = mk(light.lx, light.ly, light.lz);
             lpdf *= len2(sub(tp, st.isect_p)) / fabsf(dot(lun, wi));
         }
+        RT_MARK("adv.mat.nee");
         V3 n = dot(st.isect_n, wi) > 0.f ? st.isect_n : neg(st.isect_n);  // :187
         V3 f;
         float spdf;
@@ -604,8 +608,10 @@ __device__ __forceinline__ void advance_core(const DScene &sc, const float *tab,
             out.has_shadow = true;
         }
         // "sample BSDF with MIS" block :213-245: its ray cannot contribute; keep its draws
+        RT_MARK("adv.mat.burn");
         if (light.type != 0) mat_sample_f_burn(m, st.wo, st.isect_n, st.rs);
     }
+    RT_MARK("adv.mat.end");
 }
 
 // k_advance: one slot per thread, state in the pools.
@@ -1164,9 +1170,17 @@ __device__ __forceinline__ bool ref_visible(const DScene &sc, V3 o, V3 d, const 
     // the reference's slab setup (aabb_intersector.cuh:17-21): 1 / d with |d| clamped away from 0 -- the operand is a
     // unit vector's component, FLT_EPSILON <= |x| <= 1, where rcp_exact_normal IS the IEEE quotient (rt_device.h) -- and
     // the scaled origin (-o) * (1 / d)
+#ifndef RT_VERIFY_CLAMP
+    // (a component below FLT_EPSILON in magnitude -- where the reference clamps, and where a -0.0 would sit -- is left to the
+    // literal forms of the rare path: one min3 and one compare instead of three clamps and three sign tests)
+    const bool tiny = fminf(fabsf(d.x), fminf(fabsf(d.y), fabsf(d.z))) < kFltEps;
+    const V3 inv = mk(rcp_exact_normal(d.x), rcp_exact_normal(d.y), rcp_exact_normal(d.z));
+#else
+    const bool tiny = neg_zero3(d);
     const V3 inv = mk(rcp_exact_normal((fabsf(d.x) < kFltEps) ? copysignf(kFltEps, d.x) : d.x),
                       rcp_exact_normal((fabsf(d.y) < kFltEps) ? copysignf(kFltEps, d.y) : d.y),
                       rcp_exact_normal((fabsf(d.z) < kFltEps) ? copysignf(kFltEps, d.z) : d.z));
+#endif
     const V3 so = mul(neg(o), inv);
     // the triangle's own box (triangle.cuh:9-10,22-37)
     const V3 p1 = sub(tr.p0, tr.e1), p2 = add(tr.p0, tr.e2);
@@ -1182,11 +1196,17 @@ __device__ __forceinline__ bool ref_visible(const DScene &sc, V3 o, V3 d, const 
     const float tlz = inv.z * loz + so.z, thz = inv.z * hiz + so.z;
     const float entry = fmaxf(fminf(tlx, thx), fmaxf(fminf(tly, thy), fminf(tlz, thz)));
     const float exit = fminf(fmaxf(tlx, thx), fminf(fmaxf(tly, thy), fmaxf(tlz, thz)));
-    bool vis = entry <= exit && !neg_zero3(d);
+    bool vis = entry <= exit && !tiny;
     if (!vis) {  // rare (~1 hit in 10^7): the literal forms from here on
-        atomicAdd(&vstat[V_OWN_FAIL], 1ull);
         vis = sc.ref_root_leaf != 0;  // bvh.cuh:252 / :307: a root that is a leaf is intersected without any box test
         if (!vis) {
+            const RefSlab s = ref_slab(o, d);
+            float e;
+            // (the own box once more, literally: what the shortcut above could not decide -- a clamped or -0.0 component)
+            vis = !neg_zero3(d) && ref_box(s, make_float4(lox, hix, loy, hiy), make_float4(loz, hiz, 0.f, 0.f), e);
+        }
+        if (!vis) {
+            atomicAdd(&vstat[V_OWN_FAIL], 1ull);
             const RefSlab s = ref_slab(o, d);
             float e;
             int node = sc.ref_leaf_of[(unsigned)k];
@@ -1738,6 +1758,7 @@ k_paths(DScene sc, DPools p, Camera cam_arg, AdvanceParams ap_arg, float *__rest
     unsigned prio_tick = 0;
     const unsigned prio_rank = (4u * blockIdx.x) / gridDim.x;
     while (true) {
+        RT_MARK("loop.head");
         if (prio_period && (prio_tick++ & ((1u << prio_period) - 1u)) == 0u) {
             unsigned lvl = ((prio_tick >> prio_period) + prio_rank) & 3u;
             // ties go to the older wave, which left the two younger waves of a SIMD 5 % behind the two older ones;
@@ -1785,6 +1806,7 @@ k_paths(DScene sc, DPools p, Camera cam_arg, AdvanceParams ap_arg, float *__rest
         // or ran out of bounces (a third of all ADV work), or the ADV block found it Russian-roulette-killed to the
         // last bounce.  A tenth of the ADV block's length, so it runs for far fewer waiting lanes.
         if (SPLIT_GEN && !run_adv && n_genw > 0 && (n_genw >= gen_batch || n_node + n_tri == 0)) {
+            RT_MARK("gen.begin");
 #ifdef RT_TRACE_PROFILE
             pf[12]++; pf[15] += n_genw;
             const unsigned long long pf_tg = __builtin_readcyclecounter();
@@ -1871,6 +1893,7 @@ k_paths(DScene sc, DPools p, Camera cam_arg, AdvanceParams ap_arg, float *__rest
             pf_gen_cycles += __builtin_readcyclecounter() - pf_tg;
 #endif
             retake();
+            RT_MARK("gen.end");
         }
         if (run_adv) {
 #ifdef RT_TRACE_PROFILE
@@ -1878,6 +1901,7 @@ k_paths(DScene sc, DPools p, Camera cam_arg, AdvanceParams ap_arg, float *__rest
             const unsigned long long pf_ta = __builtin_readcyclecounter();
 #endif
             // ---------------- ADV block
+            RT_MARK("adv.head");
             AdvanceOut out;
             out.did_gen = out.did_shade = out.has_shadow = out.did_emit = out.new_ray = false;
             out.rr_draws = 0;
@@ -1891,7 +1915,12 @@ k_paths(DScene sc, DPools p, Camera cam_arg, AdvanceParams ap_arg, float *__rest
                 if (tri >= 0) {  // hit record in the form mat() consumes (render.cuh:152-153, 311-316)
                     Tri tr = load_tri(sc.tris, tri);
                     float4 sh = sc.tri_shade[(unsigned)tri];
+                    RT_MARK("adv.verify");
+#ifdef RT_DBG_NO_ADV_VERIFY  // (timing experiment only: the image is no longer the reference's)
+                    if (false) {
+#else
                     if (VERIFY) {
+#endif
                         // (o, d) are still the path ray that ended on `tri`.  A set sign bit of hv: an exact tie at the final
                         // distance (triangle block) -- or a v of -0.0, which costs a needless, equally exact re-trace
                         bool bad = (__float_as_uint(hv) >> 31) != 0u;
@@ -1910,6 +1939,7 @@ k_paths(DScene sc, DPools p, Camera cam_arg, AdvanceParams ap_arg, float *__rest
                             }
                         }
                     }
+                    RT_MARK("adv.hit_record");
                     if (!VERIFY || tri >= 0) {
                         st.isect_p = tri_point(tr, hu, hv);
                         st.isect_n = mk(sh.x, sh.y, sh.z);
@@ -1922,6 +1952,7 @@ k_paths(DScene sc, DPools p, Camera cam_arg, AdvanceParams ap_arg, float *__rest
                 st.rs = rs;
                 st.beta = beta;
                 advance_core<SPLIT_GEN, true, true>(sc, tab, cam, ap, ap.slot_lo + i, st, out, fb, acc);
+                RT_MARK("adv.tail");
                 bounces = st.bounces;
                 pixel = st.pixel;
                 gen = st.gen;
@@ -1983,6 +2014,7 @@ k_paths(DScene sc, DPools p, Camera cam_arg, AdvanceParams ap_arg, float *__rest
             pf[8] += __builtin_readcyclecounter() - pf_ta;
 #endif
             retake();
+            RT_MARK("adv.after");
         }
         const bool is_any = phase == PH_ANY;
         // ---------------- node steps for the lanes in `want`
@@ -1991,6 +2023,7 @@ k_paths(DScene sc, DPools p, Camera cam_arg, AdvanceParams ap_arg, float *__rest
             pf[2]++; pf[3] += n_want; pf[6] += n_adv;
             const unsigned long long pf_tn = __builtin_readcyclecounter();
 #endif
+            RT_MARK("node.begin");
             if (LITERAL) {
                 if (want) {
                     if (is_any) reference_walk<true>(sc, o, d, tmax, tri, hu, hv, stack, over, stack_cap);
@@ -2024,6 +2057,7 @@ k_paths(DScene sc, DPools p, Camera cam_arg, AdvanceParams ap_arg, float *__rest
 #ifdef RT_TRACE_PROFILE
             pf[9] += __builtin_readcyclecounter() - pf_tn;
 #endif
+            RT_MARK("node.end");
         };
         // ---------------- triangle tests (triangle.cuh:39-58) for the lanes in `want`: the leaf reference is the cursor
         auto tri_block = [&](bool want, int n_want) {
@@ -2031,6 +2065,7 @@ k_paths(DScene sc, DPools p, Camera cam_arg, AdvanceParams ap_arg, float *__rest
             pf[4]++; pf[5] += n_want; pf[7] += n_adv;
             const unsigned long long pf_tt = __builtin_readcyclecounter();
 #endif
+            RT_MARK("tri.begin");
             if (want) {
                 // kTriPerStep tests per lane, and ALL their triangle records are fetched before the first test: which
                 // triangles come next does not depend on the outcome of a test (only whether they are still wanted does: an
@@ -2063,14 +2098,14 @@ k_paths(DScene sc, DPools p, Camera cam_arg, AdvanceParams ap_arg, float *__rest
                 // the tests, each with the tmax the earlier ones left.  any-hit: the first accepted hit that is not the
                 // excluded triangle (bvh.cuh:243); closest-hit: bvh.cuh:227-231 (t <= tmax), ties by closest_hit_wins
                 bool occluded = false;
+                int occ_j = 0;  // which of the tests found the occluder
 #pragma unroll
                 for (int j = 0; j < kTriPerStep; j++) {
                     if (act[j] && !occluded) {
                         float t, u, v;
                         const bool hit = tri_intersect(tr[j], o, d, tmax, t, u, v);
                         occluded = hit && is_any && ks[j] != tri;
-                        // VERIFY: ... and only if the reference's walk can see that triangle (2 % of the shadow rays get here)
-                        if (VERIFY && occluded) occluded = ref_visible(sc, o, d, tr[j], ks[j], vstat);
+                        occ_j = occluded ? j : occ_j;
                         bool better = hit && !is_any;
                         if (better && t == tmax && tri >= 0) {
                             better = sc.order[(unsigned)ks[j]] > sc.order[(unsigned)tri];
@@ -2087,10 +2122,26 @@ k_paths(DScene sc, DPools p, Camera cam_arg, AdvanceParams ap_arg, float *__rest
                 }
                 pend = occluded ? kEntryDone : pd;
                 cur = occluded ? kEntryDone : cu;
+#ifndef RT_DBG_NO_TRI_VERIFY  // (timing experiment only)
+                // VERIFY: an occluder only counts if the reference's walk can see its triangle (2 % of the shadow rays get here;
+                // ONE branch behind both tests: inside each test it cost the block's straight-line shape, 2 % of the frame).  An
+                // occluder it cannot see -- ~1 in 10^7 -- says nothing about the rest of the ray: the ray ends here and is
+                // re-traced through the reference's own tree in the finished-rays section (hu = 2 marks it)
+                if (VERIFY && occluded) {
+                    static_assert(kTriPerStep == 2, "the occluder is picked from two records");
+                    Tri tq;
+                    tq.p0 = occ_j ? tr[1].p0 : tr[0].p0;
+                    tq.e1 = occ_j ? tr[1].e1 : tr[0].e1;
+                    tq.e2 = occ_j ? tr[1].e2 : tr[0].e2;
+                    tq.n = tq.p0;  // (not looked at)
+                    if (!ref_visible(sc, o, d, tq, occ_j ? ks[1] : ks[0], vstat)) hu = 2.f;
+                }
+#endif
             }
 #ifdef RT_TRACE_PROFILE
             pf[10] += __builtin_readcyclecounter() - pf_tt;
 #endif
+            RT_MARK("tri.end");
         };
         // Which of the two.  MAJORITY: the more popular block -- and when that is the node block, the triangle block right
         // behind it for the lanes that hold a leaf BY THEN (at least `tri_follow` of them): a lane that reached a leaf in
@@ -2100,7 +2151,24 @@ k_paths(DScene sc, DPools p, Camera cam_arg, AdvanceParams ap_arg, float *__rest
         if (!MAJORITY) {
             if (n_node > 0) node_block(want_node, n_node);
             if (n_tri > 0) tri_block(want_tri, n_tri);
-        } else if (n_node > 0 && n_node >= n_tri) {
+        }
+#ifndef RT_TRI_TWO_COPIES
+        else {
+            // (ONE copy of the triangle block in the code: the block behind a node block and the block on its own are the same
+            // instructions for different lanes)
+            const bool run_node = n_node > 0 && n_node >= n_tri;
+            bool w = want_tri;
+            int nw = n_tri;
+            if (run_node) {
+                node_block(want_node, n_node);
+                w = tri_follow > 0 && trav && ((cur != kEntryDone && cur < 0) || (kSpeculate && pend != kEntryDone));
+                nw = wave_count(w);
+                nw = (tri_follow > 0 && nw >= tri_follow) ? nw : 0;
+            }
+            if (nw > 0) tri_block(w, nw);
+        }
+#else
+        else if (n_node > 0 && n_node >= n_tri) {
             node_block(want_node, n_node);
             if (tri_follow > 0) {
                 const bool w = trav && ((cur != kEntryDone && cur < 0) || (kSpeculate && pend != kEntryDone));
@@ -2110,13 +2178,27 @@ k_paths(DScene sc, DPools p, Camera cam_arg, AdvanceParams ap_arg, float *__rest
         } else if (n_tri > 0) {
             tri_block(want_tri, n_tri);
         }
+#endif
         // ---------------- finished rays
+        RT_MARK("fin.begin");
         const bool fin = trav && cur == kEntryDone && (!kSpeculate || pend == kEntryDone);
 #ifdef RT_TRACE_PROFILE
         const unsigned long long pf_tf = __builtin_readcyclecounter();
         pf_fin_lanes += wave_count(fin);
         pf_fin_iters += wave_ballot(fin) != 0 ? 1 : 0;
 #endif
+        if (VERIFY) {  // the shadow rays whose occluder the reference cannot see (triangle block): the literal walk decides
+            const bool lit = fin && is_any && hu == 2.f;
+            if (wave_ballot(lit)) {
+                if (lit) {
+                    atomicAdd(&vstat[V_LITERAL], 1ull);
+                    float tm = tmax, no_v = 0.f;
+                    int excluded = tri;
+                    hu = 0.f;
+                    reference_walk<true>(sc, o, d, tm, excluded, hu, no_v, stack, over, stack_cap);
+                }
+            }
+        }
         n_deposit += wave_count((fin && is_any && hu == 0.f));
         if (fin) {
             if (is_any) {

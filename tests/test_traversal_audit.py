@@ -185,8 +185,8 @@ def test_verified_walk_returns_the_literal_walks_answer_on_every_ray(oracle, var
     occ, st_a = walk.any_verified(log["any_o"], log["any_d"], log["any_tmax"], log["any_excluded"])
     assert np.array_equal(occ, log["any_occluded"])
     plain = walk.any(log["any_o"], log["any_d"], log["any_tmax"], log["any_excluded"])
-    assert int((plain != log["any_occluded"]).sum()) == st_a["lost_hits"]  # each lost occluder flips one shadow ray
-    assert st_a["literal_retraces"] == 0                                    # shadow rays never need the literal walk
+    assert int((plain != log["any_occluded"]).sum()) <= st_a["lost_hits"]  # a lost occluder flips the shadow ray (unless another hides it too)
+    assert st_a["literal_retraces"] == st_a["lost_hits"]                    # a shadow ray is re-traced only for an unseen occluder
     tri, t, st_c = walk.closest_verified(log["closest_o"], log["closest_d"])
     hit = log["closest_tri"] >= 0
     assert np.array_equal(tri, log["closest_tri"])
