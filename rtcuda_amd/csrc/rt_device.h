@@ -201,11 +201,19 @@ RT_DEV bool mat_get_f(const Material &m, V3 wo, V3 wi, V3 n, V3 &f, float &pdf) 
     }
     return false;
 }
-// :60-109 -- mutates n so that n and wi share a hemisphere
-RT_DEV V3 mat_sample_f(const Material &m, V3 wo, Rng &rs, V3 &n, V3 &wi, float &pdf) {
+// :60-109 -- mutates n so that n and wi share a hemisphere.
+// `again_draws`: how many uniforms a SECOND call with the same (material, wo, n) consumes -- mat()'s "sample BSDF with MIS"
+// block makes one (render.cuh:218: same unit_wo, isect_unit_n again) whose ray can never be credited (Appendix A.3), so
+// only its effect on the RNG stream is kept, and that is decided by values this call computes anyway: 2 for matte
+// (uniform_sample_sphere), 0 for a mirror, and for glass 1 unless the ray cannot refract (the Schlick draw :94).  (Until
+// round 4 a second function recomputed cos / sin / the refraction test for that: 60 vector instructions per shade.  The
+// oracle makes the second call in full, as the reference does: every parity test holds the two against each other.)
+RT_DEV V3 mat_sample_f(const Material &m, V3 wo, Rng &rs, V3 &n, V3 &wi, float &pdf, int &again_draws) {
+    again_draws = 0;
     if (m.type == 0 || m.type == 1) {
         if (dot(wo, n) > 0.f) n = neg(n);
         if (m.type == 0) {
+            again_draws = 2;
             wi = unit(add(n, uniform_sample_sphere(rs)));
             pdf = dot(wi, n) * kInvPi;
             return scale(mk(m.ax, m.ay, m.az), kInvPi);
@@ -228,6 +236,7 @@ RT_DEV V3 mat_sample_f(const Material &m, V3 wo, Rng &rs, V3 &n, V3 &wi, float &
             pdf = 1.f;
             return mk(inv_cos, inv_cos, inv_cos);
         }
+        again_draws = 1;
         float r0 = (1 - m.ior) / (1 + m.ior);
         r0 = r0 * r0;
         float reflectance = r0 + (1 - r0) * rt_pow5f(1 - cos_theta);
@@ -247,23 +256,6 @@ RT_DEV V3 mat_sample_f(const Material &m, V3 wo, Rng &rs, V3 &n, V3 &wi, float &
         }
     }
 }
-// The RNG draws the SECOND sample_f call of mat() consumes (render.cuh:218).  Its ray (the
-// "CH shadow ray") targets the shading triangle itself and can never be credited
-// (render.cuh:236,321), so only its side effect on the RNG stream is kept.
-RT_DEV void mat_sample_f_burn(const Material &m, V3 wo, V3 n, Rng &rs) {
-    if (m.type == 0) {
-        rng_next(rs);
-        rng_next(rs);
-    } else if (m.type == 2) {
-        float cos_theta = dot(wo, n);
-        bool front = cos_theta < 0.f;
-        if (front) cos_theta = -cos_theta;
-        float eta = front ? 1.f / m.ior : m.ior;
-        float sin_theta = sqrtf(1.f - cos_theta * cos_theta);
-        if (!(eta * sin_theta > 1.f)) rng_next(rs);
-    }
-}
-
 // ------------------------------------------------------------------ light.cuh
 struct Light {
     int type;  // 0 POINT 1 AREA

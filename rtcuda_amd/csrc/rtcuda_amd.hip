@@ -548,10 +548,11 @@ __device__ __forceinline__ void advance_core(const DScene &sc, const float *tab,
     RT_MARK("adv.mat.sample_f");
     Material m = tab_material(tab, st.hit_info & 0xffff);
     V3 multiplier = scale(st.beta, (float)sc.num_lights);  // taken BEFORE the beta update (:150)
+    int again_draws;
     {
         V3 n = st.isect_n, wi;
         float pdf;
-        V3 f = mat_sample_f(m, st.wo, st.rs, n, wi, pdf);
+        V3 f = mat_sample_f(m, st.wo, st.rs, n, wi, pdf, again_draws);
         out.ray_o = offset_ray_origin(st.isect_p, n);
         out.ray_d = wi;
         out.new_ray = true;
@@ -609,7 +610,10 @@ __device__ __forceinline__ void advance_core(const DScene &sc, const float *tab,
         }
         // "sample BSDF with MIS" block :213-245: its ray cannot contribute; keep its draws
         RT_MARK("adv.mat.burn");
-        if (light.type != 0) mat_sample_f_burn(m, st.wo, st.isect_n, st.rs);
+        if (light.type != 0) {  // (the first call already knows how many: see mat_sample_f)
+            if (again_draws >= 1) rng_next(st.rs);
+            if (again_draws >= 2) rng_next(st.rs);
+        }
     }
     RT_MARK("adv.mat.end");
 }
