@@ -313,23 +313,30 @@ inline void prepare(const Scene &scene) { (void)rtcuda_detail::realise(scene); }
 inline std::vector<int> devices_from_env() {
     std::vector<int> d;
     if (const char *e = std::getenv("RTCUDA_DEVICES")) {
+        // a typo must not silently change which GPUs render: anything but non-negative integers separated by
+        // single commas is an error, and so is an empty list
+        const std::string text(e);
         const char *q = e;
-        while (*q) {
+        while (true) {
             char *end = nullptr;
-            long v = std::strtol(q, &end, 10);
-            if (end == q) break;
+            const long v = std::strtol(q, &end, 10);
+            if (end == q || v < 0 || v > 1 << 20 || (*end != ',' && *end != 0))
+                throw std::runtime_error("RTCUDA_DEVICES=\"" + text + "\": expected a comma-separated list of device ordinals, e.g. 0,1,2,3");
             d.push_back((int)v);
-            q = (*end == ',') ? end + 1 : end;
+            if (*end == 0) break;
+            q = end + 1;
         }
     }
     return d;
 }
 
-// ... and the library's modes: RTCUDA_REFERENCE_WALK=1 (RT_FLAG_REFERENCE_WALK: the reference's own tree, box test and tie rule
-// -- the reference algorithm's image ray for ray, about a tenth of the speed) and RTCUDA_DETERMINISTIC=1
-// (RT_FLAG_DETERMINISTIC: order-independent fixed-point accumulation, bit-reproducible image).
+// ... and the library's modes: RTCUDA_WATERTIGHT=1 (RT_FLAG_WATERTIGHT: the triangle-list definition of the hits instead of the
+// reference's -- no accepted hit lost to a box test, ties by caller index), RTCUDA_REFERENCE_WALK=1 (RT_FLAG_REFERENCE_WALK: every
+// ray through the reference's own tree; the same image as the default, several times slower: a cross-check) and
+// RTCUDA_DETERMINISTIC=1 (RT_FLAG_DETERMINISTIC: order-independent fixed-point accumulation, bit-reproducible image).
 inline uint32_t flags_from_env() {
     uint32_t f = 0;
+    if (const char *e = std::getenv("RTCUDA_WATERTIGHT")) f |= std::atoi(e) != 0 ? RT_FLAG_WATERTIGHT : 0u;
     if (const char *e = std::getenv("RTCUDA_REFERENCE_WALK")) f |= std::atoi(e) != 0 ? RT_FLAG_REFERENCE_WALK : 0u;
     if (const char *e = std::getenv("RTCUDA_DETERMINISTIC")) f |= std::atoi(e) != 0 ? RT_FLAG_DETERMINISTIC : 0u;
     return f;

@@ -30,9 +30,11 @@ FLAG_WATERTIGHT = 16     # the triangle-list definition (no hit lost to a box te
 EXPORTS = [
     "rt_scene_create", "rt_scene_destroy", "rt_scene_info", "rt_scene_build_info", "rt_camera_make", "rt_render", "rt_render_multi",
     "rt_render_shard", "rt_render_shard_fixed", "rt_post_process", "rt_post_process_fixed", "rt_trace_closest", "rt_trace_any",
-    "rt_trace_closest_flags", "rt_trace_any_flags", "rt_xorwow_states",
-    "rt_measure_copy_bandwidth", "rt_calibrate_valu", "rt_calibrate_valu_packed", "rt_probe_issue", "rt_split_probe", "rt_last_error", "rt_version", "rt_build_id",
+    "rt_trace_closest_flags", "rt_trace_any_flags", "rt_xorwow_states", "rt_shutdown", "rt_peer_access_log", "rt_last_error", "rt_version", "rt_build_id",
 ]
+# the lab (include/rtcuda_amd_tools.h, librtcuda_amd_tools.so): measurement tools, not part of the drop-in C-ABI
+TOOLS_LIB_PATH = os.path.join(_PKG, "librtcuda_amd_tools.so")
+TOOLS_EXPORTS = ["rt_measure_copy_bandwidth", "rt_calibrate_valu", "rt_calibrate_valu_packed", "rt_probe_issue", "rt_split_probe"]
 
 
 class RtError(RuntimeError):
@@ -104,7 +106,12 @@ def lib():
             f"{LIB_PATH} not found: the HIP library is the product and there is no fallback. "
             f"Build it with `make -C {CSRC}` (or python -c 'import __graft_entry__ as g; g.build()').")
     _preload_hip_runtime()
-    L = ctypes.CDLL(LIB_PATH)
+    _lib = _bind(ctypes.CDLL(LIB_PATH))
+    return _lib
+
+
+def _bind(L):
+    """Argument types of the drop-in C-ABI (include/rtcuda_amd.h) on a loaded library."""
     vp, ci, cf = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
     L.rt_last_error.restype = ctypes.c_char_p
     L.rt_version.restype = ctypes.c_char_p
@@ -127,13 +134,42 @@ def lib():
     L.rt_trace_closest_flags.argtypes = [vp, ctypes.c_uint32, ci, vp, vp, vp, vp, vp, vp, vp]
     L.rt_trace_any_flags.argtypes = [vp, ctypes.c_uint32, ci, vp, vp, vp, vp, vp]
     L.rt_xorwow_states.argtypes = [ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, ci, vp, vp]
+    L.rt_shutdown.restype = None
+    L.rt_peer_access_log.restype = ctypes.c_char_p
+    return L
+
+
+_tools = None
+
+
+def tools_lib():
+    """The LAB library (librtcuda_amd_tools.so: the product's translation unit + the measurement tools of
+    include/rtcuda_amd_tools.h).  Loaded on first use by bench.py's roofline block and tools/*.py -- never by a render."""
+    global _tools
+    if _tools is not None:
+        return _tools
+    if not os.path.exists(TOOLS_LIB_PATH):
+        raise ImportError(f"{TOOLS_LIB_PATH} not found: build it with `make -C {CSRC}`")
+    _preload_hip_runtime()
+    L = _bind(ctypes.CDLL(TOOLS_LIB_PATH))
+    vp, ci = ctypes.c_void_p, ctypes.c_int
     L.rt_measure_copy_bandwidth.argtypes = [ctypes.c_int64, ci, ctypes.POINTER(ctypes.c_double)]
     L.rt_calibrate_valu.argtypes = [ci, ci, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
     L.rt_calibrate_valu_packed.argtypes = [ci, ci, ci, ctypes.POINTER(ctypes.c_double)]
     L.rt_probe_issue.argtypes = [ci, ci, ci, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
     L.rt_split_probe.argtypes = [vp, vp, ci, ci, ci, ci, ctypes.c_uint64, ctypes.c_int64, vp, ci]
-    _lib = L
+    _tools = L
     return L
+
+
+def shutdown() -> None:
+    """Release the library's hidden device allocations (render contexts, cached output buffers): rt_shutdown."""
+    lib().rt_shutdown()
+
+
+def peer_access_log() -> str:
+    """rt_render_multi: what became of peer access between the listed devices (rt_peer_access_log)."""
+    return lib().rt_peer_access_log().decode()
 
 
 def build_id() -> str:
@@ -141,9 +177,9 @@ def build_id() -> str:
     return lib().rt_build_id().decode()
 
 
-def _check(rc: int, what: str) -> None:
+def _check(rc: int, what: str, library=None) -> None:
     if rc != 0:
-        raise RtError(f"{what}: {lib().rt_last_error().decode(errors='replace')}")
+        raise RtError(f"{what}: {(library or lib()).rt_last_error().decode(errors='replace')}")
 
 
 def _p(a):
@@ -162,8 +198,10 @@ def make_camera(lookfrom=(0.5, 0.5, 1.5), lookat=(0.5, 0.5, 0.0), up=(0.0, 1.0, 
 class Scene:
     """Device-resident scene (triangles, materials, lights, BVH) on the current HIP device."""
 
-    def __init__(self, arrays: SceneArrays):
-        L = lib()
+    def __init__(self, arrays: SceneArrays, library=None):
+        """`library`: the loaded library that owns the scene -- the product (default) or `tools_lib()`, whose private copy of
+        the product's entry points is what rt_split_probe works on."""
+        L = self.L = library or lib()
         self.arrays = arrays
         tris = np.ascontiguousarray(arrays.tris, np.float32)
         tm = np.ascontiguousarray(arrays.tri_material, np.int32)
@@ -173,12 +211,12 @@ class Scene:
         assert mats.dtype.itemsize == 20 and lights.dtype.itemsize == 32
         h = ctypes.c_void_p()
         _check(L.rt_scene_create(_p(tris), tris.shape[0], _p(tm), _p(tl), _p(mats), mats.shape[0], _p(lights),
-                                 lights.shape[0], ctypes.byref(h)), "rt_scene_create")
+                                 lights.shape[0], ctypes.byref(h)), "rt_scene_create", L)
         self.h = h
 
     def close(self):
         if getattr(self, "h", None):
-            lib().rt_scene_destroy(self.h)
+            self.L.rt_scene_destroy(self.h)
             self.h = None
 
     def __del__(self):
@@ -189,9 +227,9 @@ class Scene:
 
     def info(self) -> dict:
         out = np.zeros(4, np.int64)
-        _check(lib().rt_scene_info(self.h, _p(out)), "rt_scene_info")
+        _check(self.L.rt_scene_info(self.h, _p(out)), "rt_scene_info", self.L)
         b, sec = ctypes.c_int(0), ctypes.c_double(0.0)
-        _check(lib().rt_scene_build_info(self.h, ctypes.byref(b), ctypes.byref(sec)), "rt_scene_build_info")
+        _check(self.L.rt_scene_build_info(self.h, ctypes.byref(b), ctypes.byref(sec)), "rt_scene_build_info", self.L)
         return {"pairs": int(out[0]), "tris": int(out[1]), "max_depth": int(out[2]), "leaves": int(out[3]),
                 "builder": "lbvh" if b.value else "sah", "build_seconds": sec.value}
 
@@ -202,8 +240,8 @@ class Scene:
         cam = np.ascontiguousarray(camera, np.float32)
         out = np.zeros((height, width, 3), np.float32)
         st = RtStats()
-        _check(lib().rt_render(self.h, _p(cam), width, height, spp, max_bounces, seed, flags, _p(out),
-                               ctypes.byref(st)), "rt_render")
+        _check(self.L.rt_render(self.h, _p(cam), width, height, spp, max_bounces, seed, flags, _p(out),
+                               ctypes.byref(st)), "rt_render", self.L)
         return out, st.as_dict()
 
     def render_multi(self, camera: np.ndarray, width: int, height: int, spp: int, devices, max_bounces: int = 10,
@@ -213,8 +251,8 @@ class Scene:
         dev = np.ascontiguousarray(devices, np.int32)
         out = np.zeros((height, width, 3), np.float32)
         st = RtStats()
-        _check(lib().rt_render_multi(self.h, _p(cam), width, height, spp, max_bounces, seed, flags, _p(dev), int(dev.shape[0]),
-                                     _p(out), ctypes.byref(st)), "rt_render_multi")
+        _check(self.L.rt_render_multi(self.h, _p(cam), width, height, spp, max_bounces, seed, flags, _p(dev), int(dev.shape[0]),
+                                     _p(out), ctypes.byref(st)), "rt_render_multi", self.L)
         d = st.as_dict()
         d["device_shards"] = int(st.reserved[3])
         return out, d
@@ -225,9 +263,9 @@ class Scene:
         """Adds this shard's raw sums into the DEVICE buffer at ``d_sum_ptr`` (w*h*3 floats)."""
         cam = np.ascontiguousarray(camera, np.float32)
         st = RtStats()
-        _check(lib().rt_render_shard(self.h, _p(cam), width, height, spp, max_bounces, seed, shard_index,
+        _check(self.L.rt_render_shard(self.h, _p(cam), width, height, spp, max_bounces, seed, shard_index,
                                      shard_count, flags, ctypes.c_void_p(d_sum_ptr), ctypes.c_void_p(stream),
-                                     ctypes.byref(st)), "rt_render_shard")
+                                     ctypes.byref(st)), "rt_render_shard", self.L)
         return st.as_dict()
 
     def render_shard_fixed(self, camera: np.ndarray, width: int, height: int, spp: int, shard_index: int,
@@ -236,9 +274,9 @@ class Scene:
         """Order-independent accumulation: adds int64 fixed-point sums (2^-30) into the DEVICE buffer."""
         cam = np.ascontiguousarray(camera, np.float32)
         st = RtStats()
-        _check(lib().rt_render_shard_fixed(self.h, _p(cam), width, height, spp, max_bounces, seed, shard_index,
+        _check(self.L.rt_render_shard_fixed(self.h, _p(cam), width, height, spp, max_bounces, seed, shard_index,
                                            shard_count, flags, ctypes.c_void_p(d_sum_fixed_ptr), ctypes.c_void_p(stream),
-                                           ctypes.byref(st)), "rt_render_shard_fixed")
+                                           ctypes.byref(st)), "rt_render_shard_fixed", self.L)
         return st.as_dict()
 
     # ---- stage-level entry points (parity tests)
@@ -251,11 +289,11 @@ class Scene:
         tri = np.zeros(n, np.int32)
         t, u, v = (np.zeros(n, np.float32) for _ in range(3))
         if flags:
-            _check(lib().rt_trace_closest_flags(self.h, flags, n, _p(o3), _p(d3), _p(tmax), _p(tri), _p(t), _p(u), _p(v)),
-                   "rt_trace_closest_flags")
+            _check(self.L.rt_trace_closest_flags(self.h, flags, n, _p(o3), _p(d3), _p(tmax), _p(tri), _p(t), _p(u), _p(v)),
+                   "rt_trace_closest_flags", self.L)
         else:
-            _check(lib().rt_trace_closest(self.h, n, _p(o3), _p(d3), _p(tmax), _p(tri), _p(t), _p(u), _p(v)),
-                   "rt_trace_closest")
+            _check(self.L.rt_trace_closest(self.h, n, _p(o3), _p(d3), _p(tmax), _p(tri), _p(t), _p(u), _p(v)),
+                   "rt_trace_closest", self.L)
         return tri, t, u, v
 
     def trace_any(self, o3, d3, tmax, excluded, flags: int = 0):
@@ -266,10 +304,10 @@ class Scene:
         n = o3.shape[0]
         occ = np.zeros(n, np.int32)
         if flags:
-            _check(lib().rt_trace_any_flags(self.h, flags, n, _p(o3), _p(d3), _p(tmax), _p(excluded), _p(occ)),
-                   "rt_trace_any_flags")
+            _check(self.L.rt_trace_any_flags(self.h, flags, n, _p(o3), _p(d3), _p(tmax), _p(excluded), _p(occ)),
+                   "rt_trace_any_flags", self.L)
         else:
-            _check(lib().rt_trace_any(self.h, n, _p(o3), _p(d3), _p(tmax), _p(excluded), _p(occ)), "rt_trace_any")
+            _check(self.L.rt_trace_any(self.h, n, _p(o3), _p(d3), _p(tmax), _p(excluded), _p(occ)), "rt_trace_any", self.L)
         return occ
 
 
@@ -292,21 +330,21 @@ def xorwow_states(seed: int, first: int, count: int, draws: int = 0):
 
 def measure_copy_bandwidth(nbytes: int = 1 << 30, reps: int = 5) -> float:
     out = ctypes.c_double(0.0)
-    _check(lib().rt_measure_copy_bandwidth(nbytes, reps, ctypes.byref(out)), "rt_measure_copy_bandwidth")
+    _check(tools_lib().rt_measure_copy_bandwidth(nbytes, reps, ctypes.byref(out)), "rt_measure_copy_bandwidth", tools_lib())
     return out.value
 
 
 def calibrate_valu(waves_per_simd: int = 4, iters: int = 20000):
     """(lane-operations/s the vector ALUs sustain on independent v_fma_f32, wave-instructions per launch)."""
     rate, winstr = ctypes.c_double(0.0), ctypes.c_double(0.0)
-    _check(lib().rt_calibrate_valu(waves_per_simd, iters, ctypes.byref(rate), ctypes.byref(winstr)), "rt_calibrate_valu")
+    _check(tools_lib().rt_calibrate_valu(waves_per_simd, iters, ctypes.byref(rate), ctypes.byref(winstr)), "rt_calibrate_valu", tools_lib())
     return rate.value, winstr.value
 
 
 def calibrate_valu_packed(waves_per_simd: int = 4, iters: int = 20000, kind: int = 1) -> float:
     """Lane-operations/s of a packed-fp32 stream (kind 1 v_pk_fma_f32, 2 v_pk_mul_f32, 3 v_pk_add_f32; 2 per lane and instruction)."""
     rate = ctypes.c_double(0.0)
-    _check(lib().rt_calibrate_valu_packed(waves_per_simd, iters, kind, ctypes.byref(rate)), "rt_calibrate_valu_packed")
+    _check(tools_lib().rt_calibrate_valu_packed(waves_per_simd, iters, kind, ctypes.byref(rate)), "rt_calibrate_valu_packed", tools_lib())
     return rate.value
 
 
@@ -320,7 +358,7 @@ PROBE_ISSUE_KINDS = ["v_fma_f32", "v_fmac_f32", "v_mul_f32", "v_add_f32", "v_mov
 def probe_issue(kind: int, waves_per_simd: int, iters: int = 20000):
     """(seconds of the best launch, instructions every wave issued) of the issue probe (rt_probe_issue)."""
     sec, n = ctypes.c_double(0.0), ctypes.c_double(0.0)
-    _check(lib().rt_probe_issue(kind, waves_per_simd, iters, ctypes.byref(sec), ctypes.byref(n)), "rt_probe_issue")
+    _check(tools_lib().rt_probe_issue(kind, waves_per_simd, iters, ctypes.byref(sec), ctypes.byref(n)), "rt_probe_issue", tools_lib())
     return sec.value, n.value
 
 
@@ -336,8 +374,10 @@ def split_probe(scene: "Scene", camera: np.ndarray, width: int, height: int, spp
     """Trace-only and shade-only rates on rays / shading records dumped from the round pipeline (rt_split_probe)."""
     cam = np.ascontiguousarray(camera, np.float32)
     out = np.zeros(len(PROBE_FIELDS), np.float64)
-    _check(lib().rt_split_probe(scene.h, _p(cam), width, height, spp, max_bounces, seed, target_rays, _p(out), len(out)),
-           "rt_split_probe")
+    if scene.L is not tools_lib():
+        raise RtError("split_probe: the scene must be created with library=tools_lib()")
+    _check(tools_lib().rt_split_probe(scene.h, _p(cam), width, height, spp, max_bounces, seed, target_rays, _p(out), len(out)),
+           "rt_split_probe", tools_lib())
     return dict(zip(PROBE_FIELDS, out.tolist()))
 
 

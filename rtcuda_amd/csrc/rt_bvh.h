@@ -33,6 +33,15 @@
 
 namespace rtbvh {
 
+// Experiment knobs (RT_PERSISTENT, RT_MAJORITY, RT_BVH_WIDE, RT_BVH_MAX_LEAF, ...: DESIGN.md section 7) are read only when
+// the process sets RTCUDA_EXPERIMENTAL=1: a drop-in library must not change behaviour because some RT_* name happens to be
+// set in a user's shell.  Tests and tools set the gate; bench.py never does.
+inline const char *knob(const char *name) {
+    const char *gate = getenv("RTCUDA_EXPERIMENTAL");
+    return (gate && gate[0] == '1' && gate[1] == 0) ? getenv(name) : nullptr;
+}
+
+
 struct Box {
     float lo[3], hi[3];
     void reset() {
@@ -104,7 +113,7 @@ struct Result {
 
 // largest leaf the SAH may keep (a leaf reference carries the count in 3 bits); tunable for experiments: RT_BVH_MAX_LEAF
 inline int max_leaf() {
-    static int c = [] { const char *e = getenv("RT_BVH_MAX_LEAF"); int v = e ? atoi(e) : 4; return v < 1 ? 1 : (v > 7 ? 7 : v); }();
+    static int c = [] { const char *e = knob("RT_BVH_MAX_LEAF"); int v = e ? atoi(e) : 4; return v < 1 ? 1 : (v > 7 ? 7 : v); }();
     return c;
 }
 #define kMaxLeaf (rtbvh::max_leaf())
@@ -113,7 +122,7 @@ constexpr int kMaxBinDepth = 60;
 
 // relative cost of a traversal step (tunable for experiments: RT_BVH_TRAV_COST)
 inline float trav_cost() {
-    static float c = [] { const char *e = getenv("RT_BVH_TRAV_COST"); return e ? (float)atof(e) : 1.0f; }();
+    static float c = [] { const char *e = knob("RT_BVH_TRAV_COST"); return e ? (float)atof(e) : 1.0f; }();
     return c;
 }
 
@@ -249,7 +258,7 @@ inline void build_binary(const float *verts, int n, std::vector<BinNode> &bin, s
 // triangle ranges, so the leaf order -- and, by the tie rule of the kernels, every traversal result -- stays the same.
 // `passes`: sweeps over all nodes in order of decreasing surface area (RT_BVH_OPT, default 2; 0 = off).
 inline int opt_passes() {
-    static int c = [] { const char *e = getenv("RT_BVH_OPT"); int v = e ? atoi(e) : 2; return v < 0 ? 0 : (v > 16 ? 16 : v); }();
+    static int c = [] { const char *e = knob("RT_BVH_OPT"); int v = e ? atoi(e) : 2; return v < 0 ? 0 : (v > 16 ? 16 : v); }();
     return c;
 }
 inline double sah_cost(const std::vector<BinNode> &bin) {

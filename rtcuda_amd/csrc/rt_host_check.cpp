@@ -362,7 +362,7 @@ void *rt_hostwalk_create(const float *verts, int n) {
     w->n = n;
     w->r = rtbvh::build(verts, n);
     if (!w->r.ok) { delete w; return nullptr; }
-    if (const char *e = getenv("RT_BVH_WIDE")) w->wide = atoi(e) != 0;
+    if (const char *e = rtbvh::knob("RT_BVH_WIDE")) w->wide = atoi(e) != 0;
     w->tris = leaf_order_triangles(verts, w->r, n);
     w->inverse.assign(n, 0);
     for (int k = 0; k < n; k++) w->inverse[w->r.order[k]] = k;

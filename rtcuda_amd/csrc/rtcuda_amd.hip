@@ -66,6 +66,7 @@ using namespace rt;
 // ============================================================================ error handling
 namespace {
 thread_local std::string g_last_error;
+std::string g_peer_log;  // rt_render_multi: what became of peer access, pair by pair (rt_peer_access_log)
 int fail(const std::string &msg) {
     g_last_error = msg;
     return 1;
@@ -78,13 +79,15 @@ int fail(const std::string &msg) {
                         std::to_string(__LINE__) + ")");                                       \
     } while (0)
 
+using rtbvh::knob;  // (experiment knobs are read only under RTCUDA_EXPERIMENTAL=1: rt_bvh.h)
+
 constexpr int kW = RT_NUM_WORKING_PATHS;
 constexpr uint32_t kFlagFixedFb = 0x200u;  // internal: d_sum points to int64 fixed-point sums
 constexpr int kBlock = 256;       // 4 waves per workgroup
 constexpr int kLdsStack = 16;          // traversal stack entries kept in LDS per lane
 constexpr int kOverStride = 1 << 20;   // lanes of the overflow stack (>= lanes of the largest grid that traverses)
 constexpr int kMaxStackBound = 160;    // deepest traversal stack a scene may need (3 per level + 1)
-constexpr int kLockRounds = 4096;      // lockstep rounds of the final generation a render context can count (max_bounces + 2)
+constexpr int kLockChunk = 16;         // lockstep rounds of the final generation enqueued between two looks at the stop rule's counters
 }  // namespace
 
 // ============================================================================ device structures
@@ -2278,287 +2281,6 @@ __global__ void k_test_draw(DPools p, int n, int draws, uint32_t *__restrict__ s
     state6[6 * (size_t)i + 4] = rs.v3;
     state6[6 * (size_t)i + 5] = rs.v4;
 }
-__global__ void k_copy_f4(const float4 *__restrict__ src, float4 *__restrict__ dst, size_t n) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (; i < n; i += stride) dst[i] = src[i];
-}
-
-// VALU issue calibration: every wave issues `iters` x 16 independent v_fma_f32 (inline asm, so the compiler neither
-// packs nor folds them).  Launched with `waves_per_simd` waves on every SIMD it measures what the vector ALU of this
-// chip sustains in lane-operations per second -- the roof the render kernels (VALU-issue-bound) are priced against --
-// and, run under the PMC set of tools/, what SQ_ACTIVE_INST_VALU / SQ_BUSY_CYCLES read at that known rate.
-__global__ void __launch_bounds__(256) k_valu_calibrate(float *__restrict__ out, int iters, float seed) {
-    float a0 = seed, a1 = seed + 1.f, a2 = seed + 2.f, a3 = seed + 3.f, a4 = seed + 4.f, a5 = seed + 5.f, a6 = seed + 6.f,
-          a7 = seed + 7.f, a8 = seed + 8.f, a9 = seed + 9.f, a10 = seed + 10.f, a11 = seed + 11.f, a12 = seed + 12.f,
-          a13 = seed + 13.f, a14 = seed + 14.f, a15 = seed + 15.f;
-    const float m = 0.999f + seed * 1e-9f, c = 1e-3f;
-    for (int k = 0; k < iters; k++) {
-        __asm__ volatile(
-            "v_fma_f32 %0, %0, %16, %17\n v_fma_f32 %1, %1, %16, %17\n v_fma_f32 %2, %2, %16, %17\n v_fma_f32 %3, %3, %16, %17\n"
-            "v_fma_f32 %4, %4, %16, %17\n v_fma_f32 %5, %5, %16, %17\n v_fma_f32 %6, %6, %16, %17\n v_fma_f32 %7, %7, %16, %17\n"
-            "v_fma_f32 %8, %8, %16, %17\n v_fma_f32 %9, %9, %16, %17\n v_fma_f32 %10, %10, %16, %17\n v_fma_f32 %11, %11, %16, %17\n"
-            "v_fma_f32 %12, %12, %16, %17\n v_fma_f32 %13, %13, %16, %17\n v_fma_f32 %14, %14, %16, %17\n v_fma_f32 %15, %15, %16, %17\n"
-            : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(a8), "+v"(a9), "+v"(a10),
-              "+v"(a11), "+v"(a12), "+v"(a13), "+v"(a14), "+v"(a15)
-            : "v"(m), "v"(c));
-    }
-    float r = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7)) + ((a8 + a9) + (a10 + a11)) + ((a12 + a13) + (a14 + a15));
-    if (r == 12345.678f) out[blockIdx.x * blockDim.x + threadIdx.x] = r;  // (never true: keeps the chain alive)
-}
-
-// The same stream in packed fp32 (KIND 1: v_pk_fma_f32, 2: v_pk_mul_f32, 3: v_pk_add_f32): 16 independent chains on 16
-// aligned register PAIRS, two lane-operations per lane and instruction.  Answers one question before any hand-packing of
-// the shading arithmetic: does a packed instruction issue at the rate of a scalar one (2x the lane-operations), or at half?
-template <int KIND>
-__global__ void __launch_bounds__(256) k_valu_calibrate_pk(float *__restrict__ out, int iters, float seed) {
-    v2f a[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) a[k] = v2f{seed + (float)k, seed + 0.5f + (float)k};
-    const v2f m = {0.999f + seed * 1e-9f, 0.998f + seed * 1e-9f}, c = {1e-3f, 2e-3f};
-    for (int it = 0; it < iters; it++) {
-#define RT_PK16(OP, ARGS)                                                                                              \
-    __asm__ volatile(OP " %0, %0, " ARGS "\n" OP " %1, %1, " ARGS "\n" OP " %2, %2, " ARGS "\n" OP " %3, %3, " ARGS "\n"     \
-                     OP " %4, %4, " ARGS "\n" OP " %5, %5, " ARGS "\n" OP " %6, %6, " ARGS "\n" OP " %7, %7, " ARGS "\n"     \
-                     OP " %8, %8, " ARGS "\n" OP " %9, %9, " ARGS "\n" OP " %10, %10, " ARGS "\n" OP " %11, %11, " ARGS "\n" \
-                     OP " %12, %12, " ARGS "\n" OP " %13, %13, " ARGS "\n" OP " %14, %14, " ARGS "\n" OP " %15, %15, " ARGS  \
-                     : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]),      \
-                       "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]) \
-                     : "v"(m), "v"(c))
-        if (KIND == 1) RT_PK16("v_pk_fma_f32", "%16, %17");
-        else if (KIND == 2) RT_PK16("v_pk_mul_f32", "%16");
-        else RT_PK16("v_pk_add_f32", "%17");
-#undef RT_PK16
-    }
-    v2f r = a[0];
-#pragma unroll
-    for (int k = 1; k < 16; k++) r = r + a[k];
-    if (r.x + r.y == 12345.678f) out[blockIdx.x * blockDim.x + threadIdx.x] = r.x;  // (never true: keeps the chains alive)
-}
-
-// Issue probe (rt_probe_issue): the calibration stream with OTHER instructions -- how long one wave needs per instruction
-// of a given kind, alone on its SIMD and beside 1 / 3 / 7 other waves.  A block of k_paths takes the same time whether its
-// SIMD holds one wave or four, i.e. the kernel is bound by what ONE wave can issue, and that depends on
-// the instruction: this probe is how it was measured.  16 independent chains per lane unless the kind says "chain".
-#define RT_P16(L) L(0) L(1) L(2) L(3) L(4) L(5) L(6) L(7) L(8) L(9) L(10) L(11) L(12) L(13) L(14) L(15)
-#define RT_PL_FMA(k) "v_fma_f32 %" #k ", %" #k ", %16, %17\n"
-#define RT_PL_FMAC(k) "v_fmac_f32 %" #k ", %16, %17\n"
-#define RT_PL_MUL(k) "v_mul_f32 %" #k ", %16, %" #k "\n"
-#define RT_PL_ADD(k) "v_add_f32 %" #k ", %17, %" #k "\n"
-#define RT_PL_MOV(k) "v_mov_b32 %" #k ", %16\n"
-#define RT_PL_XOR(k) "v_xor_b32 %" #k ", %16, %" #k "\n"
-#define RT_PL_SHL(k) "v_lshlrev_b32 %" #k ", 1, %" #k "\n"
-#define RT_PL_MAX(k) "v_max_f32 %" #k ", %16, %" #k "\n"
-#define RT_PL_RCP(k) "v_rcp_f32 %" #k ", %" #k "\n"
-#define RT_PL_SQRT(k) "v_sqrt_f32 %" #k ", %" #k "\n"
-#define RT_PL_CND(k) "v_cndmask_b32 %" #k ", %" #k ", %16, vcc\n"
-#define RT_PL_MULADD(k) "v_mul_f32 %" #k ", %16, %" #k "\n v_add_f32 %" #k ", %17, %" #k "\n"
-#define RT_PL_CHAIN_FMA(k) "v_fma_f32 %0, %0, %16, %17\n"
-#define RT_PL_CHAIN_MUL(k) "v_mul_f32 %0, %16, %0\n"
-#define RT_PL_MUL_LIT(k) "v_mul_f32 %" #k ", 0x3f7fbe77, %" #k "\n"
-#define RT_PL_MUL_SGPR(k) "v_mul_f32 %" #k ", %18, %" #k "\n"
-#define RT_PL_FMA_SGPR(k) "v_fma_f32 %" #k ", %" #k ", %18, %19\n"
-#define RT_PL_CND_SGPR(k) "v_cndmask_b32_e64 %" #k ", %" #k ", %16, %20\n"
-#define RT_PL_CMP(k) "v_cmp_lt_f32_e32 vcc, %16, %" #k "\n"
-#define RT_PL_CMP_CND(k) "v_cmp_lt_f32_e32 vcc, %17, %" #k "\n v_cndmask_b32_e32 %" #k ", %" #k ", %16, vcc\n"
-#define RT_PL_BFI(k) "v_bfi_b32 %" #k ", %16, %17, %" #k "\n"
-#define RT_PL_AND(k) "v_and_b32_e32 %" #k ", %16, %" #k "\n"
-#define RT_PL_MIX_CND(k) "v_mul_f32_e32 %" #k ", %16, %" #k "\n v_mul_f32_e32 %" #k ", %16, %" #k "\n v_mul_f32_e32 %" #k ", %16, %" #k "\n v_cndmask_b32_e32 %" #k ", %" #k ", %17, vcc\n"
-#define RT_PL_MIX_MAX(k) "v_mul_f32_e32 %" #k ", %16, %" #k "\n v_mul_f32_e32 %" #k ", %16, %" #k "\n v_mul_f32_e32 %" #k ", %16, %" #k "\n v_max_f32_e32 %" #k ", %17, %" #k "\n"
-#define RT_PL_MIX_MUL(k) "v_mul_f32_e32 %" #k ", %16, %" #k "\n v_mul_f32_e32 %" #k ", %16, %" #k "\n v_mul_f32_e32 %" #k ", %16, %" #k "\n v_mul_f32_e32 %" #k ", %17, %" #k "\n"
-#define RT_PL_MIX_MOV(k) "v_mul_f32_e32 %" #k ", %16, %" #k "\n v_mul_f32_e32 %" #k ", %16, %" #k "\n v_mul_f32_e32 %" #k ", %16, %" #k "\n v_mov_b32_e32 %" #k ", %" #k "\n"
-enum { kProbeKinds = 26 };
-template <int KIND>
-__global__ void __launch_bounds__(256) k_probe_issue(float *__restrict__ out, int iters, float seed) {
-    float a0 = seed, a1 = seed + 1.f, a2 = seed + 2.f, a3 = seed + 3.f, a4 = seed + 4.f, a5 = seed + 5.f, a6 = seed + 6.f,
-          a7 = seed + 7.f, a8 = seed + 8.f, a9 = seed + 9.f, a10 = seed + 10.f, a11 = seed + 11.f, a12 = seed + 12.f,
-          a13 = seed + 13.f, a14 = seed + 14.f, a15 = seed + 15.f;
-    const float m = 0.999f + seed * 1e-9f, c = 1e-3f;
-    const float sm = __builtin_amdgcn_readfirstlane(m), sc = __builtin_amdgcn_readfirstlane(c);
-    const unsigned long long lane_mask = __builtin_amdgcn_ballot_w64(seed + (float)(threadIdx.x & 1) > 1.5f);  // (an SGPR pair)
-#define RT_PROBE_ASM(L)                                                                                                   \
-    __asm__ volatile(RT_P16(L)                                                                                            \
-                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(a8), "+v"(a9),     \
-                       "+v"(a10), "+v"(a11), "+v"(a12), "+v"(a13), "+v"(a14), "+v"(a15)                                       \
-                     : "v"(m), "v"(c), "s"(sm), "s"(sc), "s"(lane_mask)                                                          \
-                     : "vcc")
-    for (int k = 0; k < iters; k++) {
-        if (KIND == 0) RT_PROBE_ASM(RT_PL_FMA);
-        else if (KIND == 1) RT_PROBE_ASM(RT_PL_FMAC);
-        else if (KIND == 2) RT_PROBE_ASM(RT_PL_MUL);
-        else if (KIND == 3) RT_PROBE_ASM(RT_PL_ADD);
-        else if (KIND == 4) RT_PROBE_ASM(RT_PL_MOV);
-        else if (KIND == 5) RT_PROBE_ASM(RT_PL_XOR);
-        else if (KIND == 6) RT_PROBE_ASM(RT_PL_SHL);
-        else if (KIND == 7) RT_PROBE_ASM(RT_PL_MAX);
-        else if (KIND == 8) RT_PROBE_ASM(RT_PL_RCP);
-        else if (KIND == 9) RT_PROBE_ASM(RT_PL_SQRT);
-        else if (KIND == 10) RT_PROBE_ASM(RT_PL_CND);
-        else if (KIND == 11) RT_PROBE_ASM(RT_PL_MULADD);
-        else if (KIND == 12) RT_PROBE_ASM(RT_PL_CHAIN_FMA);
-        else if (KIND == 13) RT_PROBE_ASM(RT_PL_CHAIN_MUL);
-        else if (KIND == 14) RT_PROBE_ASM(RT_PL_MUL_LIT);
-        else if (KIND == 15) RT_PROBE_ASM(RT_PL_MUL_SGPR);
-        else if (KIND == 16) RT_PROBE_ASM(RT_PL_FMA_SGPR);
-        else if (KIND == 17) RT_PROBE_ASM(RT_PL_CND_SGPR);
-        else if (KIND == 18) RT_PROBE_ASM(RT_PL_CMP);
-        else if (KIND == 19) RT_PROBE_ASM(RT_PL_CMP_CND);
-        else if (KIND == 20) RT_PROBE_ASM(RT_PL_BFI);
-        else if (KIND == 21) RT_PROBE_ASM(RT_PL_AND);
-        else if (KIND == 22) RT_PROBE_ASM(RT_PL_MIX_CND);
-        else if (KIND == 23) RT_PROBE_ASM(RT_PL_MIX_MAX);
-        else if (KIND == 24) RT_PROBE_ASM(RT_PL_MIX_MUL);
-        else RT_PROBE_ASM(RT_PL_MIX_MOV);
-    }
-#undef RT_PROBE_ASM
-    float r = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7)) + ((a8 + a9) + (a10 + a11)) + ((a12 + a13) + (a14 + a15));
-    if (r == 12345.678f) out[blockIdx.x * blockDim.x + threadIdx.x] = r;  // (never true: keeps the chains alive)
-}
-
-// ============================================================================ split probe (rt_split_probe)
-// Measurement kernels for the question "would separate trace and shade kernels -- the reference's stage split
-// (render.cuh:428-449) with dense queues -- beat k_paths?".  The round pipeline's pools are copied, round after round,
-// into DENSE arrays: the rays k_trace is about to trace (closest-hit and any-hit apart), and the slot records
-// k_advance is about to shade (one bucket per material kind: a wave of the shading probe sees one material).
-// The trace side is then timed with k_trace's stage-level modes on those arrays, the shade side with k_probe_shade.
-constexpr int kProbeIn = 22;   // dwords of a shading record: bounces, hit_info, pixel, gen, rng 6, beta 3, wo 3, p 3, n 3
-constexpr int kProbeOut = 27;  // dwords a shade writes: ray 6, shadow ray 6 + tmax + L 3 + target, beta 3, rng 6, bounces
-__global__ void __launch_bounds__(kBlock)
-k_probe_dump_rays(DPools p, int n, float *__restrict__ c_o3, float *__restrict__ c_d3, float *__restrict__ c_tmax,
-                  float *__restrict__ a_o3, float *__restrict__ a_d3, float *__restrict__ a_tmax, int *__restrict__ a_excl,
-                  unsigned cap, unsigned *__restrict__ counts) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool in = i < n;
-    const int b = in ? p.bounces(i) : kDone;
-    const bool live = in && b != kDone && b != kParked;
-    const bool shadow = in && p.stmax(i) >= 0.f;
-    unsigned long long m = wave_ballot(live);
-    if (m) {
-        unsigned base = 0;
-        if (lane_id() == 0) base = atomicAdd(&counts[0], (unsigned)__popcll(m));
-        base = __builtin_amdgcn_readfirstlane(base);
-        const unsigned k = base + prefix_popc(m);
-        if (live && k < cap) {
-            c_o3[3 * (size_t)k + 0] = p.ox(i);
-            c_o3[3 * (size_t)k + 1] = p.oy(i);
-            c_o3[3 * (size_t)k + 2] = p.oz(i);
-            c_d3[3 * (size_t)k + 0] = p.dx(i);
-            c_d3[3 * (size_t)k + 1] = p.dy(i);
-            c_d3[3 * (size_t)k + 2] = p.dz(i);
-            c_tmax[k] = kFltMax;
-        }
-    }
-    m = wave_ballot(shadow);
-    if (m) {
-        unsigned base = 0;
-        if (lane_id() == 0) base = atomicAdd(&counts[1], (unsigned)__popcll(m));
-        base = __builtin_amdgcn_readfirstlane(base);
-        const unsigned k = base + prefix_popc(m);
-        if (shadow && k < cap) {
-            a_o3[3 * (size_t)k + 0] = p.sox(i);
-            a_o3[3 * (size_t)k + 1] = p.soy(i);
-            a_o3[3 * (size_t)k + 2] = p.soz(i);
-            a_d3[3 * (size_t)k + 0] = p.sdx(i);
-            a_d3[3 * (size_t)k + 1] = p.sdy(i);
-            a_d3[3 * (size_t)k + 2] = p.sdz(i);
-            a_tmax[k] = p.stmax(i);
-            a_excl[k] = p.starget(i);
-        }
-    }
-}
-// the slots the NEXT k_advance will shade (hit, bounce left: render.cuh:109,128-130), by material kind
-__global__ void __launch_bounds__(kBlock)
-k_probe_dump_shades(DScene sc, DPools p, int n, int max_bounces, float *__restrict__ rec, unsigned cap,
-                    unsigned *__restrict__ counts) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool in = i < n;
-    const int b = in ? p.bounces(i) : kDone;
-    const int hi = in ? p.hit_info(i) : -1;
-    const bool shade = in && b != kDone && b != kParked && hi >= 0 && b < max_bounces;
-    const int kind = shade ? __float_as_int(sc.tables[5 * (hi & 0xffff) + 4]) : -1;
-    for (int mk = 0; mk < 3; mk++) {
-        const bool mine = kind == mk;
-        const unsigned long long m = wave_ballot(mine);
-        if (!m) continue;
-        unsigned base = 0;
-        if (lane_id() == 0) base = atomicAdd(&counts[2 + mk], (unsigned)__popcll(m));
-        base = __builtin_amdgcn_readfirstlane(base);
-        const unsigned k = base + prefix_popc(m);
-        if (mine && k < cap) {
-            float *r = rec + (size_t)mk * kProbeIn * cap + k;  // array a of bucket mk at r[a * cap]
-            const float v[kProbeIn] = {__int_as_float(b), __int_as_float(hi), __int_as_float(p.pixel(i)), __int_as_float(p.gen(i)),
-                                       __uint_as_float(p.rd(i)), __uint_as_float(p.r0(i)), __uint_as_float(p.r1(i)),
-                                       __uint_as_float(p.r2(i)), __uint_as_float(p.r3(i)), __uint_as_float(p.r4(i)),
-                                       p.br(i), p.bg(i), p.bb(i), p.dx(i), p.dy(i), p.dz(i),
-                                       p.hpx(i), p.hpy(i), p.hpz(i), p.hnx(i), p.hny(i), p.hnz(i)};
-#pragma unroll
-            for (int a = 0; a < kProbeIn; a++) r[(size_t)a * cap] = v[a];
-        }
-    }
-}
-// init() + mat() (advance_core, the code k_advance and k_paths run) on a dense array of shading records: every lane
-// of every wave shades, one material kind per launch.  Reads kProbeIn dwords per shade, writes up to kProbeOut.
-template <bool LDS_TABLES>
-__global__ void __launch_bounds__(kBlock)
-k_probe_shade(DScene sc, Camera cam, AdvanceParams ap, const float *__restrict__ rec, unsigned cap, unsigned count,
-              float *__restrict__ outp, float *__restrict__ fb) {
-    __shared__ float s_tab[LDS_TABLES ? kTabDwordsMax : 1];
-    const float *tab = sc.tables;
-    if (LDS_TABLES) {
-        for (int k = threadIdx.x; k < sc.tab_dwords; k += kBlock) s_tab[k] = sc.tables[k];
-        __syncthreads();
-        tab = s_tab;
-    }
-    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= count) return;
-    const float *r = rec + i;
-    SlotState st;
-    st.bounces = __float_as_int(r[0 * (size_t)cap]);
-    st.hit_info = __float_as_int(r[1 * (size_t)cap]);
-    st.pixel = __float_as_int(r[2 * (size_t)cap]);
-    st.gen = __float_as_int(r[3 * (size_t)cap]);
-    st.rs = Rng{__float_as_uint(r[4 * (size_t)cap]), __float_as_uint(r[5 * (size_t)cap]), __float_as_uint(r[6 * (size_t)cap]),
-                __float_as_uint(r[7 * (size_t)cap]), __float_as_uint(r[8 * (size_t)cap]), __float_as_uint(r[9 * (size_t)cap])};
-    st.beta = mk(r[10 * (size_t)cap], r[11 * (size_t)cap], r[12 * (size_t)cap]);
-    st.wo = mk(r[13 * (size_t)cap], r[14 * (size_t)cap], r[15 * (size_t)cap]);
-    st.isect_p = mk(r[16 * (size_t)cap], r[17 * (size_t)cap], r[18 * (size_t)cap]);
-    st.isect_n = mk(r[19 * (size_t)cap], r[20 * (size_t)cap], r[21 * (size_t)cap]);
-    AdvanceOut out;
-    advance_core<true, true, false>(sc, tab, cam, ap, 0, st, out, fb);
-    float *w = outp + i;
-    if (out.new_ray) {
-        w[0 * (size_t)cap] = out.ray_o.x;
-        w[1 * (size_t)cap] = out.ray_o.y;
-        w[2 * (size_t)cap] = out.ray_o.z;
-        w[3 * (size_t)cap] = out.ray_d.x;
-        w[4 * (size_t)cap] = out.ray_d.y;
-        w[5 * (size_t)cap] = out.ray_d.z;
-    }
-    w[12 * (size_t)cap] = out.has_shadow ? out.s_tmax : -1.f;
-    if (out.has_shadow) {
-        w[6 * (size_t)cap] = out.s_o.x;
-        w[7 * (size_t)cap] = out.s_o.y;
-        w[8 * (size_t)cap] = out.s_o.z;
-        w[9 * (size_t)cap] = out.s_d.x;
-        w[10 * (size_t)cap] = out.s_d.y;
-        w[11 * (size_t)cap] = out.s_d.z;
-        w[13 * (size_t)cap] = out.s_L.x;
-        w[14 * (size_t)cap] = out.s_L.y;
-        w[15 * (size_t)cap] = out.s_L.z;
-        w[16 * (size_t)cap] = __int_as_float(out.s_target);
-    }
-    w[17 * (size_t)cap] = st.beta.x;
-    w[18 * (size_t)cap] = st.beta.y;
-    w[19 * (size_t)cap] = st.beta.z;
-    w[20 * (size_t)cap] = __uint_as_float(st.rs.d);
-    w[21 * (size_t)cap] = __uint_as_float(st.rs.v0);
-    w[22 * (size_t)cap] = __uint_as_float(st.rs.v1);
-    w[23 * (size_t)cap] = __uint_as_float(st.rs.v2);
-    w[24 * (size_t)cap] = __uint_as_float(st.rs.v3);
-    w[25 * (size_t)cap] = __uint_as_float(st.rs.v4);
-    w[26 * (size_t)cap] = __int_as_float(st.bounces);
-}
-
 // ============================================================================ device BVH build (LBVH)
 // a BVH build on the GPU.  Optional (RT_BVH_BUILDER=lbvh): a linear BVH --
 // 30-bit Morton codes of the triangle centroids, sorted, binary radix tree by longest common prefix
@@ -3099,13 +2821,60 @@ struct Context {
     bool rng_valid = false;
     uint32_t *rng_backup = nullptr;  // 6 x n words
     std::vector<hipEvent_t> timing_events;
-    unsigned int *d_lock = nullptr;  // mat() events per lockstep round of the final generation (kLockRounds words)
+    unsigned int *d_lock = nullptr;  // mat() events per lockstep round of the final generation (lock_cap words, grown on demand)
+    int lock_cap = 0;
     int *d_over = nullptr;  // overflow part of the traversal stacks of this context's grids (ensure_overflow)
     int over_levels = 0;
     std::mutex busy;  // a context (pools, counters, events) serves one render at a time
+    Context() = default;
+    Context(const Context &) = delete;
+    Context &operator=(const Context &) = delete;
+    ~Context() {  // (rt_shutdown, or a context that failed half-way through get_context): on the device it lives on
+        int saved = 0;
+        const bool hop = device >= 0 && hipGetDevice(&saved) == hipSuccess && saved != device && hipSetDevice(device) == hipSuccess;
+        for (void *q : allocs) (void)hipFree(q);
+        (void)hipFree(d_lock);
+        (void)hipFree(d_over);
+        if (h_ctr) (void)hipHostFree(h_ctr);
+        for (hipEvent_t e : ev_ring) if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : {ev_a, ev_b, ev_c}) if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : timing_events) (void)hipEventDestroy(e);
+        if (hop) (void)hipSetDevice(saved);
+    }
 };
 std::mutex g_ctx_mutex;
 std::vector<std::unique_ptr<Context>> g_contexts;
+
+// Device buffers of the calls that take HOST output (rt_render, rt_render_multi): raw sums, staging, the post-processed image.
+// Kept per (device, slot) and reused from call to call -- a hipMalloc / hipFree pair per frame cost ~0.3 ms and a device
+// synchronisation each (round 4 allocated them per call); released by rt_shutdown.  One call at a time uses them (g_out_busy).
+struct OutBuffer {
+    int device = -1, slot = 0;
+    void *ptr = nullptr;
+    size_t bytes = 0;
+};
+std::mutex g_out_busy;
+std::vector<OutBuffer> g_out_buffers;
+// (caller holds g_out_busy; the current device must be `device`)
+void *out_buffer(int device, int slot, size_t bytes) {
+    for (OutBuffer &b : g_out_buffers)
+        if (b.device == device && b.slot == slot) {
+            if (b.bytes >= bytes) return b.ptr;
+            (void)hipFree(b.ptr);
+            b.ptr = nullptr;
+            b.bytes = 0;
+            if (hipMalloc(&b.ptr, bytes) != hipSuccess) return nullptr;
+            b.bytes = bytes;
+            return b.ptr;
+        }
+    OutBuffer b;
+    b.device = device;
+    b.slot = slot;
+    if (hipMalloc(&b.ptr, bytes) != hipSuccess) return nullptr;
+    b.bytes = bytes;
+    g_out_buffers.push_back(b);
+    return b.ptr;
+}
 
 template <typename T>
 int dev_alloc(Context &c, T *&ptr, size_t count) {
@@ -3134,8 +2903,9 @@ int get_context(int n, int lane, Context **out) {
     if (dev_alloc(*c, p.base, (size_t)A_COUNT * n)) return 1;
     if (dev_alloc(*c, c->rng_backup, (size_t)6 * n)) return 1;
     if (dev_alloc(*c, c->d_ctr, 1)) return 1;
-    if (dev_alloc(*c, c->d_lock, (size_t)kLockRounds)) return 1;
-    c->n_rows = 2 * ((n + kBlock - 1) / kBlock) * (kBlock / 64);  // (x 2: RT_HALF_WAVES launches twice the waves)
+    // one counter row per wave of the largest grid this context launches: k_advance's (n / 64 waves); the RT_HALF_WAVES
+    // experiment launches k_paths with twice its usual waves, which on a small shard can exceed that
+    c->n_rows = (knob("RT_HALF_WAVES") ? 2 : 1) * ((n + kBlock - 1) / kBlock) * (kBlock / 64);
     if (dev_alloc(*c, c->d_rows, (size_t)c->n_rows)) return 1;
     if (dev_alloc(*c, c->d_jump, (size_t)20 * 800)) return 1;
     HIP_TRY(hipMemcpy(c->d_jump, jump_powers().data(), sizeof(uint32_t) * 20 * 800, hipMemcpyHostToDevice));
@@ -3155,13 +2925,13 @@ int grid_for(int n) { return (n + kBlock - 1) / kBlock; }
 // RT_STACK_CAP lowers it: a test knob that drives every traversal through the overflow path.
 static int lds_stack_cap(const rt_scene *scene, int limit) {
     int cap = std::min(limit, std::max(1, scene->stack_bound));
-    if (const char *e = getenv("RT_STACK_CAP")) cap = std::max(1, std::min(cap, atoi(e)));
+    if (const char *e = knob("RT_STACK_CAP")) cap = std::max(1, std::min(cap, atoi(e)));
     return cap;
 }
 
 // launches k_advance<LDS tables?, material-sorted?> for one round (uses grid, block, sc, c, cam, ap, lds_tables of the caller)
 static bool sort_shade() {
-    const char *e = getenv("RT_SORT_SHADE");
+    const char *e = knob("RT_SORT_SHADE");
     return e ? atoi(e) != 0 : false;  // (measured on C2's round pipeline: 535 ms sorted, 517 ms in slot order -- see k_advance)
 }
 #define RT_LAUNCH_ADVANCE(stream, fbptr)                                                                                         \
@@ -3239,7 +3009,7 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
                       float *d_sum, hipStream_t st, rt_stats *stats, int ctx_lane = 0) {
     if (!scene || !camera || !d_sum) return fail("rt_render_shard: null argument");
     if (width <= 0 || height <= 0 || spp <= 0 || max_bounces < 0) return fail("rt_render_shard: bad dimensions");
-    if (max_bounces + 2 > kLockRounds) return fail("rt_render_shard: max_bounces exceeds " + std::to_string(kLockRounds - 2));
+    if (max_bounces > (1 << 24)) return fail("rt_render_shard: max_bounces exceeds 16777216");
     if (shard_count <= 0 || kW % shard_count != 0 || shard_index < 0 || shard_index >= shard_count)
         return fail("rt_render_shard: shard_count must divide 1048576 and 0 <= shard_index < shard_count");
     if ((long long)width * height > (long long)(0x7fffffff / 3))  // framebuffer values are indexed with 32 bits
@@ -3283,7 +3053,7 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
         zero.last_live_round = -1;
         c.h_ctr[0] = zero;  // pinned staging
         HIP_TRY(hipMemcpyAsync(c.d_ctr, &c.h_ctr[0], sizeof(DCounters), hipMemcpyHostToDevice, st));
-        HIP_TRY(hipMemsetAsync(c.d_rows, 0, sizeof(DWaveRow) * (size_t)c.n_rows, st));
+        HIP_TRY(hipMemsetAsync(c.d_rows, 0, sizeof(DWaveRow) * (size_t)c.n_rows, st));  // (n / 64 rows of 64 bytes: 1 MB for the full pool)
         HIP_TRY(hipStreamSynchronize(st));  // h_ctr[0] is reused as a snapshot slot below
     }
     const int stack_cap = lds_stack_cap(scene, kLdsStack);
@@ -3356,7 +3126,7 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
     else
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_c, k_trace<MODE_POOL, false>, kBlock, lds_bytes));
     int per_cu = std::max(1, occ_c);
-    if (const char *e = getenv("RT_TRACE_BLOCKS_PER_CU")) per_cu = std::max(1, std::min(per_cu, atoi(e)));
+    if (const char *e = knob("RT_TRACE_BLOCKS_PER_CU")) per_cu = std::max(1, std::min(per_cu, atoi(e)));
     const int resident = std::max(1, dev_cus * per_cu);
     const dim3 grid_trace(std::min(grid_for(n_live), resident));
     TraceParams tpp{};
@@ -3389,7 +3159,7 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
     // ---- asynchronous part of the frame: ONE persistent launch (k_paths), or -- RT_PERSISTENT=0 -- the
     // round-per-launch pipeline (k_advance + k_trace) that the lockstep final generation also uses
     bool persistent = true;
-    if (const char *e = getenv("RT_PERSISTENT")) persistent = atoi(e) != 0;
+    if (const char *e = knob("RT_PERSISTENT")) persistent = atoi(e) != 0;
     if (per_sample && !persistent) return fail("rt_render_shard: RT_FLAG_RNG_PER_SAMPLE runs on the persistent kernel only");
     float ms_paths = 0.f;
     int top_records_in_lds = 0;
@@ -3399,7 +3169,7 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
         size_t lds_paths = sizeof(int) * (size_t)kBlock * (size_t)(paths_cap + 26) + (lds_tables ? sizeof(float) * (size_t)((scene->tab_dwords + 3) & ~3) : 0) +
                            sizeof(Camera) + sizeof(AdvanceParams);
         bool majority = true;
-        if (const char *e = getenv("RT_MAJORITY")) majority = atoi(e) != 0;
+        if (const char *e = knob("RT_MAJORITY")) majority = atoi(e) != 0;
         const int dbg = (flags & 0x100u) ? 1 : 0;
         unsigned long long *paths_prof = nullptr;
 #ifdef RT_TRACE_PROFILE
@@ -3411,11 +3181,11 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
         int paths_blocks = grid_for(n);
         // RT_HALF_WAVES=1 (experiment, shards of <= 1/8 of the slots): 32 slots per wave instead of 64, twice the waves
         int half_fill = 0;
-        if (const char *e = getenv("RT_HALF_WAVES")) half_fill = (atoi(e) != 0 && 2 * paths_blocks <= 1024 && !per_sample) ? 1 : 0;
+        if (const char *e = knob("RT_HALF_WAVES")) half_fill = (atoi(e) != 0 && 2 * paths_blocks <= 1024 && !per_sample && 2 * paths_blocks * (kBlock / 64) <= c.n_rows) ? 1 : 0;  // (rows: see get_context)
         if (half_fill) paths_blocks *= 2;
         {
             int want = 1024;
-            if (const char *e = getenv("RT_PATHS_BLOCKS")) want = std::max(1, atoi(e));
+            if (const char *e = knob("RT_PATHS_BLOCKS")) want = std::max(1, atoi(e));
             while (paths_blocks > want && paths_blocks % 2 == 0) paths_blocks /= 2;
         }
         const dim3 grid_paths(paths_blocks);
@@ -3430,7 +3200,7 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
             // first levels are L2 hits the two waves' other work hides), so it is off unless RT_TOP_NODES asks for it
             const int prefix = std::min(scene->n_nodes, (int)rtbvh::kTopPrefix * (scene->wide ? 2 : 1));
             top_n = scene->top_prefix ? std::min(scene->wide ? 0 : 384, prefix) : 0;
-            if (const char *e = getenv("RT_TOP_NODES")) top_n = scene->top_prefix ? std::max(0, std::min(std::min(768, atoi(e)), prefix)) : 0;
+            if (const char *e = knob("RT_TOP_NODES")) top_n = scene->top_prefix ? std::max(0, std::min(std::min(768, atoi(e)), prefix)) : 0;
             if (scene->wide) top_n &= ~1;  // whole nodes
             lds_paths += (size_t)top_n * 64;
             top_records_in_lds = top_n;
@@ -3444,10 +3214,10 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
             adv_batch /= 2;
             gen_batch /= 2;
         }
-        if (const char *e = getenv("RT_ADV_BATCH")) adv_batch = std::max(1, std::min(64, atoi(e)));
-        if (const char *e = getenv("RT_GEN_BATCH")) gen_batch = std::max(1, std::min(64, atoi(e)));
+        if (const char *e = knob("RT_ADV_BATCH")) adv_batch = std::max(1, std::min(64, atoi(e)));
+        if (const char *e = knob("RT_GEN_BATCH")) gen_batch = std::max(1, std::min(64, atoi(e)));
         int tri_follow = 1;  // a triangle block right behind a node block when this many lanes hold a leaf by then; 0 = never
-        if (const char *e = getenv("RT_TRI_FOLLOW")) tri_follow = std::max(0, std::min(64, atoi(e)));
+        if (const char *e = knob("RT_TRI_FOLLOW")) tri_follow = std::max(0, std::min(64, atoi(e)));
         int prio_rotate = 8;  // log2 of the priority-rotation period in scheduling decisions; 0 = off
         // period, in 64-slot blocks, after which slots repeat the same pixel-column lattice (see k_paths)
         int rot_wave = 0, rot_set = 0;
@@ -3463,11 +3233,11 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
             if (period < 16 || period > waves) period = std::max(16, waves / 8);
             rot_wave = (int)(period / 4);                // measured best on the bunny scenes: 128 / 160 blocks
             rot_set = (int)(period / 4 + period / 16);
-            if (const char *e = getenv("RT_ROT_WAVE")) rot_wave = atoi(e);
-            if (const char *e = getenv("RT_ROT_SET")) rot_set = atoi(e);
+            if (const char *e = knob("RT_ROT_WAVE")) rot_wave = atoi(e);
+            if (const char *e = knob("RT_ROT_SET")) rot_set = atoi(e);
             rot_wave &= ~3;  // keeps wave j of a workgroup on blocks = j (mod 4): the map stays a bijection
         }
-        if (const char *e = getenv("RT_PRIO_ROTATE")) prio_rotate = atoi(e);
+        if (const char *e = knob("RT_PRIO_ROTATE")) prio_rotate = atoi(e);
         HIP_TRY(hipEventRecord(c.ev_a, st));
 // MIN_WAVES: 4 waves per SIMD (at most 128 VGPRs) when the grid fills the chip, 2 (up to 256 VGPRs) when the
         // shard is so small that only 2 workgroups per CU exist anyway (8-GPU runs)
@@ -3544,7 +3314,7 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
             fprintf(stderr, "k_paths profile: ADV blocks %llu avg lanes %.1f | node steps %llu avg lanes %.1f (ADV-waiting %.1f) | tri steps %llu avg lanes %.1f (ADV-waiting %.1f)\n",
                     h[0], h[0] ? (double)h[1] / h[0] : 0.0, h[2], h[2] ? (double)h[3] / h[2] : 0.0, h[2] ? (double)h[6] / h[2] : 0.0, h[4],
                     h[4] ? (double)h[5] / h[4] : 0.0, h[4] ? (double)h[7] / h[4] : 0.0);
-            if (const char *dump = getenv("RT_PROF_DUMP")) {  // per-wave records: hw_id xcc_id cycles blocks
+            if (const char *dump = knob("RT_PROF_DUMP")) {  // per-wave records: hw_id xcc_id cycles blocks
                 std::vector<unsigned long long> recs(4 * (size_t)paths_blocks * (kBlock / 64));
                 HIP_TRY(hipMemcpy(recs.data(), paths_prof + 24, recs.size() * 8, hipMemcpyDeviceToHost));
                 if (FILE *f = fopen(dump, "w")) {
@@ -3592,27 +3362,49 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
     // reference iteration; the render ends at the first round in which nothing shades (render.cuh:436)
     // All max_bounces + 2 rounds are enqueued back to back; which of them still belong to the render is decided on the
     // device (k_advance / k_trace look at lock_shades), and the host learns the number of rounds that ran afterwards.
+    // The rounds go out in chunks of kLockChunk: the reference's 12 rounds (max_bounces = 10) are ONE chunk -- no host
+    // read-back inside the frame --, and a caller with max_bounces in the thousands does not pay thousands of empty launches
+    // once the render has ended: between chunks the host looks at the last round's counter.
     const int n_lock = max_bounces + 2;
     const bool ran_lockstep = finished && !per_sample;
+    int lock_enqueued = 0;
     if (ran_lockstep) {
-        HIP_TRY(hipMemsetAsync(c.d_lock, 0, sizeof(unsigned) * (size_t)n_lock, st));
-        for (int j = 0; j < n_lock; j++) {
-            ap.round = (int)((rounds + j) & 0x3fffffff);
-            ap.lockstep = 1 + j;
-            RT_LAUNCH_ADVANCE(st, d_sum);
-            tpp.lock_shades = c.d_lock;
-            tpp.lock_round = j;
-            RT_LAUNCH_TRACE_REF(MODE_POOL, literal, verify, scene->wide, grid_trace, lds_bytes, st, sc, c.pools, tpp, stack_cap, d_over);
+        if (n_lock > c.lock_cap) {  // (the stop rule's counters: one word per round, grown on demand)
+            HIP_TRY(hipStreamSynchronize(st));
+            (void)hipFree(c.d_lock);
+            c.d_lock = nullptr;
+            c.lock_cap = 0;
+            HIP_TRY(hipMalloc((void **)&c.d_lock, sizeof(unsigned) * (size_t)std::max(n_lock, 64)));
+            c.lock_cap = std::max(n_lock, 64);
         }
-        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemsetAsync(c.d_lock, 0, sizeof(unsigned) * (size_t)n_lock, st));
+        while (lock_enqueued < n_lock) {
+            const int hi = std::min(n_lock, lock_enqueued + kLockChunk);
+            for (int j = lock_enqueued; j < hi; j++) {
+                ap.round = (int)((rounds + j) & 0x3fffffff);
+                ap.lockstep = 1 + j;
+                RT_LAUNCH_ADVANCE(st, d_sum);
+                tpp.lock_shades = c.d_lock;
+                tpp.lock_round = j;
+                RT_LAUNCH_TRACE_REF(MODE_POOL, literal, verify, scene->wide, grid_trace, lds_bytes, st, sc, c.pools, tpp, stack_cap, d_over);
+            }
+            HIP_TRY(hipGetLastError());
+            lock_enqueued = hi;
+            if (hi < n_lock) {  // (more than one chunk: max_bounces >= 15)
+                unsigned last = 1u;
+                HIP_TRY(hipMemcpyAsync(&last, c.d_lock + (hi - 1), sizeof(unsigned), hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipStreamSynchronize(st));
+                if (last == 0u && hi - 1 >= 1) break;  // that round shaded nothing: the render is over (render.cuh:436)
+            }
+        }
     }
     HIP_TRY(hipEventRecord(ev_stop, st));
     HIP_TRY(hipEventSynchronize(ev_stop));
     if (ran_lockstep) {  // rounds that ran: up to and including the first one (after the generating round) that shaded nothing
-        std::vector<unsigned> h_lock((size_t)n_lock);
-        HIP_TRY(hipMemcpy(h_lock.data(), c.d_lock, sizeof(unsigned) * (size_t)n_lock, hipMemcpyDeviceToHost));
-        int ran = n_lock;
-        for (int j = 1; j < n_lock; j++)
+        std::vector<unsigned> h_lock((size_t)lock_enqueued);
+        HIP_TRY(hipMemcpy(h_lock.data(), c.d_lock, sizeof(unsigned) * (size_t)lock_enqueued, hipMemcpyDeviceToHost));
+        int ran = lock_enqueued;
+        for (int j = 1; j < lock_enqueued; j++)
             if (h_lock[(size_t)j] == 0u) {
                 ran = j + 1;
                 break;
@@ -3695,7 +3487,7 @@ int render_overlapped(const rt_scene *scene, const rt_camera *camera, int width,
                       int max_bounces, uint64_t seed, int shard_index, int shard_count, uint32_t flags,
                       float *d_sum, hipStream_t st, rt_stats *stats) {
     int split = 1;
-    if (const char *e = getenv("RT_SPLIT")) split = std::max(1, std::min(8, atoi(e)));
+    if (const char *e = knob("RT_SPLIT")) split = std::max(1, std::min(8, atoi(e)));
     while (split > 1 && (shard_count <= 0 || kW % (shard_count * split) != 0 || kW / (shard_count * split) < 4096)) split >>= 1;
     if (split <= 1)
         return render_shard_impl(scene, camera, width, height, spp, max_bounces, seed, shard_index, shard_count, flags,
@@ -3748,49 +3540,11 @@ int render_overlapped(const rt_scene *scene, const rt_camera *camera, int width,
 
 }  // namespace
 
-// ---- split probe: see the kernels (k_probe_*) for what is measured
-namespace {
-template <int MODE, bool WIDE, int MINW>
-int probe_trace_once(const rt_scene *scene, const TraceParams &tp, int stack_cap, int *d_over, int cus, hipEvent_t e0,
-                     hipEvent_t e1, double *seconds, double *blocks_per_cu) {
-    const size_t lds = sizeof(int) * kBlock * (size_t)(stack_cap + 2);
-    int occ = 0;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_trace<MODE, WIDE, MINW>, kBlock, lds));
-    occ = std::max(1, occ);
-    const int grid = std::max(1, std::min(grid_for(tp.total), cus * occ));
-    double best = 1e30;
-    DPools none{};
-    for (int rep = 0; rep < 3; rep++) {
-        HIP_TRY(hipEventRecord(e0, nullptr));
-        hipLaunchKernelGGL((k_trace<MODE, WIDE, MINW>), dim3(grid), dim3(kBlock), lds, nullptr, scene->dev(), none, tp,
-                           stack_cap, d_over);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipEventRecord(e1, nullptr));
-        HIP_TRY(hipEventSynchronize(e1));
-        float ms = 0.f;
-        HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-        best = std::min(best, (double)ms * 1e-3);
-    }
-    *seconds = best;
-    *blocks_per_cu = occ;
-    return 0;
-}
-template <int MODE, bool WIDE>
-int probe_trace(const rt_scene *scene, const TraceParams &tp, int stack_cap, int *d_over, int cus, hipEvent_t e0, hipEvent_t e1,
-                int minw, double *seconds, double *blocks_per_cu) {
-    switch (minw) {
-        case 8: return probe_trace_once<MODE, WIDE, 8>(scene, tp, stack_cap, d_over, cus, e0, e1, seconds, blocks_per_cu);
-        case 6: return probe_trace_once<MODE, WIDE, 6>(scene, tp, stack_cap, d_over, cus, e0, e1, seconds, blocks_per_cu);
-        case 5: return probe_trace_once<MODE, WIDE, 5>(scene, tp, stack_cap, d_over, cus, e0, e1, seconds, blocks_per_cu);
-        default: return probe_trace_once<MODE, WIDE, 4>(scene, tp, stack_cap, d_over, cus, e0, e1, seconds, blocks_per_cu);
-    }
-}
-}  // namespace
-
 // ============================================================================ C-ABI
 extern "C" {
 
 const char *rt_last_error(void) { return g_last_error.c_str(); }
+const char *rt_peer_access_log(void) { return g_peer_log.c_str(); }
 const char *rt_version(void) { return "rtcuda_amd 0.1 (gfx950)"; }
 #ifndef RT_BUILD_ID
 #define RT_BUILD_ID "unknown"
@@ -3826,7 +3580,7 @@ int rt_scene_create(const float *tri_p0p1p2, int n_tris, const int32_t *tri_mate
     auto sc = std::make_unique<rt_scene>();
     HIP_TRY(hipGetDevice(&sc->device));
     bool use_lbvh = false;
-    if (const char *e = getenv("RT_BVH_BUILDER")) use_lbvh = std::string(e) == "lbvh";
+    if (const char *e = knob("RT_BVH_BUILDER")) use_lbvh = std::string(e) == "lbvh";
     rtbvh::Result bvh;
     if (use_lbvh && n_tris >= 2) {
         int depth = 0;
@@ -3857,7 +3611,7 @@ int rt_scene_create(const float *tri_p0p1p2, int n_tris, const int32_t *tri_mate
     if (n_materials > 0) sc->h_materials.assign(materials, materials + n_materials);
     if (n_lights > 0) sc->h_lights.assign(lights, lights + n_lights);
     sc->wide = true;  // 4-wide nodes (two pair-style records each): half the dependent fetches per ray; RT_BVH_WIDE=0: 2-wide
-    if (const char *e = getenv("RT_BVH_WIDE")) sc->wide = atoi(e) != 0;
+    if (const char *e = knob("RT_BVH_WIDE")) sc->wide = atoi(e) != 0;
     // a tree too deep for the 4-wide walk's stack (up to 3 entries per level) may still fit the 2-wide walk's (1 per level):
     // a very deep LBVH, or a host tree the reinsertion pass deepened
     if (sc->wide && bvh.stack_bound > kMaxStackBound) sc->wide = false;
@@ -4051,34 +3805,50 @@ int rt_render(const rt_scene *scene, const rt_camera *camera, int width, int hei
     const bool fixed = (flags & RT_FLAG_DETERMINISTIC) != 0;
     const size_t n_values = 3 * (size_t)width * height;
     const size_t bytes = sizeof(float) * n_values;
-    float *d_fb = nullptr;
-    long long *d_fixed = nullptr;
-    HIP_TRY(hipMalloc((void **)&d_fb, bytes));
-    if (fixed && hipMalloc((void **)&d_fixed, sizeof(long long) * n_values) != hipSuccess) {
-        (void)hipFree(d_fb);
-        return fail("rt_render: out of device memory");
-    }
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> out_lock(g_out_busy);  // (the cached device buffers serve one host-output call at a time)
+    float *d_fb = (float *)out_buffer(dev, 0, bytes);
+    long long *d_fixed = fixed ? (long long *)out_buffer(dev, 1, sizeof(long long) * n_values) : nullptr;
+    if (!d_fb || (fixed && !d_fixed)) return fail("rt_render: out of device memory");
     int rc = 0;
-    do {
-        if (fixed) {
-            if (hipMemsetAsync(d_fixed, 0, sizeof(long long) * n_values, nullptr) != hipSuccess) { rc = fail("rt_render: memset failed"); break; }
-            rc = render_overlapped(scene, camera, width, height, num_samples, max_bounces, seed, 0, 1,
-                                   (flags & ~kFlagFixedFb) | kFlagFixedFb, (float *)d_fixed, nullptr, stats);
-            if (rc) break;
-            rc = rt_post_process_fixed((const int64_t *)d_fixed, d_fb, width * height, num_samples, nullptr);
-        } else {
-            if (hipMemsetAsync(d_fb, 0, bytes, nullptr) != hipSuccess) { rc = fail("rt_render: memset failed"); break; }
-            rc = render_overlapped(scene, camera, width, height, num_samples, max_bounces, seed, 0, 1, flags & ~kFlagFixedFb,
-                                   d_fb, nullptr, stats);
-            if (rc) break;
-            rc = rt_post_process(d_fb, width * height, num_samples, nullptr);
+    if (fixed) {
+        HIP_TRY(hipMemsetAsync(d_fixed, 0, sizeof(long long) * n_values, nullptr));
+        rc = render_overlapped(scene, camera, width, height, num_samples, max_bounces, seed, 0, 1,
+                               (flags & ~kFlagFixedFb) | kFlagFixedFb, (float *)d_fixed, nullptr, stats);
+        if (rc) return rc;
+        rc = rt_post_process_fixed((const int64_t *)d_fixed, d_fb, width * height, num_samples, nullptr);
+    } else {
+        HIP_TRY(hipMemsetAsync(d_fb, 0, bytes, nullptr));
+        rc = render_overlapped(scene, camera, width, height, num_samples, max_bounces, seed, 0, 1, flags & ~kFlagFixedFb,
+                               d_fb, nullptr, stats);
+        if (rc) return rc;
+        rc = rt_post_process(d_fb, width * height, num_samples, nullptr);
+    }
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(out_rgb, d_fb, bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// Releases every device allocation the library holds behind the scenes -- the per-device render contexts (path pools, RNG
+// states, counters, overflow stacks, events) and the cached output buffers of rt_render / rt_render_multi.  Scenes are the
+// caller's (rt_scene_destroy).  No render may be in flight.  The library works again afterwards (everything is re-created on
+// demand).  (The reference frees nothing at all: render.cuh:374-391, bvh.cuh:211-217.)
+void rt_shutdown(void) {
+    int saved = 0;
+    const bool have = hipGetDevice(&saved) == hipSuccess;
+    {
+        std::lock_guard<std::mutex> lock(g_ctx_mutex);
+        g_contexts.clear();  // (~Context frees on the context's own device)
+    }
+    {
+        std::lock_guard<std::mutex> out_lock(g_out_busy);
+        for (OutBuffer &b : g_out_buffers) {
+            if (hipSetDevice(b.device) == hipSuccess) (void)hipFree(b.ptr);
         }
-        if (rc) break;
-        if (hipMemcpy(out_rgb, d_fb, bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = fail("rt_render: copy-back failed");
-    } while (0);
-    (void)hipFree(d_fb);
-    (void)hipFree(d_fixed);
-    return rc;
+        g_out_buffers.clear();
+    }
+    if (have) (void)hipSetDevice(saved);
 }
 
 // The scene as it exists on `device`: the scene itself, or a replica created there from the host copies (once per device).
@@ -4128,38 +3898,58 @@ int rt_render_multi(const rt_scene *scene, const rt_camera *camera, int width, i
         on_dev[k] = scene_on_device(scene, devices[k]);
         if (!on_dev[k]) return 1;
     }
-    struct Buffers {  // everything released on every return path, each pointer on the device it was allocated on
-        std::vector<void *> ptr;
-        std::vector<int> dev;
-        int home = 0;
-        ~Buffers() {
-            for (size_t k = 0; k < ptr.size(); k++) {
-                (void)hipSetDevice(dev[k]);
-                (void)hipFree(ptr[k]);
-            }
-            (void)hipSetDevice(home);
-        }
-        void *alloc(int device, size_t bytes) {
-            void *q = nullptr;
-            if (hipSetDevice(device) != hipSuccess || hipMalloc(&q, bytes) != hipSuccess) return nullptr;
-            ptr.push_back(q);
-            dev.push_back(device);
-            return q;
-        }
+    // device buffers: cached per (device, slot) like rt_render's; slot 2 + 2k = shard k's sums on its device, 3 + 2k = its
+    // staging copy on devices[0], slot 1 = the post-processed image (fixed-point mode)
+    std::lock_guard<std::mutex> out_lock(g_out_busy);
+    struct Home {  // the calling thread's device is restored on every return path
+        int device;
+        ~Home() { (void)hipSetDevice(device); }
+    } home{caller_device};
+    struct {
+        void *alloc(int device, int slot, size_t bytes) { return hipSetDevice(device) == hipSuccess ? out_buffer(device, slot, bytes) : nullptr; }
     } buf;
-    buf.home = caller_device;
     const int dev0 = devices[0];
+    // Peer access between devices[0] and every other listed device, once per pair and process: with it the shards' sums travel
+    // over xGMI straight into devices[0]'s memory; without it hipMemcpyPeerAsync still works, staged through host memory by
+    // the runtime.  (Nothing of this has run on two PHYSICAL devices yet -- one-GPU boxes list a device twice; the first
+    // multi-GPU run is the driver's scaling run, where bench.py's probe records what happened here: `peer_access`.)
+    {
+        static std::mutex peer_mutex;
+        static std::vector<std::pair<int, int>> peer_done;
+        std::lock_guard<std::mutex> peer_lock(peer_mutex);
+        for (int k = 1; k < n_devices; k++) {
+            const int dk = devices[k];
+            if (dk == dev0 || std::find(peer_done.begin(), peer_done.end(), std::make_pair(dev0, dk)) != peer_done.end()) continue;
+            peer_done.push_back({dev0, dk});
+            int can01 = 0, can10 = 0;
+            std::string why;
+            if (hipDeviceCanAccessPeer(&can01, dev0, dk) != hipSuccess || hipDeviceCanAccessPeer(&can10, dk, dev0) != hipSuccess) why = "hipDeviceCanAccessPeer failed";
+            else if (!can01 || !can10) why = "the devices report no peer access";
+            else {
+                hipError_t e1 = hipSetDevice(dev0) == hipSuccess ? hipDeviceEnablePeerAccess(dk, 0) : hipErrorInvalidDevice;
+                hipError_t e2 = hipSetDevice(dk) == hipSuccess ? hipDeviceEnablePeerAccess(dev0, 0) : hipErrorInvalidDevice;
+                if (e1 == hipErrorPeerAccessAlreadyEnabled) e1 = hipSuccess;  // (PyTorch, or an earlier library in the process, got there first)
+                if (e2 == hipErrorPeerAccessAlreadyEnabled) e2 = hipSuccess;
+                (void)hipGetLastError();
+                if (e1 != hipSuccess || e2 != hipSuccess) why = std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e1 != hipSuccess ? e1 : e2);
+            }
+            g_peer_log += "devices " + std::to_string(dev0) + " <-> " + std::to_string(dk) + ": " + (why.empty() ? "peer access enabled" : "NO peer access (" + why + "): copies go through host memory") + "; ";
+            if (!why.empty())
+                fprintf(stderr, "rtcuda_amd: rt_render_multi: no peer access between devices %d and %d (%s): the shard's sums are copied through host memory\n", dev0, dk, why.c_str());
+        }
+        (void)hipSetDevice(caller_device);
+    }
     // shard k renders into its own raw-sum buffer on ITS device; shards 1.. land in a staging buffer on devices[0]
     std::vector<void *> d_sum(n_devices, nullptr), d_stage(n_devices, nullptr);
     for (int k = 0; k < n_devices; k++) {
-        d_sum[k] = buf.alloc(devices[k], sum_bytes);
+        d_sum[k] = buf.alloc(devices[k], 2 + 2 * k, sum_bytes);
         if (!d_sum[k]) return fail("rt_render_multi: out of device memory on device " + std::to_string(devices[k]));
         if (k > 0) {
-            d_stage[k] = devices[k] == dev0 ? d_sum[k] : buf.alloc(dev0, sum_bytes);  // (same device: the buffer is its own staging)
+            d_stage[k] = devices[k] == dev0 ? d_sum[k] : buf.alloc(dev0, 3 + 2 * k, sum_bytes);  // (same device: the buffer is its own staging)
             if (!d_stage[k]) return fail("rt_render_multi: out of device memory on device " + std::to_string(dev0));
         }
     }
-    float *d_out = fixed ? (float *)buf.alloc(dev0, n_values * sizeof(float)) : (float *)d_sum[0];
+    float *d_out = fixed ? (float *)buf.alloc(dev0, 1, n_values * sizeof(float)) : (float *)d_sum[0];
     if (!d_out) return fail("rt_render_multi: out of device memory");
     // ---- one host thread per device (render.cuh's render() is one thread on one device: this is the multi-device form of
     // the same call): select the device, zero the shard's sums, render slot shard k of n, hand the sums to devices[0]
@@ -4179,9 +3969,10 @@ int rt_render_multi(const rt_scene *scene, const rt_camera *camera, int width, i
                 rc[k] = render_shard_impl(on_dev[k], camera, width, height, num_samples, max_bounces, seed, k, n_devices, shard_flags,
                                           (float *)d_sum[k], st, &sub[k], /* a context of its own per shard: */ 8 + k);
                 if (rc[k]) err[k] = g_last_error;
-                else if (k > 0 && d_stage[k] != d_sum[k] &&
-                         hipMemcpyPeerAsync(d_stage[k], dev0, d_sum[k], devices[k], sum_bytes, st) != hipSuccess)
-                    bail("peer copy of the shard's sums failed");
+                else if (k > 0 && d_stage[k] != d_sum[k]) {
+                    const hipError_t pe = hipMemcpyPeerAsync(d_stage[k], dev0, d_sum[k], devices[k], sum_bytes, st);
+                    if (pe != hipSuccess) bail((std::string("peer copy of the shard's sums failed: ") + hipGetErrorString(pe)).c_str());
+                }
             }
             if (hipStreamSynchronize(st) != hipSuccess && rc[k] == 0) bail("stream synchronise failed");
             (void)hipStreamDestroy(st);
@@ -4357,293 +4148,6 @@ int rt_xorwow_states(uint64_t seed, uint32_t first, uint32_t count, int draws, u
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(state6, d_state, sizeof(uint32_t) * 6 * (size_t)count, hipMemcpyDeviceToHost));
     if (draws > 0) HIP_TRY(hipMemcpy(uniforms, d_uni, sizeof(float) * (size_t)count * draws, hipMemcpyDeviceToHost));
-    return 0;
-}
-
-int rt_measure_copy_bandwidth(int64_t bytes, int reps, double *out_bytes_per_s) {
-    if (bytes < 1024 || reps < 1 || !out_bytes_per_s) return fail("rt_measure_copy_bandwidth: bad argument");
-    size_t n4 = (size_t)bytes / 16;
-    float4 *a = nullptr, *b = nullptr;
-    DevScope tmp;
-    if (tmp.alloc(a, n4) || tmp.alloc(b, n4)) return 1;
-    HIP_TRY(hipMemset(a, 1, n4 * 16));
-    HIP_TRY(hipEventCreate(&tmp.e0));
-    HIP_TRY(hipEventCreate(&tmp.e1));
-    const hipEvent_t e0 = tmp.e0, e1 = tmp.e1;
-    double best = 0.0;
-    for (int r = 0; r < reps + 1; r++) {
-        HIP_TRY(hipEventRecord(e0, nullptr));
-        hipLaunchKernelGGL(k_copy_f4, dim3(256 * 8), dim3(256), 0, nullptr, a, b, n4);
-        HIP_TRY(hipEventRecord(e1, nullptr));
-        HIP_TRY(hipEventSynchronize(e1));
-        float ms = 0.f;
-        HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-        if (r > 0 && ms > 0.f) best = std::max(best, 2.0 * (double)n4 * 16.0 / (ms * 1e-3));
-    }
-    *out_bytes_per_s = best;
-    return 0;
-}
-
-int rt_calibrate_valu(int waves_per_simd, int iters, double *out_lane_ops_per_s, double *out_wave_instr) {
-    if (waves_per_simd < 1 || waves_per_simd > 8 || iters < 1 || !out_lane_ops_per_s) return fail("rt_calibrate_valu: bad argument");
-    int dev = 0, cus = 0;
-    HIP_TRY(hipGetDevice(&dev));
-    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    // one 256-thread workgroup = one wave on each of a CU's four SIMDs
-    const int blocks = cus * waves_per_simd;
-    float *d_out = nullptr;
-    DevScope tmp;
-    if (tmp.alloc(d_out, (size_t)blocks * 256)) return 1;
-    HIP_TRY(hipEventCreate(&tmp.e0));
-    HIP_TRY(hipEventCreate(&tmp.e1));
-    const hipEvent_t e0 = tmp.e0, e1 = tmp.e1;
-    double best = 0.0;
-    for (int r = 0; r < 7; r++) {  // (first launch untimed; clocks ramp: the best of six)
-        HIP_TRY(hipEventRecord(e0, nullptr));
-        hipLaunchKernelGGL(k_valu_calibrate, dim3(blocks), dim3(256), 0, nullptr, d_out, iters, 1.f);
-        HIP_TRY(hipEventRecord(e1, nullptr));
-        HIP_TRY(hipEventSynchronize(e1));
-        float ms = 0.f;
-        HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-        const double lane_ops = (double)blocks * 256.0 * 16.0 * (double)iters;
-        if (r > 0 && ms > 0.f) best = std::max(best, lane_ops / (ms * 1e-3));
-    }
-    HIP_TRY(hipGetLastError());
-    *out_lane_ops_per_s = best;
-    if (out_wave_instr) *out_wave_instr = (double)blocks * 4.0 * 16.0 * (double)iters;  // v_fma_f32 wave-instructions per launch
-    return 0;
-}
-
-int rt_calibrate_valu_packed(int waves_per_simd, int iters, int kind, double *out_lane_ops_per_s) {
-    if (waves_per_simd < 1 || waves_per_simd > 8 || iters < 1 || kind < 1 || kind > 3 || !out_lane_ops_per_s)
-        return fail("rt_calibrate_valu_packed: bad argument");
-    int dev = 0, cus = 0;
-    HIP_TRY(hipGetDevice(&dev));
-    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    const int blocks = cus * waves_per_simd;
-    float *d_out = nullptr;
-    DevScope tmp;
-    if (tmp.alloc(d_out, (size_t)blocks * 256)) return 1;
-    HIP_TRY(hipEventCreate(&tmp.e0));
-    HIP_TRY(hipEventCreate(&tmp.e1));
-    double best = 0.0;
-    for (int r = 0; r < 7; r++) {  // (first launch untimed; the best of six)
-        HIP_TRY(hipEventRecord(tmp.e0, nullptr));
-        if (kind == 1) hipLaunchKernelGGL(k_valu_calibrate_pk<1>, dim3(blocks), dim3(256), 0, nullptr, d_out, iters, 1.f);
-        else if (kind == 2) hipLaunchKernelGGL(k_valu_calibrate_pk<2>, dim3(blocks), dim3(256), 0, nullptr, d_out, iters, 1.f);
-        else hipLaunchKernelGGL(k_valu_calibrate_pk<3>, dim3(blocks), dim3(256), 0, nullptr, d_out, iters, 1.f);
-        HIP_TRY(hipEventRecord(tmp.e1, nullptr));
-        HIP_TRY(hipEventSynchronize(tmp.e1));
-        float ms = 0.f;
-        HIP_TRY(hipEventElapsedTime(&ms, tmp.e0, tmp.e1));
-        const double lane_ops = (double)blocks * 256.0 * 16.0 * 2.0 * (double)iters;  // two lane-operations per lane and instruction
-        if (r > 0 && ms > 0.f) best = std::max(best, lane_ops / (ms * 1e-3));
-    }
-    HIP_TRY(hipGetLastError());
-    *out_lane_ops_per_s = best;
-    return 0;
-}
-
-int rt_probe_issue(int kind, int waves_per_simd, int iters, double *out_seconds, double *out_wave_instr_per_wave) {
-    if (kind < 0 || kind >= kProbeKinds || waves_per_simd < 1 || waves_per_simd > 8 || iters < 1 || !out_seconds)
-        return fail("rt_probe_issue: bad argument");
-    int dev = 0, cus = 0;
-    HIP_TRY(hipGetDevice(&dev));
-    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    const int blocks = cus * waves_per_simd;
-    float *d_out = nullptr;
-    DevScope tmp;
-    if (tmp.alloc(d_out, (size_t)blocks * 256)) return 1;
-    HIP_TRY(hipEventCreate(&tmp.e0));
-    HIP_TRY(hipEventCreate(&tmp.e1));
-    double best = 1e30;
-    for (int r = 0; r < 5; r++) {  // (first launch untimed; the best of four)
-        HIP_TRY(hipEventRecord(tmp.e0, nullptr));
-        switch (kind) {
-#define RT_CASE(K) case K: hipLaunchKernelGGL(k_probe_issue<K>, dim3(blocks), dim3(256), 0, nullptr, d_out, iters, 1.f); break;
-            RT_CASE(0) RT_CASE(1) RT_CASE(2) RT_CASE(3) RT_CASE(4) RT_CASE(5) RT_CASE(6) RT_CASE(7) RT_CASE(8) RT_CASE(9)
-            RT_CASE(10) RT_CASE(11) RT_CASE(12) RT_CASE(13) RT_CASE(14) RT_CASE(15) RT_CASE(16) RT_CASE(17) RT_CASE(18) RT_CASE(19)
-            RT_CASE(20) RT_CASE(21) RT_CASE(22) RT_CASE(23) RT_CASE(24) RT_CASE(25)
-#undef RT_CASE
-        }
-        HIP_TRY(hipEventRecord(tmp.e1, nullptr));
-        HIP_TRY(hipEventSynchronize(tmp.e1));
-        float ms = 0.f;
-        HIP_TRY(hipEventElapsedTime(&ms, tmp.e0, tmp.e1));
-        if (r > 0 && ms > 0.f) best = std::min(best, (double)ms * 1e-3);
-    }
-    HIP_TRY(hipGetLastError());
-    *out_seconds = best;
-    if (out_wave_instr_per_wave)
-        *out_wave_instr_per_wave = (kind >= 22 ? 64.0 : (kind == 11 || kind == 19) ? 32.0 : 16.0) * (double)iters;
-    return 0;
-}
-
-int rt_split_probe(const rt_scene *scene, const rt_camera *camera, int width, int height, int num_samples, int max_bounces,
-                   uint64_t seed, int64_t target_rays, double *out, int n_out) {
-    if (!scene || !camera || !out || n_out < RT_PROBE_COUNT) return fail("rt_split_probe: bad argument");
-    if (width <= 0 || height <= 0 || num_samples <= 0 || max_bounces < 0 || target_rays < 1 || target_rays > (1LL << 30))
-        return fail("rt_split_probe: bad dimensions");
-    const long long cam_end = (long long)width * height * num_samples;
-    if (cam_end + 13LL * kW >= (1LL << 31)) return fail("rt_split_probe: frame exceeds the int32 camera-ray range");
-    int dev = 0, cus = 0;
-    HIP_TRY(hipGetDevice(&dev));
-    if (dev != scene->device) return fail("rt_split_probe: scene was created on another device");
-    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    for (int k = 0; k < n_out; k++) out[k] = 0.0;
-    const int n = kW;
-    Context *cp = nullptr;
-    if (get_context(n, 7, &cp)) return 1;  // (a context of its own: lane 7)
-    Context &c = *cp;
-    std::lock_guard<std::mutex> busy_lock(c.busy);
-    double rng_seconds = 0.0;
-    if (ensure_rng(c, seed, 0, nullptr, &rng_seconds)) return 1;
-    DevScope pb;
-    HIP_TRY(hipEventCreate(&pb.e0));
-    HIP_TRY(hipEventCreate(&pb.e1));
-    const unsigned cap = (unsigned)(target_rays + 2 * (long long)kW);
-    float *c_o3, *c_d3, *c_tmax, *a_o3, *a_d3, *a_tmax, *rec, *outp, *fb, *o_t, *o_u, *o_v;
-    int *a_excl, *o_i;
-    unsigned *d_counts;
-    if (pb.alloc(c_o3, 3 * (size_t)cap) || pb.alloc(c_d3, 3 * (size_t)cap) || pb.alloc(c_tmax, cap) || pb.alloc(a_o3, 3 * (size_t)cap) ||
-        pb.alloc(a_d3, 3 * (size_t)cap) || pb.alloc(a_tmax, cap) || pb.alloc(a_excl, cap) || pb.alloc(rec, 3 * (size_t)kProbeIn * cap) ||
-        pb.alloc(outp, (size_t)kProbeOut * cap) || pb.alloc(fb, 3 * (size_t)width * height) || pb.alloc(o_i, cap) || pb.alloc(o_t, cap) ||
-        pb.alloc(o_u, cap) || pb.alloc(o_v, cap) || pb.alloc(d_counts, 8))
-        return 1;
-    HIP_TRY(hipMemset(d_counts, 0, sizeof(unsigned) * 8));
-    HIP_TRY(hipMemset(fb, 0, sizeof(float) * 3 * (size_t)width * height));
-    HIP_TRY(hipMemset(c.d_rows, 0, sizeof(DWaveRow) * (size_t)c.n_rows));
-    {
-        DCounters zero{};
-        zero.last_live_round = -1;
-        HIP_TRY(hipMemcpy(c.d_ctr, &zero, sizeof(DCounters), hipMemcpyHostToDevice));
-    }
-    DScene sc = scene->dev();
-    Camera cam;
-    memcpy(&cam, camera, sizeof(Camera));
-    AdvanceParams ap{};
-    ap.n = n;
-    ap.slot_lo = 0;
-    ap.width = width;
-    ap.height = height;
-    ap.spp = num_samples;
-    ap.max_bounces = max_bounces;
-    ap.cam_end = cam_end;
-    ap.last_gen = (int)((cam_end + kW - 1) / kW) - 1;
-    ap.batch_mask = 7;
-    ap.w_over_spp = (kW % num_samples == 0) ? kW / num_samples : 0;
-    ap.dpx = ap.w_over_spp % width;
-    ap.dpy = (ap.w_over_spp > 0 && width < 32768 && height < 32768) ? ap.w_over_spp / width : -1;
-    const bool lds_tables = scene->n_mats <= kLdsTable && scene->n_lights <= kLdsTable;
-    const int stack_cap = lds_stack_cap(scene, kLdsStack);
-    const size_t lds_bytes = sizeof(int) * (size_t)kBlock * (size_t)(stack_cap + 2);
-    if (ensure_overflow(c.d_over, c.over_levels, scene->stack_bound - std::min(stack_cap, lds_stack_cap(scene, 8)))) return 1;
-    int occ_c = 0;
-    if (scene->wide) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_c, k_trace<MODE_POOL, true>, kBlock, lds_bytes));
-    else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_c, k_trace<MODE_POOL, false>, kBlock, lds_bytes));
-    const dim3 grid(grid_for(n)), block(kBlock), grid_trace(std::min(grid_for(n), std::max(1, cus * std::max(1, occ_c))));
-    TraceParams tpp{};
-    tpp.total = n;
-    tpp.fb = fb;
-    tpp.rows = c.d_rows;
-    hipLaunchKernelGGL(k_pool_init, grid, block, 0, nullptr, c.pools, n, max_bounces);
-    HIP_TRY(hipGetLastError());
-    // ---- the round pipeline, with the dumps between its stages; every stage timed with events (synchronously: a probe)
-    unsigned h_counts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    double t_adv = 0.0, t_trace = 0.0, t_adv0 = 0.0;
-    int rounds = 0;
-    auto timed = [&](double &acc) -> int {
-        HIP_TRY(hipEventRecord(pb.e1, nullptr));
-        HIP_TRY(hipEventSynchronize(pb.e1));
-        float ms = 0.f;
-        HIP_TRY(hipEventElapsedTime(&ms, pb.e0, pb.e1));
-        acc += (double)ms * 1e-3;
-        return 0;
-    };
-    while ((long long)h_counts[0] + h_counts[1] < target_rays && rounds < 4096) {
-        ap.round = rounds;
-        double t = 0.0;
-        HIP_TRY(hipEventRecord(pb.e0, nullptr));
-        RT_LAUNCH_ADVANCE(nullptr, fb);
-        if (timed(t)) return 1;
-        if (rounds == 0) t_adv0 = t;  // every slot generates: gen() alone
-        else t_adv += t;
-        hipLaunchKernelGGL(k_probe_dump_rays, grid, block, 0, nullptr, c.pools, n, c_o3, c_d3, c_tmax, a_o3, a_d3, a_tmax, a_excl, cap, d_counts);
-        HIP_TRY(hipEventRecord(pb.e0, nullptr));
-        RT_LAUNCH_TRACE(MODE_POOL, scene->wide, grid_trace, lds_bytes, nullptr, sc, c.pools, tpp, stack_cap, c.d_over);
-        if (timed(t_trace)) return 1;
-        hipLaunchKernelGGL(k_probe_dump_shades, grid, block, 0, nullptr, sc, c.pools, n, max_bounces, rec, cap, d_counts);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpy(h_counts, d_counts, sizeof(h_counts), hipMemcpyDeviceToHost));
-        rounds++;
-        if (h_counts[0] == 0) break;  // (frame exhausted)
-    }
-    c.rng_valid = false;  // the pools' RNG arrays have moved on
-    const unsigned n_c = std::min(h_counts[0], cap), n_a = std::min(h_counts[1], cap);
-    out[RT_PROBE_ROUNDS] = rounds;
-    out[RT_PROBE_CLOSEST_RAYS] = n_c;
-    out[RT_PROBE_ANY_RAYS] = n_a;
-    out[RT_PROBE_S_ADVANCE_ROUND0] = t_adv0;
-    out[RT_PROBE_S_ADVANCE] = t_adv;
-    out[RT_PROBE_S_TRACE_POOL] = t_trace;
-    // ---- trace only: the stage-level modes of k_trace on the dense ray arrays, at four register budgets
-    {
-        TraceParams tc{};
-        tc.total = (int)n_c;
-        tc.o3 = c_o3;
-        tc.d3 = c_d3;
-        tc.tmax = c_tmax;
-        tc.order = scene->d_order;
-        tc.out_i = o_i;
-        tc.out_t = o_t;
-        tc.out_u = o_u;
-        tc.out_v = o_v;
-        TraceParams ta{};
-        ta.total = (int)n_a;
-        ta.o3 = a_o3;
-        ta.d3 = a_d3;
-        ta.tmax = a_tmax;
-        ta.excluded = a_excl;
-        ta.out_i = o_i;
-        const int budgets[4] = {8, 6, 5, 4};
-        for (int v = 0; v < 4; v++) {
-            double sc_s = 0.0, sa_s = 0.0, bc = 0.0, ba = 0.0;
-            if (n_c > 0) {
-                if (scene->wide ? probe_trace<MODE_TEST_CLOSEST, true>(scene, tc, stack_cap, c.d_over, cus, pb.e0, pb.e1, budgets[v], &sc_s, &bc)
-                                : probe_trace<MODE_TEST_CLOSEST, false>(scene, tc, stack_cap, c.d_over, cus, pb.e0, pb.e1, budgets[v], &sc_s, &bc))
-                    return 1;
-            }
-            if (n_a > 0) {
-                if (scene->wide ? probe_trace<MODE_TEST_ANY, true>(scene, ta, stack_cap, c.d_over, cus, pb.e0, pb.e1, budgets[v], &sa_s, &ba)
-                                : probe_trace<MODE_TEST_ANY, false>(scene, ta, stack_cap, c.d_over, cus, pb.e0, pb.e1, budgets[v], &sa_s, &ba))
-                    return 1;
-            }
-            out[RT_PROBE_S_TRACE_CLOSEST + v] = sc_s;
-            out[RT_PROBE_S_TRACE_ANY + v] = sa_s;
-            out[RT_PROBE_TRACE_BLOCKS_PER_CU + v] = bc;
-        }
-    }
-    // ---- shade only: one launch per material kind, every lane shading
-    for (int mk = 0; mk < 3; mk++) {
-        const unsigned cnt = std::min(h_counts[2 + mk], cap);
-        out[RT_PROBE_SHADES + mk] = cnt;
-        if (cnt == 0) continue;
-        double best = 1e30;
-        for (int rep = 0; rep < 3; rep++) {
-            HIP_TRY(hipEventRecord(pb.e0, nullptr));
-            if (lds_tables)
-                hipLaunchKernelGGL(k_probe_shade<true>, dim3((cnt + kBlock - 1) / kBlock), block, 0, nullptr, sc, cam, ap,
-                                   rec + (size_t)mk * kProbeIn * cap, cap, cnt, outp, fb);
-            else
-                hipLaunchKernelGGL(k_probe_shade<false>, dim3((cnt + kBlock - 1) / kBlock), block, 0, nullptr, sc, cam, ap,
-                                   rec + (size_t)mk * kProbeIn * cap, cap, cnt, outp, fb);
-            HIP_TRY(hipGetLastError());
-            double t = 0.0;
-            if (timed(t)) return 1;
-            best = std::min(best, t);
-        }
-        out[RT_PROBE_S_SHADE + mk] = best;
-    }
     return 0;
 }
 

@@ -8,6 +8,11 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# The library reads its experiment knobs (RT_PERSISTENT, RT_BVH_WIDE, RT_STACK_CAP, ...) only under this gate; the suite drives
+# those code paths against the oracle, so the gate is on for the test session (test_knobs_are_ignored_without_the_gate takes it off)
+os.environ["RTCUDA_EXPERIMENTAL"] = "1"
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

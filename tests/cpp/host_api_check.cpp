@@ -6,6 +6,7 @@
 //   host_api_check dump <variant> <ply> <out.bin>   : scene arrays as raw binary for comparison with scenes.py
 //   host_api_check ply <file.ply> <out.bin>         : positions (double) + face indices (int64) as raw binary
 //   host_api_check unit                             : prints name=value lines of small known-answer checks
+//   host_api_check devices                          : RTCUDA_DEVICES as render() parses it (exit code 1: malformed)
 #define RTCUDA_PLY_AS_HAPPLY
 #include <cstdio>
 #include <cstring>
@@ -176,6 +177,11 @@ int main(int argc, char **argv) {
         if (mode == "dump" && argc == 5) return dump(argv[2], argv[3], argv[4]);
         if (mode == "ply" && argc == 4) return ply(argv[2], argv[3]);
         if (mode == "unit") return unit();
+        if (mode == "devices") {  // RTCUDA_DEVICES as render() reads it: the list, or an exception (exit code 1) on a malformed value
+            for (int d : devices_from_env()) printf("%d ", d);
+            printf("\n");
+            return 0;
+        }
         if (mode == "stages" && argc == 3) return stages(argv[2]);
         if (mode == "render" && argc == 3) return render_smoke(argv[2]) > 0 ? 0 : 1;
         fprintf(stderr, "usage: host_api_check dump <variant> <ply|-> <out> | ply <in> <out> | unit | render <ply>\n");

@@ -209,12 +209,12 @@ def test_bench_py_starts_ranks_itself_and_fails_loudly_without_a_gpu():
     """bench.py itself, as the driver invokes it (`python3 bench.py --gpus 2 ...`, no launcher): it must get as far as its
     ranks -- each of which refuses to run without the HIP library's GPU (there is no CPU fallback) -- and exit non-zero."""
     import subprocess
+    import torch
+    if torch.cuda.is_available():  # (checked BEFORE anything is started: on a GPU node bench.py --gpus 2 would run a whole bench)
+        pytest.skip("a GPU is present: the N > 1 flow is exercised by the GPU rehearsal instead")
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                        capture_output=True, text=True, timeout=300, env=env)
-    import torch
-    if torch.cuda.is_available():
-        pytest.skip("a GPU is present: the N > 1 flow is exercised by the GPU rehearsal instead")
     assert p.returncode != 0
     assert p.stderr.count("bench.py needs a GPU") == 2  # both ranks were started and said so
     assert "launch with torch.distributed.run" not in p.stderr

@@ -115,3 +115,38 @@ def test_cpp_driver_reaches_several_devices_through_render(api, tmp_path):
     assert (d1 != one).mean() < 1e-3 and np.abs(d1 - one).max() <= 1
     ref, _ = run("ref.ppm", env=dict(os.environ, RTCUDA_REFERENCE_WALK="1"))
     assert (ref != one).mean() < 1e-2 and ref.any()
+
+
+def test_shutdown_releases_the_hidden_allocations_and_the_library_keeps_working(api, gpu_full):
+    """rt_shutdown frees the render contexts (path pools, RNG states, counters, overflow stacks) and the cached output buffers
+    of rt_render / rt_render_multi; the next call re-creates what it needs and renders the same image."""
+    import torch
+    w, h, spp = 96, 54, 8
+    cam = api.make_camera(aspect=w / h)
+    a, st_a = gpu_full.render(cam, w, h, spp, flags=api.FLAG_DETERMINISTIC)
+    m, _ = gpu_full.render_multi(cam, w, h, spp, [0, 0], flags=api.FLAG_DETERMINISTIC)
+    torch.cuda.synchronize()
+    free_before = torch.cuda.mem_get_info()[0]
+    api.shutdown()
+    free_after = torch.cuda.mem_get_info()[0]
+    assert free_after >= free_before + (100 << 20)  # the full-pool context alone is 36 x 4 MB of path state + 24 MB of RNG backup
+    b, st_b = gpu_full.render(cam, w, h, spp, flags=api.FLAG_DETERMINISTIC)
+    m2, _ = gpu_full.render_multi(cam, w, h, spp, [0, 0], flags=api.FLAG_DETERMINISTIC)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)) and np.array_equal(m.view(np.uint32), m2.view(np.uint32))
+    assert st_a["shade_events"] == st_b["shade_events"]
+    api.shutdown()
+    api.shutdown()  # (idempotent)
+
+
+def test_peer_access_log_is_empty_until_two_different_devices_are_listed(api, gpu_full):
+    """rt_render_multi enables peer access devices[0] <-> devices[k] once per pair and says what became of it
+    (rt_peer_access_log).  A one-GPU box can only list device 0 several times: nothing to enable, an empty log -- the copy
+    between two physical devices runs for the first time in the driver's multi-GPU run, where bench.py records this string."""
+    cam = api.make_camera(aspect=1.0)
+    gpu_full.render_multi(cam, 32, 32, 4, [0, 0])
+    import torch
+    if torch.cuda.device_count() == 1:
+        assert api.peer_access_log() == ""
+    else:
+        gpu_full.render_multi(cam, 32, 32, 4, [0, 1])
+        assert "devices 0 <-> 1" in api.peer_access_log()

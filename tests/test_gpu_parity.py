@@ -491,12 +491,17 @@ def test_device_lbvh_builder_gives_the_same_image(api, oracle, cpu_matte, bunny_
         sc.close()
 
 
-def test_split_probe_counts_what_the_frame_traces(api, gpu_full):
-    """rt_split_probe (the stage split priced: tools/split_probe.py) on a small frame: the rays and shading records it dumps
-    are the frame's own -- as many closest-hit rays as the round pipeline traces in those rounds, every shading record in
-    one of the three material buckets -- and every timed stage reports a positive time."""
+def test_split_probe_counts_what_the_frame_traces(api, gpu_full, bunny_full_bsdf):
+    """rt_split_probe (the stage split priced: tools/split_probe.py; a LAB entry point: include/rtcuda_amd_tools.h,
+    librtcuda_amd_tools.so) on a small frame: the rays and shading records it dumps are the frame's own -- as many closest-hit
+    rays as the round pipeline traces in those rounds, every shading record in one of the three material buckets -- and every
+    timed stage reports a positive time."""
     w, h, spp = 320, 180, 64  # 3.5 generations
-    r = api.split_probe(gpu_full, api.make_camera(aspect=w / h), w, h, spp, target_rays=3_000_000)
+    lab_scene = api.Scene(bunny_full_bsdf, library=api.tools_lib())  # (the lab library works on scenes of its own)
+    r = api.split_probe(lab_scene, api.make_camera(aspect=w / h), w, h, spp, target_rays=3_000_000)
+    lab_scene.close()
+    with pytest.raises(api.RtError):
+        api.split_probe(gpu_full, api.make_camera(aspect=w / h), w, h, spp, target_rays=1000)  # a product-library scene
     assert r["rounds"] >= 2 and r["closest_rays"] + r["any_rays"] >= 3_000_000
     assert r["closest_rays"] <= r["rounds"] * api.W and 0 < r["any_rays"] < r["closest_rays"]
     shades = r["shades_matte"] + r["shades_mirror"] + r["shades_glass"]
@@ -527,3 +532,24 @@ def test_rcp_exact_normal_is_the_ieee_quotient_on_this_chip(tmp_path):
     one_step, two_steps, patterns = (int(x) for x in out.stdout.split()[:3])
     assert out.returncode == 0 and one_step == 0 and two_steps == 0, out.stdout
     assert patterns > 2_000_000_000
+
+
+def test_knobs_are_ignored_without_the_gate(api, gpu_full, monkeypatch):
+    """A drop-in library must not change behaviour because some RT_* variable is set in the user's shell: the experiment knobs
+    are read only under RTCUDA_EXPERIMENTAL=1.  RT_PERSISTENT=0 (one launch per round instead of the persistent kernel) shows
+    in the statistics -- many more stage rounds -- exactly when the gate is on."""
+    w, h, spp = 320, 180, 64  # 3.5 generations
+    cam = api.make_camera(aspect=w / h)
+    _, st_default = gpu_full.render(cam, w, h, spp)
+    monkeypatch.setenv("RT_PERSISTENT", "0")
+    monkeypatch.setenv("RT_MAJORITY", "0")
+    _, st_gated = gpu_full.render(cam, w, h, spp)
+    assert st_gated["iterations"] > 3 * st_default["iterations"]
+    monkeypatch.delenv("RTCUDA_EXPERIMENTAL")
+    _, st_ungated = gpu_full.render(cam, w, h, spp)
+    assert st_ungated["iterations"] == st_default["iterations"]
+    monkeypatch.setenv("RTCUDA_EXPERIMENTAL", "yes")  # (only the exact value 1 opens the gate)
+    _, st_other = gpu_full.render(cam, w, h, spp)
+    assert st_other["iterations"] == st_default["iterations"]
+    for k in ("shade_events", "any_rays", "shadow_adds", "rr_draws"):
+        assert st_default[k] == st_gated[k] == st_ungated[k]

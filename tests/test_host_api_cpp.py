@@ -372,3 +372,22 @@ def test_reference_host_build_reproduces_the_committed_fixture(tmp_path):
     assert _same_bits(got["parsed_positions_f64"], fx["parsed_positions_f32"].astype(np.float64))
     for k in ("faces", "bunny_matrix", "transformed_f32", "applied_every_997th_f64", "rotate_args", "rotate_matrices", "rotated_applies_f64"):
         assert _same_bits(got[k], fx[k]), k
+
+
+def test_rtcuda_devices_is_parsed_strictly(exe):
+    """RTCUDA_DEVICES sends the reference's unchanged render() call through rt_render_multi.  A typo must not silently change
+    which GPUs render: anything but non-negative ordinals separated by single commas throws ('a,b' used to give a
+    single-device render, '0,x' the list [0])."""
+    def run(value):
+        env = dict(os.environ)
+        env.pop("RTCUDA_DEVICES", None)
+        if value is not None:
+            env["RTCUDA_DEVICES"] = value
+        return subprocess.run([exe, "devices"], capture_output=True, text=True, env=env)
+    assert run(None).stdout.split() == []
+    assert run("0").stdout.split() == ["0"]
+    assert run("0,1,2,3").stdout.split() == ["0", "1", "2", "3"]
+    assert run("3,3").stdout.split() == ["3", "3"]
+    for bad in ("a,b", "0,x", "0,,1", "0,1,", ",0", "", "-1", "0 1", "1;2"):
+        p = run(bad)
+        assert p.returncode == 1 and "RTCUDA_DEVICES" in p.stderr, (bad, p.returncode, p.stdout, p.stderr)

@@ -18,8 +18,8 @@ with open(os.path.join(ROOT, "tests", "golden", "appendix_c.json")) as _fh:
 
 
 # ----------------------------------------------------------------------------- C-ABI surface
-def _declared_functions():
-    text = open(os.path.join(ROOT, "include", "rtcuda_amd.h")).read()
+def _declared_functions(header="rtcuda_amd.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(rt_[a-z_0-9]+)\s*\(", text)))
 
@@ -34,6 +34,13 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), name
     assert b"gfx950" in L.rt_version()
+    # the drop-in library carries the drop-in C-ABI and nothing else: the measurement tools live in a library of their own
+    tools = _declared_functions("rtcuda_amd_tools.h")
+    assert set(tools) == set(api.TOOLS_EXPORTS), (tools, api.TOOLS_EXPORTS)
+    T = api.tools_lib()
+    for name in tools:
+        assert hasattr(T, name), name
+        assert not hasattr(L, name), f"{name} is a lab entry point and must not be exported by the product library"
 
 
 def test_struct_layouts_match_the_header():

@@ -11,6 +11,7 @@ import sys
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ["RTCUDA_EXPERIMENTAL"] = "1"  # (the library reads its experiment knobs only under this gate)
 import torch  # noqa: E402
 from rtcuda_amd import api, scenes  # noqa: E402
 

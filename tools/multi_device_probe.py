@@ -32,7 +32,7 @@ def main():
     print(json.dumps({"devices": devices, "device_shards": st["device_shards"], "wall_ms_first_call": round(1e3 * t_first, 2),
                       "wall_ms": round(1e3 * t_second, 2), "device_ms_slowest_shard": round(1e3 * st["seconds_render"], 3),
                       "Msamples_per_s_wall": round(float(w) * h * spp / t_second / 1e6, 1),
-                      "totals": {k: int(st[k]) for k in keys},
+                      "totals": {k: int(st[k]) for k in keys}, "peer_access": api.peer_access_log(),
                       "image_mean": float(np.nanmean(img, dtype=np.float64)),
                       "nan_pixels": int(np.isnan(img).any(axis=2).sum())}), flush=True)
 

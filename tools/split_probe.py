@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """decide the wavefront split with measurements.
 
-Runs rt_split_probe (include/rtcuda_amd.h) on BASELINE configs[1]'s frame (C2: bun_zipper.ply, full BSDF set,
+Runs rt_split_probe (include/rtcuda_amd_tools.h) on BASELINE configs[1]'s frame (C2: bun_zipper.ply, full BSDF set,
 1920x1080x256): >= 64 M real rays of the frame's first generations are dumped from the round pipeline into dense
 device arrays, then
   A  the trace kernel alone on them (device-resident, no PCIe), at 8 / 6 / 5 / 4 waves per SIMD -> Grays/s
@@ -34,8 +34,9 @@ def run(wide: bool):
     if wide:
         os.environ.pop("RT_BVH_WIDE", None)
     else:
+        os.environ["RTCUDA_EXPERIMENTAL"] = "1"
         os.environ["RT_BVH_WIDE"] = "0"
-    sc = api.Scene(scenes.cornell_bunny(variant))
+    sc = api.Scene(scenes.cornell_bunny(variant), library=api.tools_lib())
     r = api.split_probe(sc, api.make_camera(aspect=w / h), w, h, spp, target)
     sc.close()
     os.environ.pop("RT_BVH_WIDE", None)
