@@ -79,7 +79,10 @@ typedef struct rt_stats {
                                 reserved[1] = 1 when the frame ran as one persistent k_paths launch (then
                                 seconds_trace is that launch's duration and launches_trace is 1);
                                 reserved[2] = BVH node records that launch staged in LDS (small shards only);
-                                reserved[3] = rt_render_multi: number of device shards behind these totals */
+                                reserved[3] = rt_render_multi: number of device shards behind these totals;
+                                default kernels (no RT_FLAG_WATERTIGHT): reserved[4] = rays re-traced through the reference's
+                                own tree, reserved[5] = accepted hits the reference's box test loses, reserved[6] = closest
+                                hits with an exact tie at the final distance */
 } rt_stats;
 
 /* Flags for rt_render / rt_render_shard */
@@ -96,24 +99,31 @@ typedef struct rt_stats {
                                     shards' fixed-point sums add up to the 1-GPU sums exactly, and 8 GPUs are not held to
                                     1/8 of the W chains each (SURVEY.md section 7 "per_sample", section 8b `rng_mode`) */
 
-#define RT_FLAG_REFERENCE_WALK 8u /* opt-in parity mode, never benchmarked: traverse the REFERENCE's own tree with the reference's
-                                    own decisions instead of the product's.  Two results of lashhw/rtcuda are properties of its
-                                    BVH, not of the scene: its fp32 slab test on exact boxes (aabb_intersector.cuh:14-36,
-                                    hit iff entry <= exit) drops about one accepted hit in 10^7 rays, and among hits at exactly
-                                    equal t the triangle its walk tests last wins (triangle.cuh:49).  By default the library
-                                    defines both by the triangle list alone (an accepted hit is never culled; ties go to the
-                                    larger caller index).  With this flag the library builds the reference's binary SAH tree
-                                    (bvh.cuh:30-219: std::sort per axis, full sweep, stable partition) from the scene's
-                                    triangles on first use and every ray walks it as Bvh::traverse does (bvh.cuh:221-357):
-                                    same boxes, same arithmetic, near child first by fp32 entry distance, left leaf before
-                                    right leaf, later-tested triangle wins a tie.  The image then equals the reference
-                                    algorithm's image ray for ray, including the hits its box test loses.  Several times
-                                    slower than the default kernels.  Not combinable with RT_FLAG_RNG_PER_SAMPLE. */
-
-#define RT_FLAG_WATERTIGHT 16u /* the triangle-list definition of the two results above instead of the reference's: an accepted
-                                    hit is never lost to a box test, ties go to the larger caller index.  This is what
-                                    exhaustive search over all triangles returns (about 1 path in 4 * 10^6 differs from the
-                                    reference's image).  Saves the default's check of every hit (a few per cent). */
+/* WHICH HITS A RAY FINDS: the reference's own decisions are the default.
+ * Two results of lashhw/rtcuda are properties of its own BVH, not of the scene: its fp32 slab test on exact boxes
+ * (aabb_intersector.cuh:14-36, hit iff entry <= exit, no look at tmax) drops about one accepted hit in 10^7 rays, and among
+ * hits at exactly equal t the triangle its walk tests last wins (triangle.cuh:49).  Both are functions of the ray alone --
+ * a triangle is visible to the reference's walk iff the box of its LEAF passes that slab test (the boxes above it are nested
+ * exactly and fp32 rounding is monotone, so they pass with it) -- which lets the library reproduce them on its OWN tree:
+ *
+ *   flags = 0 (default; what bench.py times): the product's 4-wide walk; a shadow ray's occluder counts only if the
+ *       reference's walk can see it; a path ray's closest hit is checked once (visible? no exact tie at the final distance?)
+ *       and the ~2 rays in 10^7 that fail are re-traced through the reference's own binary SAH tree (bvh.cuh:30-219, built
+ *       from the scene's triangles on first use).  The image equals the reference ALGORITHM's image ray for ray: every
+ *       event total and every fixed-point pixel sum of the six full BASELINE frames equals the literal CPU restatement's.
+ *   RT_FLAG_REFERENCE_WALK: every ray walks the reference's own tree as Bvh::traverse does (bvh.cuh:221-357).  Same image as
+ *       the default, five times slower: the cross-check of the default, kept for that.
+ *   RT_FLAG_WATERTIGHT: the triangle-list definition instead -- an accepted hit is never lost to a box test, ties go to the
+ *       larger caller index: what exhaustive search over all triangles returns.  About 1 path in 4 * 10^6 differs from the
+ *       reference's image (on BASELINE config 5 those paths carry whole light deposits: RMS 3.2e-4); 3 - 4 % faster.
+ *
+ * CAVEAT ("the reference" = its algorithm in separately rounded fp32): this library and the CPU oracle are built with
+ * -ffp-contract=off, so inv * bound + scaled_origin is a multiplication and an addition.  The reference's CMake build uses
+ * nvcc's defaults (fmad on): a CUDA binary contracts that expression -- and others -- into FMAs and loses a DIFFERENT handful
+ * of rays; its libdevice sincosf / powf differ from the pinned forms here as well.  Bit parity with a CUDA binary is unpinned
+ * and cannot be had offline; what is exact is parity with the literal restatement of the source. */
+#define RT_FLAG_REFERENCE_WALK 8u /* every ray through the reference's own tree (see above); not with RT_FLAG_RNG_PER_SAMPLE */
+#define RT_FLAG_WATERTIGHT 16u    /* the triangle-list definition of the hits (see above); not with RT_FLAG_REFERENCE_WALK */
 
 /* ---- scene -------------------------------------------------------------------------------
  * Replaces: Triangle(p0,p1,p2) x n (triangle.cuh:6-7), cudaMalloc/Memcpy of triangles,
@@ -196,9 +206,9 @@ int rt_trace_closest(const rt_scene *scene, int n, const float *origin_xyz, cons
 /* Any hit excluding one triangle (bvh.cuh:306-357; ah(), render.cuh:278-294): occluded[i] in {0,1}. */
 int rt_trace_any(const rt_scene *scene, int n, const float *origin_xyz, const float *dir_xyz,
                  const float *tmax, const int32_t *excluded_tri, int32_t *occluded);
-/* The same two entry points with a flags word: RT_FLAG_REFERENCE_WALK sends the rays through the reference's own
- * tree and walk (see the flag) -- hit_tri, t, u, v and occluded are then the reference's answers, ties and lost
- * hits included.  flags = 0 is rt_trace_closest / rt_trace_any. */
+/* The same two entry points with a flags word (RT_FLAG_REFERENCE_WALK / RT_FLAG_WATERTIGHT: see the flags).  flags = 0 is
+ * rt_trace_closest / rt_trace_any: hit_tri, t, u, v and occluded are the reference's answers, ties and lost hits included.
+ * Directions are unit vectors (finite, every component below 2^126 in magnitude). */
 int rt_trace_closest_flags(const rt_scene *scene, uint32_t flags, int n, const float *origin_xyz, const float *dir_xyz,
                            const float *tmax, int32_t *hit_tri, float *t, float *u, float *v);
 int rt_trace_any_flags(const rt_scene *scene, uint32_t flags, int n, const float *origin_xyz, const float *dir_xyz,
