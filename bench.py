@@ -143,6 +143,7 @@ class Config:
         self.local_sum = self.fb_fixed if deterministic else self.fb
         self.last = {}
         self.rng_init_s = None
+        self.ref_tree_s = None
 
     def render_local(self):
         e = self.env
@@ -162,6 +163,7 @@ class Config:
         self.last = st
         if self.rng_init_s is None:
             self.rng_init_s = round(st["seconds_rng_init"], 6)  # (first frame: later frames reuse the cached states)
+            self.ref_tree_s = round(st["seconds_reference_tree"], 4)  # (first frame: the reference's own tree, built once per scene)
         return st
 
     def timed(self, steps, warmup, per_sample):
@@ -243,11 +245,13 @@ def main():
     head = Config(env, arrays, w, h, spp, args.max_bounces,
                   base_flags | (api.FLAG_RNG_PER_SAMPLE if per_sample_headline else 0), args.deterministic)
     one_off = {"scene_recipe_s": round(t_recipe, 4), "scene_create_s": round(head.scene_create_s, 4), "rng_init_s": None,
-               "note": "outside the timed region (SURVEY 8d): PLY parse + scene recipe, BVH build + upload, one-off XORWOW state init"}
+               "note": "outside the timed region (SURVEY 8d): PLY parse + scene recipe, BVH build + upload, one-off XORWOW state init, "
+                       "the reference's own tree (first frame, inside the warm-up)"}
 
     # ---- the headline: warm-up outside, then K timed steps between barrier + synchronize, MAX over ranks (the driver's contract)
     elapsed, agg, fail_msg = head.timed(args.steps, args.warmup, per_sample_headline)
     one_off["rng_init_s"] = head.rng_init_s
+    one_off["reference_tree_s"] = head.ref_tree_s  # host: the reference's binary SAH tree (bvh.cuh:30-219) for the rare re-traces + leaf boxes
     any_failed = rtdist.agree_on_failure(bool(fail_msg))
     if any_failed:  # every rank exits, together and non-zero; rank 0 still prints a line that says so
         if rank == 0:

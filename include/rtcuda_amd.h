@@ -72,7 +72,8 @@ typedef struct rt_stats {
     double seconds_trace;    /* trace kernel (closest-hit + any-hit rays of a round in one launch): average
                                 launch duration (HIP events on the launch stream, every 4th round sampled)
                                 x launches; 0 unless RT_FLAG_TIME_KERNELS */
-    double seconds_unused;
+    double seconds_reference_tree; /* host seconds this call spent building + uploading the reference's own tree (first render of
+                                      a scene without RT_FLAG_WATERTIGHT; 0 afterwards): a one-off like the BVH build */
     double seconds_advance;  /* same for the advance kernel */
     int64_t launches_trace;  /* launches of each stage kernel (= iterations) */
     int64_t reserved[7];     /* reserved[0] = launches actually sampled by the event timer;

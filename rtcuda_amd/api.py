@@ -47,7 +47,7 @@ class RtStats(ctypes.Structure):
         ("any_rays", ctypes.c_int64), ("emission_adds", ctypes.c_int64), ("shadow_adds", ctypes.c_int64),
         ("rr_draws", ctypes.c_int64), ("iterations", ctypes.c_int64), ("bvh_nodes", ctypes.c_int64),
         ("bvh_depth", ctypes.c_int64), ("seconds_render", ctypes.c_double), ("seconds_rng_init", ctypes.c_double),
-        ("seconds_trace", ctypes.c_double), ("seconds_unused", ctypes.c_double), ("seconds_advance", ctypes.c_double),
+        ("seconds_trace", ctypes.c_double), ("seconds_reference_tree", ctypes.c_double), ("seconds_advance", ctypes.c_double),
         ("launches_trace", ctypes.c_int64), ("reserved", ctypes.c_int64 * 7),
     ]
 

@@ -68,6 +68,7 @@ struct WalkResult {
     bool occluded = false;  // any hit
     long long nodes = 0, tris = 0, leaves = 0;
     int max_sp = 0;
+    long long sp_hist[32] = {0};  // node steps by the stack size the lane has when it makes them (>= 31 in the last bin)
     bool failed = false;
     bool unseen_occluder = false;  // verified any-hit walks: the occluder found is invisible to the reference's walk
     float tie_t = -1.f;     // closest: the distance of the last EXACT tie between two accepted hits (a tie at the final t
@@ -155,6 +156,7 @@ WalkResult walk_ray(const std::vector<rtbvh::Pair> &rec, bool wide, const std::v
         if (++steps > 1000000) { w.failed = true; break; }
         if (cur >= 0) {
             w.nodes++;
+            w.sp_hist[sp < 31 ? sp : 31]++;
             const float *boxes[4];
             int links[4];
             int nk = 0;
@@ -380,6 +382,14 @@ void *rt_hostwalk_create(const float *verts, int n) {
 void rt_hostwalk_destroy(void *h) { delete (HostWalk *)h; }
 // work counters of the walks since the last reset: [0] rays [1] node steps [2] triangle tests [3] leaves visited
 static long long g_walk_stats[4] = {0, 0, 0, 0};
+static long long g_sp_hist[32] = {0};
+// node steps of the walks since the last reset, by stack size at the step (what an LDS stack of a given depth would hold)
+void rt_hostwalk_sp_hist(long long *out32, int reset) {
+    for (int k = 0; k < 32; k++) {
+        out32[k] = g_sp_hist[k];
+        if (reset) g_sp_hist[k] = 0;
+    }
+}
 void rt_hostwalk_stats(long long *out4, int reset) {
     for (int k = 0; k < 4; k++) {
         out4[k] = g_walk_stats[k];
@@ -403,6 +413,8 @@ int rt_hostwalk_trace(void *h, int mode, int n_rays, const float *o3, const floa
         WalkResult res = walk_ray(rec, w.wide, w.tris, r.order, stack_entries, mode, o, d, tmax_in[i], excl);
         failures += res.failed ? 1 : 0;
         st_nodes += res.nodes; st_tris += res.tris; st_leaves += res.leaves;
+#pragma omp critical
+        for (int k = 0; k < 32; k++) g_sp_hist[k] += res.sp_hist[k];
         if (mode == 1) {
             out_i[i] = res.occluded ? 1 : 0;
         } else {

@@ -3034,7 +3034,12 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
     if (dev != scene->device) return fail("rt_render_shard: scene was created on another device");
-    if ((literal || verify) && ensure_ref_tree(scene)) return 1;
+    double ref_tree_seconds = 0.0;
+    if (literal || verify) {
+        const bool was_ready = scene->ref_ready;
+        if (ensure_ref_tree(scene)) return 1;
+        if (!was_ready) ref_tree_seconds = scene->build_seconds_ref;  // (this call paid for it)
+    }
     const int n = per_sample ? kW : kW / shard_count;
     const int slot_lo = per_sample ? 0 : shard_index * n;
     Context *cp = nullptr;
@@ -3460,7 +3465,7 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
         // sampled every kTimeStride-th round; scaled to all rounds (average launch duration x launches)
         double scale_up = n_sampled > 0 ? (double)rounds / (double)n_sampled : 0.0;
         stats->seconds_trace = t_ch * 1e-3 * scale_up;
-        stats->seconds_unused = 0.0;
+        stats->seconds_reference_tree = ref_tree_seconds;
         (void)t_ah;
         stats->seconds_advance = t_adv * 1e-3 * scale_up;
         stats->launches_trace = rounds;
@@ -3529,6 +3534,7 @@ int render_overlapped(const rt_scene *scene, const rt_camera *camera, int width,
             tot.seconds_advance += sub[k].seconds_advance;
             tot.seconds_render = std::max(tot.seconds_render, sub[k].seconds_render);
             tot.seconds_rng_init = std::max(tot.seconds_rng_init, sub[k].seconds_rng_init);
+            tot.seconds_reference_tree = std::max(tot.seconds_reference_tree, sub[k].seconds_reference_tree);
             tot.reserved[0] += sub[k].reserved[0];
             tot.reserved[2] = std::max(tot.reserved[2], sub[k].reserved[2]);
             for (int q = 4; q < 7; q++) tot.reserved[q] += sub[k].reserved[q];
@@ -4009,6 +4015,7 @@ int rt_render_multi(const rt_scene *scene, const rt_camera *camera, int width, i
             tot.seconds_advance = std::max(tot.seconds_advance, sub[k].seconds_advance);
             tot.seconds_render = std::max(tot.seconds_render, sub[k].seconds_render);  // the devices render side by side
             tot.seconds_rng_init = std::max(tot.seconds_rng_init, sub[k].seconds_rng_init);
+            tot.seconds_reference_tree = std::max(tot.seconds_reference_tree, sub[k].seconds_reference_tree);
             for (int q = 4; q < 7; q++) tot.reserved[q] += sub[k].reserved[q];
         }
         tot.reserved[3] = n_devices;
