@@ -513,7 +513,7 @@ int rt_split_probe(const rt_scene *scene, const rt_camera *camera, int width, in
     const bool lds_tables = scene->n_mats <= kLdsTable && scene->n_lights <= kLdsTable;
     const int stack_cap = lds_stack_cap(scene, kLdsStack);
     const size_t lds_bytes = sizeof(int) * (size_t)kBlock * (size_t)(stack_cap + 2);
-    if (ensure_overflow(c.d_over, c.over_levels, scene->stack_bound - std::min(stack_cap, lds_stack_cap(scene, 8)))) return 1;
+    if (ensure_overflow(c.d_over, c.over_levels, scene->stack_bound - std::min(stack_cap, lds_stack_cap(scene, kPathsLdsStack)))) return 1;
     int occ_c = 0;
     if (scene->wide) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_c, k_trace<MODE_POOL, true>, kBlock, lds_bytes));
     else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_c, k_trace<MODE_POOL, false>, kBlock, lds_bytes));

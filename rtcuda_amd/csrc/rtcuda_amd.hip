@@ -84,7 +84,9 @@ using rtbvh::knob;  // (experiment knobs are read only under RTCUDA_EXPERIMENTAL
 constexpr int kW = RT_NUM_WORKING_PATHS;
 constexpr uint32_t kFlagFixedFb = 0x200u;  // internal: d_sum points to int64 fixed-point sums
 constexpr int kBlock = 256;       // 4 waves per workgroup
-constexpr int kLdsStack = 16;          // traversal stack entries kept in LDS per lane
+constexpr int kLdsStack = 16;          // traversal stack entries kept in LDS per lane (k_trace)
+constexpr int kPathsLdsStack = 10;     // ... by k_paths: 10 + 1 + 26 rows = 37 KB per workgroup, four workgroups per CU; with 10 the
+                                       // step without overflow handling (inner_step<WIDE, SHALLOW>) serves 95 % of the node steps
 constexpr int kOverStride = 1 << 20;   // lanes of the overflow stack (>= lanes of the largest grid that traverses)
 constexpr int kMaxStackBound = 160;    // deepest traversal stack a scene may need (3 per level + 1)
 constexpr int kLockChunk = 16;         // lockstep rounds of the final generation enqueued between two looks at the stop rule's counters
@@ -893,11 +895,15 @@ __device__ __forceinline__ int leaf_ref(int first, int count) { return ~((first 
 // continue with the nearest one that the ray may enter, push the others (far first).
 // `top` / `top_n`: the first top_n records (the top of the tree, breadth-first: rt_bvh.h) may be staged
 // in LDS by the caller; nullptr / 0 otherwise.
-template <bool WIDE>
+// SHALLOW (4-wide nodes, k_paths): the caller has established -- with one wave vote -- that every lane taking this step has at
+// most stack_cap - 3 entries, so neither the pop nor the up to three pushes of the step can leave the LDS part of the stack:
+// no clamps, no overflow branches (each of which costs the wave an exec-mask save / restore pair and a jump whether or not a
+// lane takes it; the general step has four such rare regions).  95 % of the node steps of C2 qualify at stack_cap = 10.
+template <bool WIDE, bool SHALLOW = false>
 __device__ __forceinline__ void inner_step(const DScene &sc, V3 o, V3 inv, float tmax, int &cur, int &sp, int *stack,
                                            int *over, int stack_cap, const float4 *top = nullptr, int top_n = 0) {
     // (2-wide records) the top of the LDS part of the stack, in case this step ends in a pop: see below
-    const int spec_top = stack[max(min(sp - 1, stack_cap - 1), 0) * kBlock];
+    const int spec_top = SHALLOW ? stack[max(sp - 1, 0) * kBlock] : stack[max(min(sp - 1, stack_cap - 1), 0) * kBlock];
     float4 q0, q1, q2, q3, r0, r1, r2, r3;  // (r*: the second record of a 4-wide node)
     if (top_n > 0 && cur < top_n) {
         const float4 *q = top + 4 * cur;
@@ -1015,14 +1021,24 @@ __device__ __forceinline__ void inner_step(const DScene &sc, V3 o, V3 inv, float
         int spec = spec_top;
         __asm__ volatile("" : "+v"(spec));  // the read stays where it was issued: the compiler otherwise sinks it into a branch
         int popped = sp > 0 ? spec : kEntryDone;
-        if (!any_hit && sp > stack_cap) {
+        if (!SHALLOW && !any_hit && sp > stack_cap) {
             popped = over[(size_t)(sp - 1 - stack_cap) * kOverStride];
             __asm__ volatile("" ::: "memory");
         }
         cur = any_hit ? near_link : popped;
         sp -= (!any_hit && sp > 0) ? 1 : 0;
-        push_if4(stack, over, sp, stack_cap, c0, h[0] && near_k != 0, c1, h[1] && near_k != 1, c2, h[2] && near_k != 2, c3,
-                 h[3] && near_k != 3);
+        if (SHALLOW) {  // (every value is stored one above the running top; the top moves only if the push is meant)
+            const bool p0 = h[0] && near_k != 0, p1 = h[1] && near_k != 1, p2 = h[2] && near_k != 2, p3 = h[3] && near_k != 3;
+            const int s0 = sp, s1 = s0 + (p0 ? 1 : 0), s2 = s1 + (p1 ? 1 : 0), s3 = s2 + (p2 ? 1 : 0);
+            stack[s0 * kBlock] = c0;
+            stack[s1 * kBlock] = c1;
+            stack[s2 * kBlock] = c2;
+            stack[s3 * kBlock] = c3;
+            sp = s3 + (p3 ? 1 : 0);
+        } else {
+            push_if4(stack, over, sp, stack_cap, c0, h[0] && near_k != 0, c1, h[1] && near_k != 1, c2, h[2] && near_k != 2, c3,
+                     h[3] && near_k != 3);
+        }
     }
 }
 
@@ -2040,12 +2056,33 @@ k_paths(DScene sc, DPools p, Camera cam_arg, AdvanceParams ap_arg, float *__rest
             } else if (want) {
                 // a bounded while-while: up to kNodePerStep consecutive node steps (2 triangle tests in the
                 // triangle block) per scheduling decision -- measured best at 8 / 2 (+22 % over 1 / 1; 4 / 2: +20 %)
-                auto step = [&]() {
+                auto step_general = [&]() {
                     if (cur >= 0) {
                         inner_step<WIDE>(sc, o, inv, tmax, cur, sp, stack, over, stack_cap, s_top, top_n);
                     } else if (kSpeculate && cur != kEntryDone && pend == kEntryDone && sp > 0) {
                         pend = cur;  // a leaf: set it aside, go on with the next entry
                         cur = stack_pop(stack, over, sp, stack_cap);
+                    }
+                };
+                // 4-wide nodes on the full pool: ONE wave vote per step decides between the step without any overflow
+                // handling (all lanes of the block hold at most stack_cap - 3 entries: 95 % of the steps) and the general one
+                auto step = [&]() {
+#ifdef RT_NO_SHALLOW
+                    if (true) {
+#else
+                    if (!WIDE || MIN_WAVES == 2) {
+#endif
+                        step_general();
+                    } else if (wave_ballot(sp > stack_cap - 3) == 0ull) {
+                        if (cur >= 0) {
+                            inner_step<WIDE, true>(sc, o, inv, tmax, cur, sp, stack, over, stack_cap);
+                        } else if (kSpeculate && cur != kEntryDone && pend == kEntryDone && sp > 0) {
+                            pend = cur;
+                            sp--;
+                            cur = stack[sp * kBlock];
+                        }
+                    } else {
+                        step_general();
                     }
                 };
                 if (kNodeCont == 0 || !WIDE) {
@@ -2097,6 +2134,8 @@ k_paths(DScene sc, DPools p, Camera cam_arg, AdvanceParams ap_arg, float *__rest
                     const bool more = ((~enc) & 7) > 1;
                     const int rest = more ? enc - 7 : kEntryDone;  // one triangle further: first + 1, count - 1
                     int popped = kEntryDone;
+                    // (the same wave vote as in the node step -- no lane has entries in the overflow part -- measured here: +1 %
+                    // SLOWER, it undoes the node step's gain: profiles/r05_experiments.md)
                     if (act[j] && !fp && !more && sp > 0) popped = stack_pop(stack, over, sp, stack_cap);
                     pd = (act[j] && fp) ? rest : pd;
                     cu = (act[j] && !fp) ? (more ? rest : popped) : cu;
@@ -3067,7 +3106,7 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
     // entries in LDS, so it needs the deeper overflow
     // (the literal walk of the reference's tree -- depth <= 30 -- borrows the lane's stack: reference_walk)
     const int stack_need = std::max(scene->stack_bound, (literal || verify) ? 32 : 0);
-    if (ensure_overflow(c.d_over, c.over_levels, stack_need - std::min(stack_cap, lds_stack_cap(scene, 8)))) return 1;
+    if (ensure_overflow(c.d_over, c.over_levels, stack_need - std::min(stack_cap, lds_stack_cap(scene, kPathsLdsStack)))) return 1;
     int *const d_over = c.d_over;
     // Slots of this shard that ever get a camera ray: slot s serves the camera rays s, s + W, ..., so in a frame of fewer than
     // W camera rays the slots from cam_end on never do anything -- the kernels of such a frame (it is nothing but the
@@ -3169,7 +3208,7 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
     float ms_paths = 0.f;
     int top_records_in_lds = 0;
     if (persistent) {
-        const int paths_cap = lds_stack_cap(scene, 8);
+        const int paths_cap = lds_stack_cap(scene, kPathsLdsStack);
         int *const d_over2 = d_over;
         size_t lds_paths = sizeof(int) * (size_t)kBlock * (size_t)(paths_cap + 26) + (lds_tables ? sizeof(float) * (size_t)((scene->tab_dwords + 3) & ~3) : 0) +
                            sizeof(Camera) + sizeof(AdvanceParams);
