@@ -2153,12 +2153,14 @@ k_paths(DScene sc, DPools p, Camera cam_arg, AdvanceParams ap_arg, float *__rest
                         occluded = hit && is_any && ks[j] != tri;
                         occ_j = occluded ? j : occ_j;
                         bool better = hit && !is_any;
-                        if (better && t == tmax && tri >= 0) {
+                        if (VERIFY) {
+                            // an exact tie is the reference's tree order to decide: the ray is re-traced literally in the ADV block
+                            // (the mark is the sign bit of hv; v >= 0 for an accepted hit), so which of the two stays until then
+                            // does not matter -- no branch, no look at the caller order
+                            const bool tie = better && t == tmax && tri >= 0;
+                            v = __uint_as_float(__float_as_uint(v) | (tie ? 0x80000000u : 0u));
+                        } else if (better && t == tmax && tri >= 0) {  // (RT_FLAG_WATERTIGHT: ties go to the larger caller index)
                             better = sc.order[(unsigned)ks[j]] > sc.order[(unsigned)tri];
-                            if (VERIFY) {  // an exact tie: whichever of the two stays, its hv carries the mark (see the ADV block)
-                                v = __uint_as_float(__float_as_uint(v) | 0x80000000u);
-                                hv = __uint_as_float(__float_as_uint(hv) | 0x80000000u);
-                            }
                         }
                         tmax = better ? t : tmax;
                         hu = occluded ? 1.f : (better ? u : hu);

@@ -193,7 +193,8 @@ def test_render_matches_oracle_matte(api, oracle, gpu_matte, cpu_matte, w, h, sp
     (32, 24, 8, 0, 1),      # no bounce at all: emission only
     (32, 24, 8, 1, 1),
     (32, 24, 8, 2, 1),
-    (24, 16, 8, 20, 1),     # Russian roulette over 20 lockstep rounds
+    (24, 16, 8, 20, 1),     # Russian roulette over 20 lockstep rounds (two chunks of 16 enqueued rounds)
+    (24, 16, 8, 100, 1),    # 102 possible rounds: seven chunks, the host looks at the stop rule's counter between them
 ])
 def test_render_edge_configurations_match_oracle(api, oracle, gpu_full, cpu_full, w, h, spp, max_bounces, seed):
     """Sizes, sample counts, bounce limits and seeds through the lockstep pipeline (final-generation schedule, the
