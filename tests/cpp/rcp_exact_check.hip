@@ -4,8 +4,10 @@
 // needs 1 / d exactly as the reference computes it (an IEEE division, aabb_intersector.cuh:17-19).  The product uses
 // v_rcp_f32 + one FMA Newton step there (rcp_exact_normal<1>); v_rcp_f32 is a hardware approximation, so the only proof of "same bits" is to
 // try every operand the call site can see: the reference clamps |d| to >= FLT_EPSILON and d is a unit vector's component,
-// so FLT_EPSILON <= |x| <= 1 -- scanned far wider, 2^-24 <= |x| < 2^126 (2 x 1.26 G bit patterns), so that the stage-level
-// entry points may be given any finite direction a caller could reasonably pass.
+// so FLT_EPSILON <= |x| <= 1 -- scanned far wider: EVERY normal fp32 with |x| < 2^126 (biased exponents 1 .. 252, 2 x 2.1 G bit
+// patterns), so that the stage-level entry points may be given any finite direction a caller could reasonably pass.  (Beyond
+// that range both forms fail: for |x| >= 2^126 the quotient is denormal, and zero / denormal / inf / NaN operands need the
+// special-case handling of the compiler's expansion.)
 // Built with the product's flags (-ffp-contract=off -fno-fast-math) by tests/test_gpu_parity.py; prints
 //   steps1_mismatches steps2_mismatches patterns first_bad_bits_steps2
 // and exits 0 iff neither form ever differs from the compiler's IEEE division.
@@ -37,7 +39,7 @@ __global__ void k_scan(uint32_t lo, uint32_t hi, unsigned long long *out) {
 }
 
 int main() {
-    const uint32_t lo = 0x33800000u /* 2^-24 */, hi = 0x7e7fffffu /* just below 2^126 */;
+    const uint32_t lo = 0x00800000u /* 2^-126, the smallest normal */, hi = 0x7e7fffffu /* just below 2^126 */;
     unsigned long long *d = nullptr, h[3] = {0, 0, ~0ull};
     if (hipMalloc((void **)&d, sizeof(h)) != hipSuccess) return 2;
     if (hipMemcpy(d, h, sizeof(h), hipMemcpyHostToDevice) != hipSuccess) return 2;
