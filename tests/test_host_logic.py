@@ -329,6 +329,37 @@ def test_reference_tree_of_the_product_is_the_oracles_node_for_node(oracle, vari
     assert (bounds.shape[0], prims.shape[0], depth) == expect  # "BVH has N nodes and M primitives, with max_depth = D"
 
 
+@pytest.mark.parametrize("variant", ["matte", "sixteen_lights", "four_bunnies"])
+def test_reference_tree_boxes_are_nested_exactly(variant):
+    """The premise of the default kernels' visibility test (rtcuda_amd.hip: ref_visible): along every
+    root-to-leaf path of the reference's tree the boxes are NESTED EXACTLY -- a child's bounds lie inside its parent's with no
+    rounding in between (both are min / max of the same fp32 triangle bounds: bvh.cuh:57-61,150-160) -- and every leaf's box
+    contains the own box of each of its triangles as triangle.cuh:22-37 computes it from the stored record (p1 = p0 - e1,
+    p2 = p0 + e2).  With fp32 rounding monotone, that is all "the leaf's box passes => every ancestor's passes" needs."""
+    from rtcuda_amd import scenes
+    arrays = scenes.cornell_bunny(variant)
+    bounds, count, link, prims, _ = _ref_tree(_hostcheck(), arrays.tris)
+    inner = np.where(count == 0)[0]
+    for child in (link[inner], link[inner] + 1):
+        assert (bounds[child][:, 0::2] >= bounds[inner][:, 0::2]).all()   # mins
+        assert (bounds[child][:, 1::2] <= bounds[inner][:, 1::2]).all()   # maxs
+    t = np.ascontiguousarray(arrays.tris, np.float32).reshape(-1, 3, 3)
+    p0 = t[:, 0]
+    e1, e2 = p0 - t[:, 1], t[:, 2] - p0
+    p1, p2 = p0 - e1, p0 + e2                                              # the reference's reconstructions, fp32
+    lo = np.minimum(p0, np.minimum(p1, p2))
+    hi = np.maximum(p0, np.maximum(p1, p2))
+    leaves = np.where(count > 0)[0]
+    seen = np.zeros(len(t), bool)
+    for k in leaves:
+        idx = prims[link[k]:link[k] + count[k]]
+        seen[idx] = True
+        assert (lo[idx] >= bounds[k][0::2]).all() and (hi[idx] <= bounds[k][1::2]).all(), k
+        # ... and is exactly their union
+        assert np.array_equal(lo[idx].min(axis=0), bounds[k][0::2]) and np.array_equal(hi[idx].max(axis=0), bounds[k][1::2])
+    assert seen.all()
+
+
 @pytest.mark.parametrize("n", [0, 1, 2, 3, 7, 200])
 def test_reference_tree_tiny_and_coincident(oracle, n):
     """Small and degenerate inputs (equal centres: the order std::sort leaves among equal keys is part of the tree)."""

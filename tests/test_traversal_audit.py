@@ -228,3 +228,33 @@ def test_verified_walk_on_rays_chosen_to_break_it(oracle, bunny_matte, walk_matt
     excl = rng.integers(-1, bunny_matte.n_tris, len(o)).astype(np.int32)
     occ, _ = walk_matte.any_verified(o, d, tm, excl)
     assert np.array_equal(occ, sc.trace_any(o, d, tm, excl))
+
+
+def test_slab_term_is_monotone_in_the_bound():
+    """The second premise of ref_visible: an fp32 slab term inv * bound + scaled_origin -- two roundings, as the reference
+    computes it (aabb_intersector.cuh:25-33) -- is a monotone function of the bound (non-decreasing for inv > 0, non-increasing
+    for inv < 0), because each rounding is.  Not a proof (rounding to nearest is monotone by definition), a tripwire: 4 * 10^6
+    random (inv, origin, bound, bound') with bounds as close as neighbouring floats, magnitudes from 1e-7 to 8e6."""
+    rng = np.random.default_rng(2025)
+    n = 4_000_000
+    f = np.float32
+    inv = (rng.choice([-1.0, 1.0], n) * np.exp(rng.uniform(np.log(1e-1), np.log(8.4e6), n))).astype(f)
+    o = rng.uniform(-2, 2, n).astype(f)
+    so = (-o * inv).astype(f)
+    b1 = rng.uniform(-2, 2, n).astype(f)
+    steps = rng.integers(0, 4, n)
+    b2 = b1.copy()
+    for _ in range(3):
+        b2 = np.where(steps > 0, np.nextafter(b2, f(np.inf)), b2)
+        steps = steps - 1
+    far = rng.random(n) < 0.3
+    b2 = np.where(far, np.maximum(b1, rng.uniform(-2, 2, n).astype(f)), b2)
+    assert (b2 >= b1).all()
+    t1 = ((inv * b1).astype(f) + so).astype(f)
+    t2 = ((inv * b2).astype(f) + so).astype(f)
+    pos = inv > 0
+    assert (t2[pos] >= t1[pos]).all() and (t2[~pos] <= t1[~pos]).all()
+    # the FMA form a CUDA build would use (one rounding) is monotone as well: the same argument covers it
+    u1 = (inv.astype(np.float64) * b1 + so).astype(f)
+    u2 = (inv.astype(np.float64) * b2 + so).astype(f)
+    assert (u2[pos] >= u1[pos]).all() and (u2[~pos] <= u1[~pos]).all()
