@@ -1177,12 +1177,12 @@ __device__ inline void reference_walk(const DScene &sc, V3 o, V3 d, float &tmax,
 //     1 / copysign(eps, -0.0) is negative): the nesting argument does not hold then and the ancestors are tested one by
 //     one through the parent links.
 // So the default kernels keep their own tree, node format, speculation and scheduling and still return the reference's
-// answers: a shadow ray's accepted hit only counts if its triangle is visible (k_paths / k_trace: `ref_visible` where
-// `occluded` is about to be set), and a finished path ray's closest hit T is checked once, in the block that shades it
-// anyway: T visible and no exact tie at the final distance  =>  T is the reference's closest hit (T is the nearest
-// accepted triangle of ALL, so also of the visible ones).  The rest -- T invisible (the nearest VISIBLE hit is needed)
-// or a tie (the reference's test order decides) -- is ~2 rays in 10^7 and is re-traced by reference_walk behind a
-// rare branch.  tests/test_traversal_audit.py replays > 4 * 10^7 rays of literal oracle renders through the CPU twin of
+// answers: a shadow ray's accepted hit only counts if its triangle is visible (k_trace: the walk goes on past an unseen
+// occluder; k_paths: the ray ends at its first occluder, and if the reference cannot see that one -- ~1 in 10^7 -- the
+// literal walk decides), and a finished path ray's closest hit T is checked once, in the block that shades it anyway: T
+// visible and no exact tie at the final distance  =>  T is the reference's closest hit (T is the nearest accepted triangle
+// of ALL, so also of the visible ones).  The rest -- T invisible (the nearest VISIBLE hit is needed) or a tie (the
+// reference's test order decides) -- is ~2 rays in 10^7 and is re-traced by reference_walk behind a rare branch.  tests/test_traversal_audit.py replays > 4 * 10^7 rays of literal oracle renders through the CPU twin of
 // exactly this procedure (rt_host_check.cpp): equal on every ray; the GPU suite holds whole frames to the LITERAL
 // oracle's fixed-point image bit for bit.
 __device__ __forceinline__ bool neg_zero3(V3 d) {
@@ -2888,16 +2888,20 @@ std::vector<std::unique_ptr<Context>> g_contexts;
 
 // Device buffers of the calls that take HOST output (rt_render, rt_render_multi): raw sums, staging, the post-processed image.
 // Kept per (device, slot) and reused from call to call -- a hipMalloc / hipFree pair per frame cost ~0.3 ms and a device
-// synchronisation each (round 4 allocated them per call); released by rt_shutdown.  One call at a time uses them (g_out_busy).
+// synchronisation each (round 4 allocated them per call); released by rt_shutdown.  The buffers of ONE device serve one call at
+// a time (g_dev_busy[device]); calls on different devices -- one host thread per GPU -- do not wait for each other.
 struct OutBuffer {
     int device = -1, slot = 0;
     void *ptr = nullptr;
     size_t bytes = 0;
 };
-std::mutex g_out_busy;
+constexpr int kMaxDevices = 64;
+std::mutex g_dev_busy[kMaxDevices];
+std::mutex g_out_mutex;  // the list below
 std::vector<OutBuffer> g_out_buffers;
-// (caller holds g_out_busy; the current device must be `device`)
+// (caller holds g_dev_busy[device]; the current device must be `device`)
 void *out_buffer(int device, int slot, size_t bytes) {
+    std::lock_guard<std::mutex> list_lock(g_out_mutex);
     for (OutBuffer &b : g_out_buffers)
         if (b.device == device && b.slot == slot) {
             if (b.bytes >= bytes) return b.ptr;
@@ -3248,6 +3252,10 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
             top_n = scene->top_prefix ? std::min(scene->wide ? 0 : 384, prefix) : 0;
             if (const char *e = knob("RT_TOP_NODES")) top_n = scene->top_prefix ? std::max(0, std::min(std::min(768, atoi(e)), prefix)) : 0;
             if (scene->wide) top_n &= ~1;  // whole nodes
+            // (never more than the 64 KB of dynamic LDS a launch gets without further ado: scenes with many materials / lights
+            // have larger tables)
+            const size_t room = lds_paths < 65536 ? (65536 - lds_paths) / 64 : 0;
+            top_n = (int)std::min<size_t>((size_t)top_n, room) & (scene->wide ? ~1 : ~0);
             lds_paths += (size_t)top_n * 64;
             top_records_in_lds = top_n;
         }
@@ -3854,7 +3862,8 @@ int rt_render(const rt_scene *scene, const rt_camera *camera, int width, int hei
     const size_t bytes = sizeof(float) * n_values;
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
-    std::lock_guard<std::mutex> out_lock(g_out_busy);  // (the cached device buffers serve one host-output call at a time)
+    if (dev < 0 || dev >= kMaxDevices) return fail("rt_render: device ordinal out of range");
+    std::lock_guard<std::mutex> out_lock(g_dev_busy[dev]);  // (this device's cached buffers serve one host-output call at a time)
     float *d_fb = (float *)out_buffer(dev, 0, bytes);
     long long *d_fixed = fixed ? (long long *)out_buffer(dev, 1, sizeof(long long) * n_values) : nullptr;
     if (!d_fb || (fixed && !d_fixed)) return fail("rt_render: out of device memory");
@@ -3889,7 +3898,7 @@ void rt_shutdown(void) {
         g_contexts.clear();  // (~Context frees on the context's own device)
     }
     {
-        std::lock_guard<std::mutex> out_lock(g_out_busy);
+        std::lock_guard<std::mutex> list_lock(g_out_mutex);
         for (OutBuffer &b : g_out_buffers) {
             if (hipSetDevice(b.device) == hipSuccess) (void)hipFree(b.ptr);
         }
@@ -3947,7 +3956,12 @@ int rt_render_multi(const rt_scene *scene, const rt_camera *camera, int width, i
     }
     // device buffers: cached per (device, slot) like rt_render's; slot 2 + 2k = shard k's sums on its device, 3 + 2k = its
     // staging copy on devices[0], slot 1 = the post-processed image (fixed-point mode)
-    std::lock_guard<std::mutex> out_lock(g_out_busy);
+    std::vector<int> distinct(devices, devices + n_devices);
+    std::sort(distinct.begin(), distinct.end());
+    distinct.erase(std::unique(distinct.begin(), distinct.end()), distinct.end());
+    if (distinct.back() >= kMaxDevices) return fail("rt_render_multi: device ordinal out of range");
+    std::vector<std::unique_lock<std::mutex>> out_locks;  // (ascending device order: two concurrent calls cannot deadlock)
+    for (int d : distinct) out_locks.emplace_back(g_dev_busy[d]);
     struct Home {  // the calling thread's device is restored on every return path
         int device;
         ~Home() { (void)hipSetDevice(device); }
