@@ -911,11 +911,13 @@ __device__ __forceinline__ void inner_step(const DScene &sc, V3 o, V3 inv, float
         q1 = q[1];
         q2 = q[2];
         q3 = q[3];
-        if (WIDE) {
+        if (WIDE) {  // (the links of children 2, 3 ride in the spare half of q3: seven 16-byte loads per node, not eight)
             r0 = q[4];
             r1 = q[5];
             r2 = q[6];
+#ifdef RT_NODE_8_LOADS  // (A/B build: the links of children 2, 3 from the second record, as until round 5)
             r3 = q[7];
+#endif
         }
         // keeps the two branches apart: merged into a select of pointers they become FLAT loads, which go
         // through the texture addresser like any global load and make the LDS copy pointless
@@ -926,11 +928,13 @@ __device__ __forceinline__ void inner_step(const DScene &sc, V3 o, V3 inv, float
         q1 = q[1];
         q2 = q[2];
         q3 = q[3];
-        if (WIDE) {
+        if (WIDE) {  // (the links of children 2, 3 ride in the spare half of q3: seven 16-byte loads per node, not eight)
             r0 = q[4];
             r1 = q[5];
             r2 = q[6];
+#ifdef RT_NODE_8_LOADS  // (A/B build: the links of children 2, 3 from the second record, as until round 5)
             r3 = q[7];
+#endif
         }
     }
     if (!WIDE) {
@@ -978,7 +982,12 @@ __device__ __forceinline__ void inner_step(const DScene &sc, V3 o, V3 inv, float
         // dependent fetches of the 2-wide walk for the same box arithmetic.  The nearest child the ray may enter becomes
         // the cursor, the others go onto the stack in record order (measured on the CPU walk: sorting them as well
         // saves 0.3 % of the steps), nothing entered -> the speculative top of the stack.
+        #ifdef RT_NODE_8_LOADS
         const int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y), c2 = __float_as_int(r3.x), c3 = __float_as_int(r3.y);
+#else
+        (void)r3;
+        const int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y), c2 = __float_as_int(q3.z), c3 = __float_as_int(q3.w);
+#endif
         const v2f ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z};
         const v2f ix = {inv.x, inv.x}, iy = {inv.y, inv.y}, iz = {inv.z, inv.z};
         // (clamped to a finite value: an absent child has an all-+inf box -- rt_bvh.h -- whose entry distance is +inf or
@@ -3729,6 +3738,14 @@ int rt_scene_create(const float *tri_p0p1p2, int n_tris, const int32_t *tri_mate
                 memcpy(&r[13], &pr.rlink, 4);
                 r[14] = r[15] = 0.f;
             }
+            // 4-wide: the links of children 2, 3 (second record) ALSO in the spare words of the first, so that a node step
+            // loads seven 16-byte words instead of eight (a divergent wave-wide load occupies the CU's texture addresser
+            // for about a cycle per active lane: profiles/r05_gather_rate.txt)
+            if (sc->wide)
+                for (size_t k = 0; k + 1 < recs.size(); k += 2) {
+                    inter[16 * k + 14] = inter[16 * (k + 1) + 12];
+                    inter[16 * k + 15] = inter[16 * (k + 1) + 13];
+                }
             src = inter.data();
         }
         HIP_TRY(hipMalloc((void **)&sc->d_nodes, 64 * (size_t)sc->n_nodes));
