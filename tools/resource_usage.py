@@ -11,7 +11,7 @@ KEYS = {"TotalSGPRs": "sgpr", "VGPRs": "vgpr", "VGPRs Spill": "spill", "ScratchS
 
 
 def main():
-    out = subprocess.run(["make", "-C", CSRC, "resource-usage"], capture_output=True, text=True)
+    out = subprocess.run(["make", "-C", CSRC, "resource-usage"] + (["DEFS=" + os.environ["DEFS"]] if os.environ.get("DEFS") else []), capture_output=True, text=True)
     text = out.stdout + out.stderr
     cur = None
     rows = []
