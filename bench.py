@@ -623,6 +623,16 @@ def main():
                 roof["lane_utilisation"] = round(lane_util, 4)
                 roof["valu_wave_instructions_per_launch"] = pmc["SQ_INSTS_VALU"]
                 roof["valu_issue_frac"] = round(pmc["SQ_INSTS_VALU"] * 64.0 / avg_s / VALU_PEAK_LANE_OPS, 4)
+                # the second bound: the CU's texture addresser takes a load whose lanes read different records apart lane by
+                # lane (~1 cycle per active lane: profiles/r05_gather_rate.txt); busy share of the kernel's cycles from the PMC pass
+                if pmc.get("SQ_INSTS_VMEM"):
+                    roof["vmem"] = {"wave_instructions_per_launch": pmc["SQ_INSTS_VMEM"],
+                                    "per_ray": round(pmc["SQ_INSTS_VMEM"] * 64.0 / max(c_per + a_per, 1.0), 1),
+                                    "ta_busy_frac": round(pmc["ta_busy_frac"], 4) if pmc.get("ta_busy_frac") else None,
+                                    "ta_busy_max_frac": round(pmc["ta_busy_max_frac"], 4) if pmc.get("ta_busy_max_frac") else None,
+                                    "note": "vector-memory wave-instructions (x 64 / rays = lane slots per ray, idle lanes included); TA_BUSY_avr / "
+                                            "TA_BUSY_max over the kernel's cycles -- a saturated gather microbenchmark reads 0.84 / 0.96 "
+                                            "(tools/lab/gather_rate.hip)"}
                 roof["active_lane_ops_per_ray"] = round(lane_ops / max(c_per + a_per, 1.0), 1)
                 roof["traffic"] = pmc.get("hbm_bytes_per_launch")
                 if roof["traffic"]:

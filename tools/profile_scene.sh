@@ -17,8 +17,10 @@ timeout -k 10 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv 
 timeout -k 10 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/pmc_write -- python3 $P > $O/pmc_write.log 2>&1
 timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_LDS GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_sq1 -- python3 $P > $O/pmc_sq1.log 2>&1
 timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS --output-format csv -d $O/pmc_sq2 -- python3 $P > $O/pmc_sq2.log 2>&1
+# the texture addresser (vector-memory path): busy cycles, averaged over the units and of the busiest one (own pass)
+timeout -k 10 200 rocprofv3 --kernel-trace --pmc TA_TA_BUSY_sum TA_BUSY_avr TA_BUSY_max --output-format csv -d $O/pmc_ta -- python3 $P > $O/pmc_ta.log 2>&1
 echo "$SCENE pmc done"
-python3 tools/pmc_summary.py $O/pmc_fetch $O/pmc_write $O/pmc_sq1 $O/pmc_sq2 > $O/pmc_summary.json
+python3 tools/pmc_summary.py $O/pmc_fetch $O/pmc_write $O/pmc_sq1 $O/pmc_sq2 $O/pmc_ta > $O/pmc_summary.json
 find $O/stats -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/kernel_stats.csv
 head -4 $O/kernel_stats.csv
-rm -rf $O/stats $O/pmc_fetch $O/pmc_write $O/pmc_sq1 $O/pmc_sq2   # raw traces are large; the summaries are what is kept
+rm -rf $O/stats $O/pmc_fetch $O/pmc_write $O/pmc_sq1 $O/pmc_sq2 $O/pmc_ta   # raw traces are large; the summaries are what is kept

@@ -51,13 +51,19 @@ for scene in ("full_bsdf", "four_bunnies", "sixteen_lights", "matte"):
              "note": f"rocprofv3 --pmc passes of `bench.py --scene {scene} --spp 256 --steps 1 --warmup 0 --no-cpu-baseline "
                      f"--no-kernel-timing` (tools/profile_scene.sh; profiles/{tag}_{scene}_pmc.json); HBM bytes = (2*FETCH_SIZE + "
                      "WRITE_SIZE) KB per MI355X_MICROARCH.md (gfx950 FETCH_SIZE counts half of streaming reads)"}
+    if "TA_BUSY_avr" in c:  # (texture addresser: busy cycles per unit, mean and maximum over the units, in kernel cycles)
+        entry["TA_BUSY_avr"] = c["TA_BUSY_avr"]
+        entry["TA_BUSY_max"] = c.get("TA_BUSY_max")
+        entry["ta_busy_frac"] = c["TA_BUSY_avr"] / gui
+        entry["ta_busy_max_frac"] = c.get("TA_BUSY_max", 0.0) / gui
     table[f"{scene}_1920x1080x256_n1"] = entry
     lane_util = c["SQ_THREAD_CYCLES_VALU"] / (64 * c["SQ_ACTIVE_INST_VALU"])
     print("%-15s %.1f ms | VALU wave-instr %.4g | lane util %.1f %% | issue %.1f %% of 1 per 2 clk per SIMD | active lane-ops %.4g | "
-          "HBM %.1f GB | L2 hit %.1f %% | wait_any %.0f %% wait_inst %.0f %% of wave cycles" % (
+          "HBM %.1f GB | L2 hit %.1f %% | wait_any %.0f %% wait_inst %.0f %% of wave cycles | VMEM wave-instr %.4g | TA busy %s" % (
               scene, gui / 2.4e6, c["SQ_INSTS_VALU"], 100 * lane_util, 100 * 2 * c["SQ_INSTS_VALU"] / (1024 * gui),
               c["SQ_INSTS_VALU"] * 64 * lane_util, entry["hbm_bytes_per_launch"] / 1e9, 100 * entry["l2_hit_rate"],
-              100 * c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], 100 * c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"]))
+              100 * c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], 100 * c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"], c["SQ_INSTS_VMEM"],
+              ("%.0f %% (max %.0f %%)" % (100 * entry["ta_busy_frac"], 100 * entry["ta_busy_max_frac"])) if "ta_busy_frac" in entry else "n/a"))
 # one rank's shard of a 2-, 4-, 8-GPU run (tools/refresh_profiles.sh: shard_breakdown.py R under the SQ counter passes; no
 # FETCH / WRITE pass, so no HBM traffic): the entries an N-GPU bench line prices rank 0's k_paths with
 for R in (2, 4, 8):
