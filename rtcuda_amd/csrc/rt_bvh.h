@@ -135,6 +135,42 @@ inline float pad_up(float v, int k) {
     return v;
 }
 
+// ---- padding of the 4-wide records for the kernels' one-fma plane distance
+// The 4-wide node step computes the distance to a plane b of axis a as ONE fused multiply-add, b * (1 / d_a) + s_a with
+// s_a = -o_a * (1 / d_a) rounded on its own (half the vector instructions of (b - o_a) * (1 / d_a) for the 24 planes of a
+// node).  The rounding of s_a moves EVERY plane of that axis, seen from the ray, by up to 2^-24 |o_a| in world units -- half an
+// ulp of the ORIGIN's coordinate, whatever 1 / d_a is.  (The rounding of the fma itself and of 1 / d are relative to the
+// distance and are covered, as before, by the widened exit distance of the test.)  So the records the kernels read are the
+// 2-ulp-padded ones pushed outward by another 2^-23 R_a, where R_a bounds |o_a| over every ray that will be traced:
+// origins of secondary rays lie on the scene's triangles (offset by at most 256 ulps: offset_ray_origin), the camera and
+// the rays of the test hooks are looked at by the caller, who re-pads for a larger radius when one comes along.
+inline void quads_abs_bounds(const std::vector<Pair> &quads, float m[3]) {
+    m[0] = m[1] = m[2] = 0.f;
+    for (const Pair &p : quads)
+        for (int side = 0; side < 2; side++) {
+            if ((side ? p.rlink : p.llink) == kNoChild) continue;
+            const float *b = side ? p.rbox : p.lbox;
+            for (int a = 0; a < 3; a++) {
+                if (std::isfinite(b[a])) m[a] = std::max(m[a], std::fabs(b[a]));
+                if (std::isfinite(b[3 + a])) m[a] = std::max(m[a], std::fabs(b[3 + a]));
+            }
+        }
+    for (int a = 0; a < 3; a++) m[a] = m[a] * 1.001f;  // (256 ulps of offset and to spare)
+}
+inline void pad_quads_for_origins(const std::vector<Pair> &base, const float radius[3], std::vector<Pair> &out) {
+    out = base;
+    for (Pair &p : out)
+        for (int side = 0; side < 2; side++) {
+            if ((side ? p.rlink : p.llink) == kNoChild) continue;  // (all-+inf boxes: stay as they are)
+            float *b = side ? p.rbox : p.lbox;
+            for (int a = 0; a < 3; a++) {
+                const double pad = std::ldexp((double)radius[a], -23);
+                if (std::isfinite(b[a])) b[a] = pad_down((float)((double)b[a] - pad), 1);         // (the conversion rounds to nearest: one ulp further)
+                if (std::isfinite(b[3 + a])) b[3 + a] = pad_up((float)((double)b[3 + a] + pad), 1);
+            }
+        }
+}
+
 // ---- step 1: binary SAH tree
 inline void build_binary(const float *verts, int n, std::vector<BinNode> &bin, std::vector<int32_t> &order,
                          int &bin_depth, int &num_leaves) {

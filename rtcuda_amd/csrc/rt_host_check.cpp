@@ -48,6 +48,19 @@ inline bool box_hit(V3 o, V3 inv, const float *lo, const float *hi, float tmax, 
     t_out = t_out * 1.000001f;
     return t_in <= t_out && t_out >= 0.f && t_in <= tmax * 1.000001f;
 }
+// The 4-wide node step of the kernels: plane distance as ONE fma, b * (1 / d) + s with s = -o * (1 / d) rounded on its own
+// (inner_step<true> in rtcuda_amd.hip); the records it is given are padded for that (rt_bvh.h, pad_quads_for_origins)
+inline bool box_hit_fma(V3 o, V3 inv, const float *lo, const float *hi, float tmax, float &entry) {
+    const float sx = -o.x * inv.x, sy = -o.y * inv.y, sz = -o.z * inv.z;
+    float ax = fmaf(lo[0], inv.x, sx), bx = fmaf(hi[0], inv.x, sx);
+    float ay = fmaf(lo[1], inv.y, sy), by = fmaf(hi[1], inv.y, sy);
+    float az = fmaf(lo[2], inv.z, sz), bz = fmaf(hi[2], inv.z, sz);
+    float t_in = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+    float t_out = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+    entry = t_in;
+    t_out = t_out * 1.000001f;
+    return fmaxf(t_in, 0.f) <= fminf(t_out, fminf(tmax * 1.000001f, FLT_MAX));
+}
 inline V3 inv_dir(V3 d) {
     auto clampinv = [](float x) { return 1.f / ((fabsf(x) < FLT_EPSILON) ? copysignf(FLT_EPSILON, x) : x); };
     return V3{clampinv(d.x), clampinv(d.y), clampinv(d.z)};
@@ -167,7 +180,9 @@ WalkResult walk_ray(const std::vector<rtbvh::Pair> &rec, bool wide, const std::v
             }
             float e[4];
             bool h[4];
-            for (int k = 0; k < nk; k++) h[k] = box_hit(o, inv, boxes[k], boxes[k] + 3, tmax, e[k]) && links[k] != rtbvh::kNoChild;
+            for (int k = 0; k < nk; k++)
+                h[k] = (wide ? box_hit_fma(o, inv, boxes[k], boxes[k] + 3, tmax, e[k]) : box_hit(o, inv, boxes[k], boxes[k] + 3, tmax, e[k])) &&
+                       links[k] != rtbvh::kNoChild;
             int near_k = -1;
             for (int k = 0; k < nk; k++)  // nearest entered child; ties: the lower index (as the kernels' !(a > b) selects)
                 if (h[k] && (near_k < 0 || e[k] < e[near_k])) near_k = k;
@@ -211,6 +226,21 @@ WalkResult walk_ray(const std::vector<rtbvh::Pair> &rec, bool wide, const std::v
     return w;
 }
 
+// The 4-wide records as the kernels are given them: padded for the origins of the rays at hand (the scene's own bounds, and
+// whatever lies farther out in this batch -- ensure_origin_radius in rtcuda_amd.hip does the same per render / per call)
+std::vector<rtbvh::Pair> padded_quads(const rtbvh::Result &r, int n_rays, const float *o3) {
+    float radius[3];
+    rtbvh::quads_abs_bounds(r.quads, radius);
+    for (int i = 0; i < n_rays; i++)
+        for (int a = 0; a < 3; a++) {
+            const float v = o3[3 * (size_t)i + a];
+            if (std::isfinite(v) && std::fabs(v) * 1.001f > radius[a]) radius[a] = 2.f * std::fabs(v) * 1.001f;
+        }
+    if (rtbvh::knob("RT_NO_ORIGIN_PAD")) radius[0] = radius[1] = radius[2] = 0.f;  // (tests: shows what the padding is for)
+    std::vector<rtbvh::Pair> out;
+    rtbvh::pad_quads_for_origins(r.quads, radius, out);
+    return out;
+}
 // structural validation of one record format: returns the number of errors
 int64_t validate(const rtbvh::Result &r, const std::vector<rtbvh::Pair> &rec, bool wide, const float *verts, int n, int &max_leaf) {
     const int per_node = wide ? 2 : 1;
@@ -271,6 +301,29 @@ int rt_bvh_selfcheck(const float *verts, int n, int n_rays, const float *o3, con
     if (r.quads.size() != 2 * r.nodes.size()) errors++;
     if (n > 0) {
         errors += validate(r, r.quads, true, verts, n, max_leaf);
+        {   // the records as the kernels are given them (padded for the origins of this call's rays): the same structure, and
+            // every plane at least 2^-24 x radius farther out than the builder's -- what the one-fma plane distance needs
+            float radius[3];
+            rtbvh::quads_abs_bounds(r.quads, radius);
+            for (int i = 0; i < n_rays; i++)
+                for (int a = 0; a < 3; a++)
+                    if (std::isfinite(o3[3 * (size_t)i + a])) radius[a] = std::max(radius[a], std::fabs(o3[3 * (size_t)i + a]));
+            const std::vector<rtbvh::Pair> padded = padded_quads(r, n_rays, o3);
+            int ml = 0;
+            errors += validate(r, padded, true, verts, n, ml);
+            if (padded.size() != r.quads.size()) errors++;
+            else if (!rtbvh::knob("RT_NO_ORIGIN_PAD"))
+                for (size_t k = 0; k < padded.size(); k++)
+                    for (int side = 0; side < 2; side++) {
+                        if ((side ? padded[k].rlink : padded[k].llink) != (side ? r.quads[k].rlink : r.quads[k].llink)) errors++;
+                        if ((side ? padded[k].rlink : padded[k].llink) == rtbvh::kNoChild) continue;
+                        const float *pb = side ? padded[k].rbox : padded[k].lbox, *bb = side ? r.quads[k].rbox : r.quads[k].lbox;
+                        for (int a = 0; a < 3; a++) {
+                            const double need = std::ldexp((double)radius[a], -24);
+                            if (!((double)bb[a] - (double)pb[a] >= need) || !((double)pb[3 + a] - (double)bb[3 + a] >= need)) errors++;
+                        }
+                    }
+        }
         if (r.pairs.size() > 1 || r.pairs[0].llink != rtbvh::kNoChild) errors += validate(r, r.pairs, false, verts, n, max_leaf);
     }
     out10[3] = max_leaf;
@@ -278,8 +331,9 @@ int rt_bvh_selfcheck(const float *verts, int n, int n_rays, const float *o3, con
     if (errors) return 0;
     // CPU walks with the kernels' control flow vs exhaustive search, both formats
     const std::vector<Tri> tris = leaf_order_triangles(verts, r, n);
-    int64_t mism = 0, max_stack = 0, max_steps = 0;
+    int64_t mism = 0, max_stack = 0, max_steps = 0, mism_fmt[2] = {0, 0};
     double sum_nodes[2] = {0, 0}, sum_tris[2] = {0, 0};
+    const std::vector<rtbvh::Pair> wide_recs = padded_quads(r, n_rays, o3);  // (as the kernels are given them)
     for (int i = 0; i < n_rays; i++) {
         V3 o{o3[3 * i], o3[3 * i + 1], o3[3 * i + 2]}, d{d3[3 * i], d3[3 * i + 1], d3[3 * i + 2]};
         float bt = FLT_MAX, t;
@@ -288,15 +342,17 @@ int rt_bvh_selfcheck(const float *verts, int n, int n_rays, const float *o3, con
             if (tri_hit(tris[k], o, d, bt, t) && (!(t == bt && bb >= 0) || r.order[k] > r.order[bb])) { bt = t; bb = k; }
         for (int fmt = 0; fmt < 2; fmt++) {
             const bool wide = fmt == 0;
-            WalkResult w = walk_ray(wide ? r.quads : r.pairs, wide, tris, r.order, wide ? r.stack_bound : r.pair_depth + 1, 0, o, d, FLT_MAX, -1);
+            WalkResult w = walk_ray(wide ? wide_recs : r.pairs, wide, tris, r.order, wide ? r.stack_bound : r.pair_depth + 1, 0, o, d, FLT_MAX, -1);
             if (w.failed) { mism += 1000000; continue; }
-            if (w.best != bb || (bb >= 0 && w.t != bt)) mism++;
+            if (w.best != bb || (bb >= 0 && w.t != bt)) { mism++; mism_fmt[fmt]++; }
             if (wide) { max_stack = std::max<int64_t>(max_stack, w.max_sp); max_steps = std::max<int64_t>(max_steps, w.nodes); }
             sum_nodes[fmt] += (double)w.nodes;
             sum_tris[fmt] += (double)w.tris;
         }
     }
     out10[5] = mism; out10[6] = max_stack; out10[7] = max_steps;
+    if (getenv("RT_BVH_STATS") && n_rays > 0)
+        fprintf(stderr, "bvh walk mismatches: 4-wide %lld, 2-wide %lld\n", (long long)mism_fmt[0], (long long)mism_fmt[1]);
     if (getenv("RT_BVH_STATS") && n_rays > 0)
         fprintf(stderr, "bvh walk per ray: 4-wide %.2f nodes %.2f tris | 2-wide %.2f nodes %.2f tris | %zu quads records, %zu pairs, depths %d / %d\n",
                 sum_nodes[0] / n_rays, sum_tris[0] / n_rays, sum_nodes[1] / n_rays, sum_tris[1] / n_rays, r.quads.size(), r.pairs.size(), r.max_depth, r.pair_depth);
@@ -402,7 +458,8 @@ int rt_hostwalk_trace(void *h, int mode, int n_rays, const float *o3, const floa
                       int *out_i, float *out_t) {
     const HostWalk &w = *(const HostWalk *)h;
     const rtbvh::Result &r = w.r;
-    const std::vector<rtbvh::Pair> &rec = w.wide ? r.quads : r.pairs;
+    const std::vector<rtbvh::Pair> padded = w.wide ? padded_quads(r, n_rays, o3) : std::vector<rtbvh::Pair>();
+    const std::vector<rtbvh::Pair> &rec = w.wide ? padded : r.pairs;
     const int stack_entries = w.wide ? r.stack_bound : r.pair_depth + 1;
     int failures = 0;
     long long st_nodes = 0, st_tris = 0, st_leaves = 0;
@@ -441,7 +498,8 @@ int rt_hostwalk_trace_verified(void *h, int mode, int n_rays, const float *o3, c
                                const int *excluded, int *out_i, float *out_t, long long *stats6) {
     const HostWalk &w = *(const HostWalk *)h;
     const rtbvh::Result &r = w.r;
-    const std::vector<rtbvh::Pair> &rec = w.wide ? r.quads : r.pairs;
+    const std::vector<rtbvh::Pair> padded = w.wide ? padded_quads(r, n_rays, o3) : std::vector<rtbvh::Pair>();
+    const std::vector<rtbvh::Pair> &rec = w.wide ? padded : r.pairs;
     const int stack_entries = w.wide ? r.stack_bound : r.pair_depth + 1;
     int failures = 0;
     long long own = 0, leafb = 0, ties = 0, negz = 0, lit = 0;

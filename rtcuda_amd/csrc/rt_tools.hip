@@ -465,6 +465,7 @@ int rt_split_probe(const rt_scene *scene, const rt_camera *camera, int width, in
     int dev = 0, cus = 0;
     HIP_TRY(hipGetDevice(&dev));
     if (dev != scene->device) return fail("rt_split_probe: scene was created on another device");
+    if (int rc = ensure_origin_radius(scene, camera->lookfrom)) return rc;
     HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     for (int k = 0; k < n_out; k++) out[k] = 0.0;
     const int n = kW;

@@ -997,9 +997,15 @@ __device__ __forceinline__ void inner_step(const DScene &sc, V3 o, V3 inv, float
         bool h[4];
         // entered <=> entry <= exit, exit >= 0, entry <= tmax: max(entry, 0) <= min(exit, tmax) -- one comparison per child
         // instead of three and their scalar ANDs (tmax >= 0 always)
+        // plane distance = b * (1 / d) + s, s = -o * (1 / d): ONE packed fma per pair of planes where (b - o) * (1 / d) takes
+        // two instructions.  s is rounded on its own, which moves the planes of an axis by up to 2^-24 |o| as the ray sees
+        // them: the records are padded for that (rt_bvh.h, pad_quads_for_origins; ensure_origin_radius on the host)
+        const v2f sx = {-o.x * inv.x, -o.x * inv.x}, sy = {-o.y * inv.y, -o.y * inv.y}, sz = {-o.z * inv.z, -o.z * inv.z};
+        (void)ox; (void)oy; (void)oz;
+#define RT_SLAB(b, i, s_) __builtin_elementwise_fma((b), (i), (s_))
         {
-            v2f ax = (v2f{q0.x, q0.y} - ox) * ix, ay = (v2f{q0.z, q0.w} - oy) * iy, az = (v2f{q1.x, q1.y} - oz) * iz;
-            v2f bx = (v2f{q1.z, q1.w} - ox) * ix, by = (v2f{q2.x, q2.y} - oy) * iy, bz = (v2f{q2.z, q2.w} - oz) * iz;
+            v2f ax = RT_SLAB((v2f{q0.x, q0.y}), ix, sx), ay = RT_SLAB((v2f{q0.z, q0.w}), iy, sy), az = RT_SLAB((v2f{q1.x, q1.y}), iz, sz);
+            v2f bx = RT_SLAB((v2f{q1.z, q1.w}), ix, sx), by = RT_SLAB((v2f{q2.x, q2.y}), iy, sy), bz = RT_SLAB((v2f{q2.z, q2.w}), iz, sz);
             e[0] = fmaxf(fmaxf(fminf(ax.x, bx.x), fminf(ay.x, by.x)), fminf(az.x, bz.x));
             e[1] = fmaxf(fmaxf(fminf(ax.y, bx.y), fminf(ay.y, by.y)), fminf(az.y, bz.y));
             v2f t_out = {fminf(fminf(fmaxf(ax.x, bx.x), fmaxf(ay.x, by.x)), fmaxf(az.x, bz.x)),
@@ -1009,8 +1015,8 @@ __device__ __forceinline__ void inner_step(const DScene &sc, V3 o, V3 inv, float
             h[1] = fmaxf(e[1], 0.f) <= fminf(t_out.y, tmax_w);
         }
         {
-            v2f ax = (v2f{r0.x, r0.y} - ox) * ix, ay = (v2f{r0.z, r0.w} - oy) * iy, az = (v2f{r1.x, r1.y} - oz) * iz;
-            v2f bx = (v2f{r1.z, r1.w} - ox) * ix, by = (v2f{r2.x, r2.y} - oy) * iy, bz = (v2f{r2.z, r2.w} - oz) * iz;
+            v2f ax = RT_SLAB((v2f{r0.x, r0.y}), ix, sx), ay = RT_SLAB((v2f{r0.z, r0.w}), iy, sy), az = RT_SLAB((v2f{r1.x, r1.y}), iz, sz);
+            v2f bx = RT_SLAB((v2f{r1.z, r1.w}), ix, sx), by = RT_SLAB((v2f{r2.x, r2.y}), iy, sy), bz = RT_SLAB((v2f{r2.z, r2.w}), iz, sz);
             e[2] = fmaxf(fmaxf(fminf(ax.x, bx.x), fminf(ay.x, by.x)), fminf(az.x, bz.x));
             e[3] = fmaxf(fmaxf(fminf(ax.y, bx.y), fminf(ay.y, by.y)), fminf(az.y, bz.y));
             v2f t_out = {fminf(fminf(fmaxf(ax.x, bx.x), fmaxf(ay.x, by.x)), fmaxf(az.x, bz.x)),
@@ -1019,6 +1025,7 @@ __device__ __forceinline__ void inner_step(const DScene &sc, V3 o, V3 inv, float
             h[2] = fmaxf(e[2], 0.f) <= fminf(t_out.x, tmax_w);
             h[3] = fmaxf(e[3], 0.f) <= fminf(t_out.y, tmax_w);
         }
+#undef RT_SLAB
         // nearest entered child (a child that is not entered counts as infinitely far)
         const float f0 = h[0] ? e[0] : kFltMax, f1 = h[1] ? e[1] : kFltMax, f2 = h[2] ? e[2] : kFltMax, f3 = h[3] ? e[3] : kFltMax;
         const bool a01 = !(f0 > f1), a23 = !(f2 > f3);       // winner of each record (ties: the lower index)
@@ -2488,6 +2495,11 @@ struct rt_scene {
     int n_tris = 0, n_nodes = 0, max_depth = 0, stack_bound = 1, n_leaves = 0, n_lights = 0, n_mats = 0;
     float4 *d_nodes = nullptr;
     bool wide = false;  // node records: 4-wide (two pair-style records per node, rtbvh::Result::quads) or 2-wide (rtbvh::Pair)
+    // 4-wide records are padded for the ray origins that will be traced (rt_bvh.h, pad_quads_for_origins): the builder's
+    // records, the radius the device copy is padded for at the moment, and a lock for the (rare) re-padding
+    std::vector<rtbvh::Pair> h_quads;
+    mutable float origin_radius[3] = {0.f, 0.f, 0.f};
+    mutable std::mutex pad_mutex;
     bool top_prefix = true;  // the first records are the top of the tree in level order (host builder)
     double build_seconds = 0.0;  // BVH build time (host wall clock, or device events for the LBVH)
     int builder = 0;             // 0 host SAH, 1 device LBVH
@@ -2656,6 +2668,64 @@ bool validate_pairs(const std::vector<rtbvh::Pair> &pairs, int n_tris) {
 // The same for the 4-wide format (two consecutive records per node; inner links are even record indices), plus the
 // invariant the kernels' box test rests on: a child is absent (link kNoChild) if and only if its box is all +inf -- the
 // one-comparison slab test of inner_step<true> never looks at links.
+// Device layout of a 64-byte record: the two children's bounds INTERLEAVED --
+//   (l.lo.x, r.lo.x, l.lo.y, r.lo.y | l.lo.z, r.lo.z, l.hi.x, r.hi.x | l.hi.y, r.hi.y, l.hi.z, r.hi.z | llink, rlink, spare, spare)
+// -- so that every (left, right) pair of bounds arrives in an aligned register pair and the slab arithmetic of both children
+// runs as packed fp32, see inner_step.  4-wide: a node is two such records back to back (children 0, 1 | children 2, 3:
+// rt_bvh.h `quads`), padded for ray origins within `radius` (pad_quads_for_origins), and the links of children 2, 3 ride ALSO
+// in the spare words of the first record, so that a node step loads seven 16-byte words instead of eight (a divergent
+// wave-wide load occupies the CU's texture addresser for about a cycle per active lane: profiles/r05_gather_rate.txt).
+int upload_node_records(const rt_scene *sc, const std::vector<rtbvh::Pair> &base, const float radius[3]) {
+    std::vector<rtbvh::Pair> padded;
+    const std::vector<rtbvh::Pair> *recs = &base;
+    if (sc->wide) {
+        rtbvh::pad_quads_for_origins(base, radius, padded);
+        recs = &padded;
+    }
+    if ((size_t)sc->n_nodes != recs->size()) return fail("upload_node_records: record count changed");
+    std::vector<float> inter(16 * recs->size());
+    for (size_t k = 0; k < recs->size(); k++) {
+        const rtbvh::Pair &pr = (*recs)[k];
+        float *r = &inter[16 * k];
+        for (int a = 0; a < 6; a++) {
+            r[2 * a] = pr.lbox[a];
+            r[2 * a + 1] = pr.rbox[a];
+        }
+        memcpy(&r[12], &pr.llink, 4);
+        memcpy(&r[13], &pr.rlink, 4);
+        r[14] = r[15] = 0.f;
+    }
+    if (sc->wide)
+        for (size_t k = 0; k + 1 < recs->size(); k += 2) {
+            inter[16 * k + 14] = inter[16 * (k + 1) + 12];
+            inter[16 * k + 15] = inter[16 * (k + 1) + 13];
+        }
+    HIP_TRY(hipMemcpy(sc->d_nodes, inter.data(), 64 * (size_t)sc->n_nodes, hipMemcpyHostToDevice));
+    for (int a = 0; a < 3; a++) sc->origin_radius[a] = radius[a];
+    return 0;
+}
+// Before rays are traced whose origins may lie outside the radius the 4-wide records are padded for (a camera outside the
+// scene's bounds; the rays of the test hooks): re-pad, generously, and upload.  Renders of the same scene that are in flight
+// on other streams read a mix of the old and the new bounds meanwhile -- both are conservative for THEIR rays.
+int ensure_origin_radius(const rt_scene *sc, const float need[3]) {
+    if (!sc->wide) return 0;
+    std::lock_guard<std::mutex> lock(sc->pad_mutex);
+    bool grow = false;
+    float radius[3];
+    for (int a = 0; a < 3; a++) {
+        const float want = std::isfinite(need[a]) ? std::fabs(need[a]) * 1.001f : 0.f;  // (a non-finite origin hits nothing anyway)
+        grow = grow || want > sc->origin_radius[a];
+        radius[a] = want > sc->origin_radius[a] ? 2.f * want : sc->origin_radius[a];
+    }
+    if (!grow) return 0;
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev != sc->device) HIP_TRY(hipSetDevice(sc->device));
+    const int rc = upload_node_records(sc, sc->h_quads, radius);
+    if (dev != sc->device) HIP_TRY(hipSetDevice(dev));
+    return rc;
+}
+
 bool validate_quads(const std::vector<rtbvh::Pair> &quads, int n_tris) {
     const int nr = (int)quads.size();
     if (nr < 2 || (nr & 1)) return false;
@@ -3068,6 +3138,7 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
         return fail("rt_render_shard: shard_count must divide 1048576 and 0 <= shard_index < shard_count");
     if ((long long)width * height > (long long)(0x7fffffff / 3))  // framebuffer values are indexed with 32 bits
         return fail("rt_render_shard: width*height exceeds 715827882 pixels");
+    if (int rc = ensure_origin_radius(scene, camera->lookfrom)) return rc;  // (camera rays start at lookfrom: camera.cuh:22-26)
     // RT_FLAG_RNG_PER_SAMPLE: this rank renders the whole frame at num_samples / shard_count samples per pixel with ALL W
     // slots; camera ray `cid` of the rank has the global key cid * shard_count + shard_index, so the keys of a pixel's
     // samples are the same set whatever the shard count (see AdvanceParams)
@@ -3716,40 +3787,15 @@ int rt_scene_create(const float *tri_p0p1p2, int n_tris, const int32_t *tri_mate
     static_assert(sizeof(Light) == sizeof(rt_light), "light layout");
     static_assert(sizeof(Material) == sizeof(rt_material), "material layout");
     static_assert(sizeof(Camera) == sizeof(rt_camera), "camera layout");
-    {
-        // device layout of a 2-wide record: the two children's bounds INTERLEAVED --
-        //   (l.lo.x, r.lo.x, l.lo.y, r.lo.y | l.lo.z, r.lo.z, l.hi.x, r.hi.x | l.hi.y, r.hi.y, l.hi.z, r.hi.z | llink, rlink, 0, 0)
-        // -- so that every (left, right) pair of bounds arrives in an aligned register pair and the slab
-        // arithmetic of both children runs as packed fp32 (v_pk_add_f32 / v_pk_mul_f32), see inner_step
-        // (4-wide: a node is two such records back to back -- children 0, 1 and children 2, 3 -- rt_bvh.h `quads`)
-        std::vector<float> inter;
-        const std::vector<rtbvh::Pair> &recs = sc->wide ? bvh.quads : bvh.pairs;
-        const void *src = nullptr;
-        {
-            inter.resize(16 * recs.size());
-            for (size_t k = 0; k < recs.size(); k++) {
-                const rtbvh::Pair &pr = recs[k];
-                float *r = &inter[16 * k];
-                for (int a = 0; a < 6; a++) {
-                    r[2 * a] = pr.lbox[a];
-                    r[2 * a + 1] = pr.rbox[a];
-                }
-                memcpy(&r[12], &pr.llink, 4);
-                memcpy(&r[13], &pr.rlink, 4);
-                r[14] = r[15] = 0.f;
-            }
-            // 4-wide: the links of children 2, 3 (second record) ALSO in the spare words of the first, so that a node step
-            // loads seven 16-byte words instead of eight (a divergent wave-wide load occupies the CU's texture addresser
-            // for about a cycle per active lane: profiles/r05_gather_rate.txt)
-            if (sc->wide)
-                for (size_t k = 0; k + 1 < recs.size(); k += 2) {
-                    inter[16 * k + 14] = inter[16 * (k + 1) + 12];
-                    inter[16 * k + 15] = inter[16 * (k + 1) + 13];
-                }
-            src = inter.data();
-        }
-        HIP_TRY(hipMalloc((void **)&sc->d_nodes, 64 * (size_t)sc->n_nodes));
-        HIP_TRY(hipMemcpy(sc->d_nodes, src, 64 * (size_t)sc->n_nodes, hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc((void **)&sc->d_nodes, 64 * (size_t)sc->n_nodes));
+    if (sc->wide) {
+        sc->h_quads = bvh.quads;
+        float radius[3];
+        rtbvh::quads_abs_bounds(sc->h_quads, radius);
+        if (int rc = upload_node_records(sc.get(), sc->h_quads, radius)) return rc;
+    } else {
+        const float none[3] = {0.f, 0.f, 0.f};
+        if (int rc = upload_node_records(sc.get(), bvh.pairs, none)) return rc;
     }
     HIP_TRY(hipMalloc((void **)&sc->d_tris, sizeof(float) * trec.size()));
     HIP_TRY(hipMemcpy(sc->d_tris, trec.data(), sizeof(float) * trec.size(), hipMemcpyHostToDevice));
@@ -4118,6 +4164,13 @@ int rt_trace_closest_flags(const rt_scene *scene, uint32_t flags, int n, const f
     if (tmp.alloc(d_o, 3 * (size_t)n) || tmp.alloc(d_d, 3 * (size_t)n) || tmp.alloc(d_tm, (size_t)n) || tmp.alloc(d_t, (size_t)n) ||
         tmp.alloc(d_u, (size_t)n) || tmp.alloc(d_v, (size_t)n) || tmp.alloc(d_h, (size_t)n))
         return 1;
+    {
+        float need[3] = {0.f, 0.f, 0.f};  // the 4-wide records must be padded for these origins (ensure_origin_radius)
+        for (int i = 0; i < n; i++)
+            for (int a = 0; a < 3; a++)
+                if (std::isfinite(origin_xyz[3 * (size_t)i + a])) need[a] = std::max(need[a], std::fabs(origin_xyz[3 * (size_t)i + a]));
+        if (int rc = ensure_origin_radius(scene, need)) return rc;
+    }
     HIP_TRY(hipMemcpy(d_o, origin_xyz, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d_d, dir_xyz, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d_tm, tmax, sizeof(float) * (size_t)n, hipMemcpyHostToDevice));
@@ -4178,6 +4231,13 @@ int rt_trace_any_flags(const rt_scene *scene, uint32_t flags, int n, const float
     if (tmp.alloc(d_o, 3 * (size_t)n) || tmp.alloc(d_d, 3 * (size_t)n) || tmp.alloc(d_tm, (size_t)n) || tmp.alloc(d_e, (size_t)n) ||
         tmp.alloc(d_occ, (size_t)n))
         return 1;
+    {
+        float need[3] = {0.f, 0.f, 0.f};  // the 4-wide records must be padded for these origins (ensure_origin_radius)
+        for (int i = 0; i < n; i++)
+            for (int a = 0; a < 3; a++)
+                if (std::isfinite(origin_xyz[3 * (size_t)i + a])) need[a] = std::max(need[a], std::fabs(origin_xyz[3 * (size_t)i + a]));
+        if (int rc = ensure_origin_radius(scene, need)) return rc;
+    }
     HIP_TRY(hipMemcpy(d_o, origin_xyz, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d_d, dir_xyz, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d_tm, tmax, sizeof(float) * (size_t)n, hipMemcpyHostToDevice));

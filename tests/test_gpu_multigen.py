@@ -525,6 +525,41 @@ def test_deterministic_sums_equal_the_oracles_fixed_point_sums_bit_for_bit(api, 
     assert torch.equal(acc, got)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("lookfrom,vfov", [((0.5, 0.5, 40.0), 1.6), ((-30.0, 12.0, 25.0), 2.2)])
+def test_a_camera_far_outside_the_scene_re_pads_the_node_records_and_changes_nothing(api, oracle, lookfrom, vfov):
+    """The 4-wide node step's one-fma plane distance is exact enough only for ray origins the records are padded for
+    (rt_bvh.h, pad_quads_for_origins): a camera ~40 scene sizes away makes rt_render_shard re-pad and upload them
+    (ensure_origin_radius) -- on a scene object that renders from the usual camera before and after.  Every frame must be
+    the literal oracle's, bit for bit, and RT_FLAG_REFERENCE_WALK's."""
+    import torch
+    from conftest import usable_cpus
+    variant, w, h, spp = "full_bsdf", 320, 180, 24
+    gpu, _ = _scenes(api, oracle, variant)
+    osc = oracle_scene(oracle, variant, False)
+    near = api.make_camera(aspect=w / h)
+
+    def sums(cam, flags=0):
+        buf = torch.zeros(h * w * 3, dtype=torch.int64, device="cuda")
+        st = gpu.render_shard_fixed(cam, w, h, spp, 0, 1, buf.data_ptr(), flags=flags)
+        torch.cuda.synchronize()
+        return buf.cpu().numpy().reshape(h, w, 3), st
+
+    before, _ = sums(near)
+    far = api.make_camera(lookfrom=lookfrom, lookat=(0.5, 0.4, -0.5), vfov=vfov, aspect=w / h)
+    want = np.zeros((h, w, 3), np.int64)
+    ocam = oracle.camera(lookfrom, (0.5, 0.4, -0.5), (0.0, 1.0, 0.0), vfov, w / h)
+    _, _, st_c = osc.render(ocam, w, h, spp, threads=usable_cpus(), fixed_out=want)
+    got, st_g = sums(far)
+    _assert_same_events(st_g, st_c, w * h * spp)
+    assert st_c["sum_mat"] > 0.2 * w * h * spp  # (the frame looks at the scene)
+    assert np.array_equal(got, want), int((got != want).sum())
+    ref, _ = sums(far, api.FLAG_REFERENCE_WALK)
+    assert np.array_equal(ref, want)
+    after, _ = sums(near)  # the wider padding stays: still the same image from the usual camera
+    assert np.array_equal(after, before)
+
+
 def _full_size_hashes():
     import json
     here = os.path.dirname(os.path.abspath(__file__))

@@ -170,6 +170,30 @@ def test_product_bvh_structure_and_cpu_walk(oracle, bunny_matte):
     assert r["nodes"] < r["leaves"]  # 4-wide: fewer node records than leaves
 
 
+@pytest.mark.parametrize("scale", [3.0, 30.0])
+def test_product_walk_finds_every_hit_of_rays_that_start_far_outside_the_scene(bunny_matte, scale):
+    """The 4-wide node step computes a plane distance as ONE fma, b * (1 / d) - o * (1 / d); the rounding of o * (1 / d) moves
+    the planes of an axis by up to 2^-24 |o|, so the records are padded for the origins that are traced (rt_bvh.h,
+    pad_quads_for_origins; the selfcheck validates the padded records and their margins).  Rays from up to ~100 scene sizes
+    away, aimed at points near the vertices and edges of random triangles: both record formats find what exhaustive search
+    finds.  (From thousands of scene sizes away the fp32 triangle test itself is noisier than any box: not a regime the
+    reference's scenes have.)"""
+    L = _hostcheck()
+    tris = np.asarray(bunny_matte.tris, np.float32).reshape(-1, 9)[::16]
+    rng = np.random.default_rng(5)
+    n = 20000
+    tsel = tris[rng.integers(0, len(tris), n)].reshape(n, 3, 3)
+    w = rng.dirichlet([0.3, 0.3, 0.3], n).astype(np.float32)
+    target = (tsel * w[:, :, None]).sum(axis=1)
+    dirs = rng.normal(size=(n, 3))
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    ro = (target - dirs * scale * rng.uniform(0.3, 3.0, (n, 1))).astype(np.float32)
+    rd = target - ro.astype(np.float64)
+    rd = (rd / np.linalg.norm(rd, axis=1, keepdims=True)).astype(np.float32)
+    r = _selfcheck(L, tris, ro, rd)
+    assert r["errors"] == 0 and r["mismatch"] == 0
+
+
 @pytest.mark.parametrize("n", [0, 1, 2, 3, 5, 64])
 def test_product_bvh_tiny_and_degenerate(n):
     L = _hostcheck()
