@@ -180,7 +180,10 @@ int rt_render_multi(const rt_scene *scene, const rt_camera *camera, int width, i
  * rays c with c % W == s, so shards are disjoint and their raw sums add up to the 1-GPU image.
  * d_sum_rgb: DEVICE buffer of width*height*3 floats on the current device; contributions are
  * ADDED to it (zero it first).  stream: hipStream_t (NULL = default stream).  The call is
- * synchronous on that stream when it returns.  shard_count must divide W. */
+ * synchronous on that stream when it returns.  shard_count must divide W.
+ * (Every render entry point: the scene's BVH records are padded for ray origins within the scene's own bounds; the first
+ * render from a camera whose lookfrom lies outside them widens the padding and uploads the records again, once, a few
+ * milliseconds.  Thread-safe; the image does not depend on it.) */
 int rt_render_shard(const rt_scene *scene, const rt_camera *camera, int width, int height, int num_samples,
                     int max_bounces, uint64_t seed, int shard_index, int shard_count, uint32_t flags,
                     float *d_sum_rgb, void *stream, rt_stats *stats);

@@ -904,7 +904,7 @@ __device__ __forceinline__ void inner_step(const DScene &sc, V3 o, V3 inv, float
                                            int *over, int stack_cap, const float4 *top = nullptr, int top_n = 0) {
     // (2-wide records) the top of the LDS part of the stack, in case this step ends in a pop: see below
     const int spec_top = SHALLOW ? stack[max(sp - 1, 0) * kBlock] : stack[max(min(sp - 1, stack_cap - 1), 0) * kBlock];
-    float4 q0, q1, q2, q3, r0, r1, r2, r3;  // (r*: the second record of a 4-wide node)
+    float4 q0, q1, q2, q3, r0, r1, r2;  // (r*: the second record of a 4-wide node; its link word is not needed: see q3)
     if (top_n > 0 && cur < top_n) {
         const float4 *q = top + 4 * cur;
         q0 = q[0];
@@ -915,9 +915,6 @@ __device__ __forceinline__ void inner_step(const DScene &sc, V3 o, V3 inv, float
             r0 = q[4];
             r1 = q[5];
             r2 = q[6];
-#ifdef RT_NODE_8_LOADS  // (A/B build: the links of children 2, 3 from the second record, as until round 5)
-            r3 = q[7];
-#endif
         }
         // keeps the two branches apart: merged into a select of pointers they become FLAT loads, which go
         // through the texture addresser like any global load and make the LDS copy pointless
@@ -932,9 +929,6 @@ __device__ __forceinline__ void inner_step(const DScene &sc, V3 o, V3 inv, float
             r0 = q[4];
             r1 = q[5];
             r2 = q[6];
-#ifdef RT_NODE_8_LOADS  // (A/B build: the links of children 2, 3 from the second record, as until round 5)
-            r3 = q[7];
-#endif
         }
     }
     if (!WIDE) {
@@ -982,12 +976,7 @@ __device__ __forceinline__ void inner_step(const DScene &sc, V3 o, V3 inv, float
         // dependent fetches of the 2-wide walk for the same box arithmetic.  The nearest child the ray may enter becomes
         // the cursor, the others go onto the stack in record order (measured on the CPU walk: sorting them as well
         // saves 0.3 % of the steps), nothing entered -> the speculative top of the stack.
-        #ifdef RT_NODE_8_LOADS
-        const int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y), c2 = __float_as_int(r3.x), c3 = __float_as_int(r3.y);
-#else
-        (void)r3;
         const int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y), c2 = __float_as_int(q3.z), c3 = __float_as_int(q3.w);
-#endif
         const v2f ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z};
         const v2f ix = {inv.x, inv.x}, iy = {inv.y, inv.y}, iz = {inv.z, inv.z};
         // (clamped to a finite value: an absent child has an all-+inf box -- rt_bvh.h -- whose entry distance is +inf or
