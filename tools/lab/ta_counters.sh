@@ -1,6 +1,8 @@
 # usage (on the GPU box): bash tools/lab/ta_counters.sh <outdir>
 # Texture-addresser / vector-L1 counters of k_paths on the C2 frame and of the gather microbenchmark (tools/lab/gather_rate),
-# one small counter group per pass, only counters this rocprofv3 lists.  Lab, not product.
+# one small counter group per pass, only counters this rocprofv3 lists (a group the hardware cannot collect in one pass makes
+# rocprofv3 abort and then hang in its finalisation until the timeout: three TA stall counters together did).  Lab, not product.
+# The TA_BUSY pass is part of tools/profile_scene.sh since; this script is for looking further.
 set -e
 O=${1:-gpurun_out/ta}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
@@ -12,13 +14,9 @@ have() { grep -qx "$1" $O/avail_ta_tcp.txt; }
 P="bench.py --scene full_bsdf --spp 256 --no-cpu-baseline --no-extras --steps 1 --warmup 0 --no-kernel-timing"
 n=0
 for group in "TA_TA_BUSY_sum TA_BUSY_avr TA_BUSY_max" \
-             "TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TA_ADDR_STALLED_BY_TD_CYCLES_sum" \
-             "TA_BUFFER_WAVEFRONTS_sum TA_FLAT_WAVEFRONTS_sum TA_BUFFER_READ_WAVEFRONTS_sum TA_FLAT_READ_WAVEFRONTS_sum" \
-             "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_ACCESSES_sum" \
-             "TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_TA_TCP_STATE_READ_sum" \
-             "TCP_GATE_EN1_sum TCP_GATE_EN2_sum TCP_TD_TCP_STALL_CYCLES_sum" \
-             "TD_TD_BUSY_sum TD_TC_STALL_sum TD_LOAD_WAVEFRONT_sum" \
-             "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_FLAT SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
+             "TA_ADDR_STALLED_BY_TC_CYCLES_sum" "TA_DATA_STALLED_BY_TC_CYCLES_sum" \
+             "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum" \
+             "TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum"; do
   names=""
   for c in $group; do if have $c || echo $c | grep -q "^SQ_\|^GRBM"; then names="$names $c"; fi; done
   [ -z "$names" ] && continue
