@@ -89,6 +89,38 @@ def test_trace_closest_matches_oracle(api, oracle, gpu_matte, cpu_matte):
     _closest_compare(gpu_matte, cpu_matte, o3, d3, np.full(len(o3), FLT_MAX, np.float32))
 
 
+def test_rays_that_start_far_outside_the_scene_match_the_oracle(api, oracle, bunny_matte):
+    """The 4-wide records are padded for the ray origins that are traced (one-fma plane distance: rt_bvh.h); the hooks look at
+    the origins of a batch and re-pad when they lie outside (ensure_origin_radius).  Rays from 3 to 60 scene sizes away, aimed at
+    points near the vertices and edges of random triangles, on a scene object of its own (so that the padding starts at the
+    scene's bounds): triangle, t, u, v as the literal oracle has them, closest and any hit -- and the same rays again after
+    the widest batch."""
+    gpu = api.Scene(bunny_matte)
+    cpu = oracle.scene(bunny_matte)
+    tris = np.asarray(bunny_matte.tris, np.float32).reshape(-1, 3, 3)
+    rng = np.random.default_rng(31)
+    batches = []
+    for scale in (3.0, 20.0, 60.0, 3.0):
+        n = 60_000
+        tsel = tris[rng.integers(0, len(tris), n)]
+        w = rng.dirichlet([0.3, 0.3, 0.3], n).astype(np.float32)
+        target = (tsel * w[:, :, None]).sum(axis=1)
+        dirs = rng.normal(size=(n, 3))
+        dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+        o = (target - dirs * scale * rng.uniform(0.3, 3.0, (n, 1))).astype(np.float32)
+        d = target - o.astype(np.float64)
+        d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+        batches.append((o, d))
+    for o, d in batches:
+        tmax = np.full(len(o), FLT_MAX, np.float32)
+        g, c, _ = _closest_compare(gpu, cpu, o, d, tmax)
+        assert (c[0] >= 0).mean() > 0.5
+        tm = (0.999 * np.where(c[0] >= 0, c[1], 1.0)).astype(np.float32)  # shadow-ray style: up to just before the first hit
+        excl = np.full(len(o), -1, np.int32)
+        assert np.array_equal(gpu.trace_any(o, d, tm, excl), cpu.trace_any(o, d, tm, excl))
+    gpu.close()
+
+
 def test_trace_any_matches_oracle(api, oracle, gpu_matte, cpu_matte, bunny_matte):
     cam = default_camera(oracle, 1.0)
     o, d = raygen.camera_rays(cam, 512, 512, 100_000, seed=21)
