@@ -3341,7 +3341,9 @@ int render_shard_impl(const rt_scene *scene, const rt_camera *camera, int width,
         if (const char *e = knob("RT_GEN_BATCH")) gen_batch = std::max(1, std::min(64, atoi(e)));
         int tri_follow = 1;  // a triangle block right behind a node block when this many lanes hold a leaf by then; 0 = never
         if (const char *e = knob("RT_TRI_FOLLOW")) tri_follow = std::max(0, std::min(64, atoi(e)));
-        int prio_rotate = 8;  // log2 of the priority-rotation period in scheduling decisions; 0 = off
+        // log2 of the priority-rotation period in scheduling decisions; 0 = off (128 ms for C2's frame).  Full pool: 111.7 - 112.2 /
+        // 111.8 / 111.9 / 112.1 / 112.5 ms at 4 / 5 / 6 / 7 / 8 (late round 5; C3 -0.9 % at 4, C4 flat); 1/8 shards want 8 (+1 % at 4)
+        int prio_rotate = few_blocks ? 8 : 5;
         // period, in 64-slot blocks, after which slots repeat the same pixel-column lattice (see k_paths)
         int rot_wave = 0, rot_set = 0;
         {
