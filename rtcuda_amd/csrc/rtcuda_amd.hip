@@ -904,32 +904,54 @@ __device__ __forceinline__ void inner_step(const DScene &sc, V3 o, V3 inv, float
                                            int *over, int stack_cap, const float4 *top = nullptr, int top_n = 0) {
     // (2-wide records) the top of the LDS part of the stack, in case this step ends in a pop: see below
     const int spec_top = SHALLOW ? stack[max(sp - 1, 0) * kBlock] : stack[max(min(sp - 1, stack_cap - 1), 0) * kBlock];
-    float4 q0, q1, q2, q3, r0, r1, r2;  // (r*: the second record of a 4-wide node; its link word is not needed: see q3)
-    if (top_n > 0 && cur < top_n) {
+    // 2-wide: one 64-byte record, q0..q3.  4-wide: the node's 128 bytes are laid out BY PLANE (upload_node_records): per axis a
+    // 16-byte word with the four children's lower bounds and one with their upper bounds, then the four links.  Which of the two
+    // is the NEAR plane of an axis depends on the sign of 1 / d alone, so each lane fetches near and far planes by address
+    // (word index 2 * axis + sign, and the other one) and the slab test needs no min / max per axis: 24 instructions fewer per
+    // node step than sorting each pair of distances.  n*: near planes, f*: far planes, q3: links.
+    float4 q0, q1, q2, q3, nx, ny, nz, fx, fy, fz;
+    if (WIDE) {
+        const unsigned bx = (__float_as_uint(inv.x) >> 27) & 16u, by = (__float_as_uint(inv.y) >> 27) & 16u,
+                       bz = (__float_as_uint(inv.z) >> 27) & 16u;  // 16 where 1 / d is negative: the upper bound is the near one
+        if (top_n > 0 && cur < top_n) {
+            const char *q = (const char *)(top + 4 * cur);
+            nx = *(const float4 *)(q + bx);
+            fx = *(const float4 *)(q + (bx ^ 16u));
+            ny = *(const float4 *)(q + 32 + by);
+            fy = *(const float4 *)(q + 32 + (by ^ 16u));
+            nz = *(const float4 *)(q + 64 + bz);
+            fz = *(const float4 *)(q + 64 + (bz ^ 16u));
+            q3 = *(const float4 *)(q + 96);
+            __asm__ volatile("" ::: "memory");  // (keeps the two branches apart: see below)
+        } else {
+            const char *q = (const char *)sc.nodes;
+            const unsigned base = (unsigned)cur << 6;
+            nx = *(const float4 *)(q + (base | bx));
+            fx = *(const float4 *)(q + ((base | bx) ^ 16u));
+            ny = *(const float4 *)(q + ((base | by) + 32u));
+            fy = *(const float4 *)(q + (((base | by) ^ 16u) + 32u));
+            nz = *(const float4 *)(q + ((base | bz) + 64u));
+            fz = *(const float4 *)(q + (((base | bz) ^ 16u) + 64u));
+            q3 = *(const float4 *)(q + (base + 96u));
+        }
+        q0 = q1 = q2 = q3;  // (unused in this form)
+    } else if (top_n > 0 && cur < top_n) {
         const float4 *q = top + 4 * cur;
         q0 = q[0];
         q1 = q[1];
         q2 = q[2];
         q3 = q[3];
-        if (WIDE) {  // (the links of children 2, 3 ride in the spare half of q3: seven 16-byte loads per node, not eight)
-            r0 = q[4];
-            r1 = q[5];
-            r2 = q[6];
-        }
         // keeps the two branches apart: merged into a select of pointers they become FLAT loads, which go
         // through the texture addresser like any global load and make the LDS copy pointless
         __asm__ volatile("" ::: "memory");
+        nx = ny = nz = fx = fy = fz = q0;
     } else {
         const float4 *q = (const float4 *)((const char *)sc.nodes + ((unsigned)cur << 6));
         q0 = q[0];
         q1 = q[1];
         q2 = q[2];
         q3 = q[3];
-        if (WIDE) {  // (the links of children 2, 3 ride in the spare half of q3: seven 16-byte loads per node, not eight)
-            r0 = q[4];
-            r1 = q[5];
-            r2 = q[6];
-        }
+        nx = ny = nz = fx = fy = fz = q0;
     }
     if (!WIDE) {
         // 2-wide record: two exact boxes, near child first, far child onto the stack.  The bounds of the two
@@ -988,28 +1010,28 @@ __device__ __forceinline__ void inner_step(const DScene &sc, V3 o, V3 inv, float
         // instead of three and their scalar ANDs (tmax >= 0 always)
         // plane distance = b * (1 / d) + s, s = -o * (1 / d): ONE packed fma per pair of planes where (b - o) * (1 / d) takes
         // two instructions.  s is rounded on its own, which moves the planes of an axis by up to 2^-24 |o| as the ray sees
-        // them: the records are padded for that (rt_bvh.h, pad_quads_for_origins; ensure_origin_radius on the host)
+        // them: the records are padded for that (rt_bvh.h, pad_quads_for_origins; ensure_origin_radius on the host).
+        // Near and far planes were picked by the sign of 1 / d when they were fetched: monotone rounding makes the near
+        // plane's distance the smaller of the two, the very value min() would pick.
         const v2f sx = {-o.x * inv.x, -o.x * inv.x}, sy = {-o.y * inv.y, -o.y * inv.y}, sz = {-o.z * inv.z, -o.z * inv.z};
-        (void)ox; (void)oy; (void)oz;
+        (void)ox; (void)oy; (void)oz; (void)q0; (void)q1; (void)q2;
 #define RT_SLAB(b, i, s_) __builtin_elementwise_fma((b), (i), (s_))
         {
-            v2f ax = RT_SLAB((v2f{q0.x, q0.y}), ix, sx), ay = RT_SLAB((v2f{q0.z, q0.w}), iy, sy), az = RT_SLAB((v2f{q1.x, q1.y}), iz, sz);
-            v2f bx = RT_SLAB((v2f{q1.z, q1.w}), ix, sx), by = RT_SLAB((v2f{q2.x, q2.y}), iy, sy), bz = RT_SLAB((v2f{q2.z, q2.w}), iz, sz);
-            e[0] = fmaxf(fmaxf(fminf(ax.x, bx.x), fminf(ay.x, by.x)), fminf(az.x, bz.x));
-            e[1] = fmaxf(fmaxf(fminf(ax.y, bx.y), fminf(ay.y, by.y)), fminf(az.y, bz.y));
-            v2f t_out = {fminf(fminf(fmaxf(ax.x, bx.x), fmaxf(ay.x, by.x)), fmaxf(az.x, bz.x)),
-                         fminf(fminf(fmaxf(ax.y, bx.y), fmaxf(ay.y, by.y)), fmaxf(az.y, bz.y))};
+            const v2f tnx = RT_SLAB((v2f{nx.x, nx.y}), ix, sx), tny = RT_SLAB((v2f{ny.x, ny.y}), iy, sy), tnz = RT_SLAB((v2f{nz.x, nz.y}), iz, sz);
+            const v2f tfx = RT_SLAB((v2f{fx.x, fx.y}), ix, sx), tfy = RT_SLAB((v2f{fy.x, fy.y}), iy, sy), tfz = RT_SLAB((v2f{fz.x, fz.y}), iz, sz);
+            e[0] = fmaxf(fmaxf(tnx.x, tny.x), tnz.x);
+            e[1] = fmaxf(fmaxf(tnx.y, tny.y), tnz.y);
+            v2f t_out = {fminf(fminf(tfx.x, tfy.x), tfz.x), fminf(fminf(tfx.y, tfy.y), tfz.y)};
             t_out = t_out * v2f{1.000001f, 1.000001f};
             h[0] = fmaxf(e[0], 0.f) <= fminf(t_out.x, tmax_w);
             h[1] = fmaxf(e[1], 0.f) <= fminf(t_out.y, tmax_w);
         }
         {
-            v2f ax = RT_SLAB((v2f{r0.x, r0.y}), ix, sx), ay = RT_SLAB((v2f{r0.z, r0.w}), iy, sy), az = RT_SLAB((v2f{r1.x, r1.y}), iz, sz);
-            v2f bx = RT_SLAB((v2f{r1.z, r1.w}), ix, sx), by = RT_SLAB((v2f{r2.x, r2.y}), iy, sy), bz = RT_SLAB((v2f{r2.z, r2.w}), iz, sz);
-            e[2] = fmaxf(fmaxf(fminf(ax.x, bx.x), fminf(ay.x, by.x)), fminf(az.x, bz.x));
-            e[3] = fmaxf(fmaxf(fminf(ax.y, bx.y), fminf(ay.y, by.y)), fminf(az.y, bz.y));
-            v2f t_out = {fminf(fminf(fmaxf(ax.x, bx.x), fmaxf(ay.x, by.x)), fmaxf(az.x, bz.x)),
-                         fminf(fminf(fmaxf(ax.y, bx.y), fmaxf(ay.y, by.y)), fmaxf(az.y, bz.y))};
+            const v2f tnx = RT_SLAB((v2f{nx.z, nx.w}), ix, sx), tny = RT_SLAB((v2f{ny.z, ny.w}), iy, sy), tnz = RT_SLAB((v2f{nz.z, nz.w}), iz, sz);
+            const v2f tfx = RT_SLAB((v2f{fx.z, fx.w}), ix, sx), tfy = RT_SLAB((v2f{fy.z, fy.w}), iy, sy), tfz = RT_SLAB((v2f{fz.z, fz.w}), iz, sz);
+            e[2] = fmaxf(fmaxf(tnx.x, tny.x), tnz.x);
+            e[3] = fmaxf(fmaxf(tnx.y, tny.y), tnz.y);
+            v2f t_out = {fminf(fminf(tfx.x, tfy.x), tfz.x), fminf(fminf(tfx.y, tfy.y), tfz.y)};
             t_out = t_out * v2f{1.000001f, 1.000001f};
             h[2] = fmaxf(e[2], 0.f) <= fminf(t_out.x, tmax_w);
             h[3] = fmaxf(e[3], 0.f) <= fminf(t_out.y, tmax_w);
@@ -2657,13 +2679,13 @@ bool validate_pairs(const std::vector<rtbvh::Pair> &pairs, int n_tris) {
 // The same for the 4-wide format (two consecutive records per node; inner links are even record indices), plus the
 // invariant the kernels' box test rests on: a child is absent (link kNoChild) if and only if its box is all +inf -- the
 // one-comparison slab test of inner_step<true> never looks at links.
-// Device layout of a 64-byte record: the two children's bounds INTERLEAVED --
+// Device layout.  2-wide: a 64-byte record with the two children's bounds INTERLEAVED --
 //   (l.lo.x, r.lo.x, l.lo.y, r.lo.y | l.lo.z, r.lo.z, l.hi.x, r.hi.x | l.hi.y, r.hi.y, l.hi.z, r.hi.z | llink, rlink, spare, spare)
 // -- so that every (left, right) pair of bounds arrives in an aligned register pair and the slab arithmetic of both children
-// runs as packed fp32, see inner_step.  4-wide: a node is two such records back to back (children 0, 1 | children 2, 3:
-// rt_bvh.h `quads`), padded for ray origins within `radius` (pad_quads_for_origins), and the links of children 2, 3 ride ALSO
-// in the spare words of the first record, so that a node step loads seven 16-byte words instead of eight (a divergent
-// wave-wide load occupies the CU's texture addresser for about a cycle per active lane: profiles/r05_gather_rate.txt).
+// runs as packed fp32, see inner_step.  4-wide: a node (two builder records: children 0, 1 | children 2, 3, rt_bvh.h `quads`,
+// padded for ray origins within `radius`: pad_quads_for_origins) is 128 bytes laid out BY PLANE -- see below and inner_step:
+// a node step loads seven 16-byte words (a divergent wave-wide load occupies the CU's texture addresser for about a cycle
+// per active lane: profiles/r05_gather_rate.txt) and picks near and far planes by address instead of by min / max.
 int upload_node_records(const rt_scene *sc, const std::vector<rtbvh::Pair> &base, const float radius[3]) {
     std::vector<rtbvh::Pair> padded;
     const std::vector<rtbvh::Pair> *recs = &base;
@@ -2673,22 +2695,36 @@ int upload_node_records(const rt_scene *sc, const std::vector<rtbvh::Pair> &base
     }
     if ((size_t)sc->n_nodes != recs->size()) return fail("upload_node_records: record count changed");
     std::vector<float> inter(16 * recs->size());
-    for (size_t k = 0; k < recs->size(); k++) {
-        const rtbvh::Pair &pr = (*recs)[k];
-        float *r = &inter[16 * k];
-        for (int a = 0; a < 6; a++) {
-            r[2 * a] = pr.lbox[a];
-            r[2 * a + 1] = pr.rbox[a];
+    if (!sc->wide) {
+        for (size_t k = 0; k < recs->size(); k++) {
+            const rtbvh::Pair &pr = (*recs)[k];
+            float *r = &inter[16 * k];
+            for (int a = 0; a < 6; a++) {
+                r[2 * a] = pr.lbox[a];
+                r[2 * a + 1] = pr.rbox[a];
+            }
+            memcpy(&r[12], &pr.llink, 4);
+            memcpy(&r[13], &pr.rlink, 4);
+            r[14] = r[15] = 0.f;
         }
-        memcpy(&r[12], &pr.llink, 4);
-        memcpy(&r[13], &pr.rlink, 4);
-        r[14] = r[15] = 0.f;
+    } else {
+        // 4-wide node j = builder records 2j (children 0, 1) and 2j + 1 (children 2, 3) -> 128 bytes BY PLANE:
+        //   word 2a: the four children's lower bounds of axis a, word 2a + 1: their upper bounds (a = x, y, z), word 6: the
+        //   four links, word 7: spare
+        for (size_t j = 0; 2 * j + 1 < recs->size(); j++) {
+            const rtbvh::Pair &p0 = (*recs)[2 * j], &p1 = (*recs)[2 * j + 1];
+            const float *box[4] = {p0.lbox, p0.rbox, p1.lbox, p1.rbox};
+            const int32_t link[4] = {p0.llink, p0.rlink, p1.llink, p1.rlink};
+            float *r = &inter[32 * j];
+            for (int a = 0; a < 3; a++)
+                for (int c = 0; c < 4; c++) {
+                    r[8 * a + c] = box[c][a];
+                    r[8 * a + 4 + c] = box[c][3 + a];
+                }
+            memcpy(&r[24], link, 16);
+            r[28] = r[29] = r[30] = r[31] = 0.f;
+        }
     }
-    if (sc->wide)
-        for (size_t k = 0; k + 1 < recs->size(); k += 2) {
-            inter[16 * k + 14] = inter[16 * (k + 1) + 12];
-            inter[16 * k + 15] = inter[16 * (k + 1) + 13];
-        }
     HIP_TRY(hipMemcpy(sc->d_nodes, inter.data(), 64 * (size_t)sc->n_nodes, hipMemcpyHostToDevice));
     for (int a = 0; a < 3; a++) sc->origin_radius[a] = radius[a];
     return 0;
