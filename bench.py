@@ -679,7 +679,7 @@ def main():
             out["scaling_modes"] = {
                 "value": "THE PARITY MODE: the reference's per-slot XORWOW streams, slot-range shards -- the N-GPU image is the 1-GPU image "
                          "(event totals above: equal to the committed literal-oracle totals).  A slot's camera rays are sequential, so a "
-                         "1/8 shard is 2 waves per SIMD whatever the kernel: predicted 4.2x at 8 GPUs, ceiling 4.4x (DESIGN section 6)",
+                         "1/8 shard is 2 waves per SIMD whatever the kernel: predicted 4.1x at 8 GPUs, ceiling 4.2x (DESIGN section 6)",
                 "per_sample.value": "NOT a parity mode (one stream per camera ray: a statistically equivalent image, exactly "
                                     "partition-invariant sums): every rank runs all 2^20 slots on spp / N samples -- the mode expected to "
                                     "meet the north star's >= 6x at 8 GPUs (predicted 7.3x)"}
